@@ -1,0 +1,109 @@
+"""ctypes binding of libe2eft.so (include/e2eft.h).  Fails loudly when the library is missing: there is no
+PyTorch / CPU fallback for the compute path."""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first so that libamdhip64.so.7 is torch's copy)
+
+from . import build as _build
+
+_LIB = None
+
+F32, F16, BF16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+
+def dtype_id(dt):
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError("libe2eft supports float32/float16/bfloat16, got %s" % dt)
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "batch", "hin", "win", "hl", "wl", "c1", "ldx1", "c2", "ldx2", "kh", "kw", "stride", "pad_t", "pad_l",
+        "hout", "wout", "cout", "ldo", "ldr", "ldw")] + [("alpha", C.c_float)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("dtype", "m", "n", "k", "lda", "ldw", "ldo", "ldr", "nzo", "nzi")]
+                + [(n, C.c_int64) for n in ("sa_o", "sa_i", "sw_o", "sw_i", "so_o", "so_i", "sr_o", "sr_i")]
+                + [("bias_along_m", C.c_int32), ("alpha", C.c_float)])
+
+
+class GroupNormDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "batch", "hw", "c1", "ldx1", "c2", "ldx2", "groups", "ldy", "silu")] + [
+        ("eps", C.c_float)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "batch", "heads", "nq", "nk_seg", "kv_nseg", "kv_bmod", "ldq", "ldk", "ldv",
+                                          "ldo")] + [("scale", C.c_float)]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_L = C.c_int64
+_F = C.c_float
+_Z = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol declared in include/e2eft.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "e2eft_version": (_I, []),
+    "e2eft_last_error": (C.c_char_p, []),
+    "e2eft_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "e2eft_gemm": (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P]),
+    "e2eft_groupnorm_workspace_bytes": (_Z, [C.POINTER(GroupNormDesc)]),
+    "e2eft_groupnorm_fwd": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "e2eft_layernorm_fwd": (_I, [_I, _L, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
+    "e2eft_geglu_fwd": (_I, [_I, _L, _I, _I, _I, _P, _P, _P]),
+    "e2eft_softmax_rows": (_I, [_I, _L, _I, _L, _F, _P, _P]),
+    "e2eft_attn_fwd": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
+    "e2eft_nchw_to_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "e2eft_nhwc_to_nchw": (_I, [_I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "e2eft_copy_scale": (_I, [_I, _L, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "e2eft_add": (_I, [_I, _L, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "e2eft_timestep_embedding": (_I, [_I, _I, _I, _P, _P, _P]),
+    "e2eft_silu": (_I, [_I, _L, _P, _P, _P]),
+    "e2eft_depth_head": (_I, [_I, _I, _L, _I, _I, _P, _P, _P]),
+    "e2eft_normal_head": (_I, [_I, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "e2eft_ssi_loss_workspace_bytes": (_Z, [_I]),
+    "e2eft_ssi_loss_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "e2eft_angular_loss_workspace_bytes": (_Z, [_I]),
+    "e2eft_angular_loss_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+}
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building if the sources are newer and hipcc is available) and type the library."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # no hipcc on this box and no prebuilt library
+            raise RuntimeError(
+                "libe2eft.so is missing (%s) and could not be built: %s. The HIP extension is mandatory; "
+                "run `python -c 'import __graft_entry__ as g; g.build()'` on a box with ROCm." % (path, e))
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.e2eft_version() < 100:
+        raise RuntimeError("libe2eft.so is stale (version %d)" % lib.e2eft_version())
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().e2eft_last_error()
+        raise RuntimeError("libe2eft error %d: %s" % (rc, msg.decode() if msg else "?"))

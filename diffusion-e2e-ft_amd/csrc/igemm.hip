@@ -1,0 +1,337 @@
+// igemm.hip — implicit-GEMM convolution / NT-GEMM on MFMA for gfx950 (MI355X).
+//
+//   out[m, n] = alpha * ( sum_k A[m, k] * W[n, k] + bias + rowadd[img(m), n] ) + residual[m, n]
+//
+// One kernel family serves every dense contraction of the path: conv3x3 (s1/s2, symmetric or
+// VAE-asymmetric padding, fused nearest upsample, fused channel concat of two sources), conv1x1, nn.Linear and
+// the batched attention matmuls of the unfused path.
+//
+// Design (CDNA4): 128x128 output tile per 256-thread workgroup (4 waves, 2x2, each wave 64x64 = 2x2 MFMA 32x32
+// tiles, fp32 accumulators in registers).  One k-tile is 128 BYTES of K per row (64 halves / 32 floats), staged
+// global -> registers -> LDS (16-byte vector loads, the im2col gather and the zero padding happen in the load),
+// LDS rows padded 128 -> 144 bytes so that ds_read_b128 fragment reads are bank-conflict free, two LDS buffers
+// with the next tile's global loads in flight under the current tile's MFMAs (one barrier per k-tile).
+// MFMA: v_mfma_f32_32x32x16_{f16,bf16} for 16-bit data; v_mfma_f32_32x32x2_f32 (exact fp32) for the strict-fp32
+// parity path.  blockIdx -> tile mapping is XCD-aware (bijective remap) so that the N-tiles sharing one A panel
+// run on the same XCD's L2.
+#include "common.h"
+
+namespace e2eft {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 128;        // data bytes per LDS row = one k-tile
+constexpr int ROWS = ROWB + 16;  // padded LDS row stride (bytes)
+constexpr int TILE_BYTES = 128 * ROWS;
+
+struct IgemmParams {
+    const void* x1;
+    const void* x2;
+    const void* w;
+    const void* bias;
+    const void* rowadd;
+    const void* residual;
+    void* out;
+    int M, N, K;
+    int ldx1, ldx2, c1, cin;
+    int hin, win, hl, wl, kh, kw, stride, pad_t, pad_l, hout, wout;
+    float up_sh, up_sw;
+    int ldw, ldr, ldo;
+    int bias_along_m;
+    int rows_per_img;
+    float alpha;
+    int nzi;
+    long sa_o, sa_i, sw_o, sw_i, so_o, so_i, sr_o, sr_i;
+    int mtiles, ntiles;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<f16> {
+    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16> {
+    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bhalf8, a), __builtin_bit_cast(bhalf8, b), c, 0, 0, 0);
+    }
+};
+
+// MODE 0: A rows are plain (GEMM / 1x1 conv); MODE 1: im2col gather.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    constexpr int EPC = 16 / (int)sizeof(T);    // elements per 16-byte chunk
+    constexpr int BK = ROWB / (int)sizeof(T);   // k elements per tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // ---- XCD-aware tile mapping (bijective) ----
+    const int nblk = p.mtiles * p.ntiles;
+    int lid;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = lid / p.ntiles, nt = lid - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int z = blockIdx.y;
+    const int zo = z / p.nzi, zi = z - zo * p.nzi;
+
+    const T* __restrict__ X1 = (const T*)p.x1 + zo * p.sa_o + zi * p.sa_i;
+    const T* __restrict__ X2 = (const T*)p.x2;
+    const T* __restrict__ W = (const T*)p.w + zo * p.sw_o + zi * p.sw_i;
+
+    // ---- per-thread loader state: 4 rows (r0 + 32 i), one 16-byte k-chunk column kc ----
+    const int kc = tid & 7;
+    const int r0 = tid >> 3;
+    long a_base[4];      // MODE 0: element offset of the row; MODE 1: image index b
+    int a_iy0[4], a_ix0[4];
+    bool a_ok[4];
+    long w_base[4];
+    bool w_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        a_ok[i] = m < p.M;
+        if (MODE == 0) {
+            a_base[i] = (long)m * p.ldx1;
+            a_iy0[i] = a_ix0[i] = 0;
+        } else {
+            const int hw = p.hout * p.wout;
+            const int mm = a_ok[i] ? m : 0;
+            const int b = mm / hw;
+            const int rem = mm - b * hw;
+            const int oy = rem / p.wout, ox = rem - oy * p.wout;
+            a_base[i] = b;
+            a_iy0[i] = oy * p.stride - p.pad_t;
+            a_ix0[i] = ox * p.stride - p.pad_l;
+        }
+        const int n = n0 + r0 + 32 * i;
+        w_ok[i] = n < p.N;
+        w_base[i] = (long)n * p.ldw;
+    }
+
+    u32x4 ra[4], rb[4];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kc * EPC;
+        const bool kok = k < p.K;
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                ra[i] = (kok && a_ok[i]) ? *reinterpret_cast<const u32x4*>(X1 + a_base[i] + k) : zero4;
+        } else {
+            const int kpos = k / p.cin;
+            const int c = k - kpos * p.cin;
+            const int ky = kpos / p.kw, kx = kpos - ky * p.kw;
+            const bool second = c >= p.c1;
+            const T* src = second ? X2 : X1;
+            const int ld = second ? p.ldx2 : p.ldx1;
+            const int cc = second ? c - p.c1 : c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                const bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
+                int sy = iy, sx = ix;
+                if (p.hl != p.hin) sy = min((int)floorf(iy * p.up_sh), p.hin - 1);
+                if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
+                const long pix = (a_base[i] * p.hin + sy) * p.win + sx;
+                ra[i] = ok ? *reinterpret_cast<const u32x4*>(src + pix * ld + cc) : zero4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rb[i] = (kok && w_ok[i]) ? *reinterpret_cast<const u32x4*>(W + w_base[i] + k) : zero4;
+    };
+    auto store_tile = [&](int buf) {
+        char* sa = smem + buf * 2 * TILE_BYTES;
+        char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = (r0 + 32 * i) * ROWS + kc * 16;
+            *reinterpret_cast<u32x4*>(sa + off) = ra[i];
+            *reinterpret_cast<u32x4*>(sb + off) = rb[i];
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * 2 * TILE_BYTES + (wm * 64 + l31) * ROWS;
+        const char* sb = smem + buf * 2 * TILE_BYTES + TILE_BYTES + (wn * 64 + l31) * ROWS;
+        if constexpr (sizeof(T) == 2) {
+            // 4 k-steps of 16; lane half h holds k = 8h..8h+7 of each step
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = ks * 32 + h * 16;
+                u32x4 a0 = *reinterpret_cast<const u32x4*>(sa + off);
+                u32x4 a1 = *reinterpret_cast<const u32x4*>(sa + 32 * ROWS + off);
+                u32x4 b0 = *reinterpret_cast<const u32x4*>(sb + off);
+                u32x4 b1 = *reinterpret_cast<const u32x4*>(sb + 32 * ROWS + off);
+                acc[0][0] = Mma<T>::run(a0, b0, acc[0][0]);
+                acc[0][1] = Mma<T>::run(a0, b1, acc[0][1]);
+                acc[1][0] = Mma<T>::run(a1, b0, acc[1][0]);
+                acc[1][1] = Mma<T>::run(a1, b1, acc[1][1]);
+            }
+        } else {
+            // fp32: 32 k per tile; MFMA 32x32x2 step s pairs k = s (lanes 0-31) with k = 16 + s (lanes 32-63);
+            // the same slot permutation is applied to A and W so the sum is the plain dot product.
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int off = h * 64 + qd * 16;
+                floatx4 a0 = *reinterpret_cast<const floatx4*>(sa + off);
+                floatx4 a1 = *reinterpret_cast<const floatx4*>(sa + 32 * ROWS + off);
+                floatx4 b0 = *reinterpret_cast<const floatx4*>(sb + off);
+                floatx4 b1 = *reinterpret_cast<const floatx4*>(sb + 32 * ROWS + off);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tile(kt + 1);
+        compute(cur);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias / per-image row vector / alpha / residual, direct stores ----
+    const T* __restrict__ bias = (const T*)p.bias;
+    const T* __restrict__ rowadd = (const T*)p.rowadd;
+    const T* __restrict__ res = p.residual ? (const T*)p.residual + zo * p.sr_o + zi * p.sr_i : nullptr;
+    T* __restrict__ out = (T*)p.out + zo * p.so_o + zi * p.so_i;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (n >= p.N) continue;
+        const float bn = (bias && !p.bias_along_m) ? to_f(bias[n]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bn;
+                if (bias && p.bias_along_m) v += to_f(bias[m]);
+                if (rowadd) v += to_f(rowadd[(long)(m / p.rows_per_img) * p.N + n]);
+                v *= p.alpha;
+                if (res) v += to_f(res[(long)m * p.ldr + n]);
+                out[(long)m * p.ldo + n] = from_f<T>(v);
+            }
+        }
+    }
+}
+
+template <typename T, int MODE> static int launch_igemm(const IgemmParams& p, int nz, hipStream_t s) {
+    dim3 grid(p.mtiles * p.ntiles, nz, 1);
+    hipLaunchKernelGGL((igemm_kernel<T, MODE>), grid, dim3(256), 0, s, p);
+    return check_launch("igemm");
+}
+
+static int run_igemm(int dtype, int mode, IgemmParams& p, int nz, void* stream) {
+    p.mtiles = cdiv(p.M, BM);
+    p.ntiles = cdiv(p.N, BN);
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return fail(E2EFT_ERR_BAD_ARG, "igemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+    if ((long)p.mtiles * p.ntiles > 2000000000L) return fail(E2EFT_ERR_BAD_ARG, "igemm: grid too large");
+    if (nz > 65535) return fail(E2EFT_ERR_BAD_ARG, "igemm: batch %d > 65535", nz);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == E2EFT_F32) return mode ? launch_igemm<float, 1>(p, nz, s) : launch_igemm<float, 0>(p, nz, s);
+    if (dtype == E2EFT_F16) return mode ? launch_igemm<f16, 1>(p, nz, s) : launch_igemm<f16, 0>(p, nz, s);
+    if (dtype == E2EFT_BF16) return mode ? launch_igemm<bf16, 1>(p, nz, s) : launch_igemm<bf16, 0>(p, nz, s);
+    return fail(E2EFT_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
+}
+
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace e2eft
+
+using namespace e2eft;
+
+extern "C" int e2eft_conv2d_fwd(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w,
+                                const void* bias, const void* rowadd, const void* residual, void* out, void* stream) {
+    E2EFT_REQUIRE(d && x1 && w && out, "conv2d: null pointer");
+    const int epc = 16 / (int)dtype_size(d->dtype);
+    const int cin = d->c1 + d->c2;
+    E2EFT_REQUIRE(d->dtype >= 0 && d->dtype <= 2, "conv2d: bad dtype %d", d->dtype);
+    E2EFT_REQUIRE(d->batch > 0 && d->hin > 0 && d->win > 0 && d->hout > 0 && d->wout > 0 && d->cout > 0, "conv2d: bad geometry");
+    E2EFT_REQUIRE(d->c1 > 0 && d->c1 % epc == 0 && d->c2 >= 0 && d->c2 % epc == 0, "conv2d: channels (%d,%d) must be multiples of %d", d->c1, d->c2, epc);
+    E2EFT_REQUIRE(d->ldx1 >= d->c1 && d->ldx1 % epc == 0, "conv2d: ldx1=%d", d->ldx1);
+    E2EFT_REQUIRE(d->c2 == 0 || (x2 && d->ldx2 >= d->c2 && d->ldx2 % epc == 0), "conv2d: second source");
+    E2EFT_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0, "conv2d: kernel/stride");
+    E2EFT_REQUIRE(d->ldw >= d->kh * d->kw * cin && d->ldw % epc == 0, "conv2d: ldw=%d", d->ldw);
+    E2EFT_REQUIRE(d->ldo >= d->cout, "conv2d: ldo=%d < cout=%d", d->ldo, d->cout);
+    E2EFT_REQUIRE(d->hl >= d->hin && d->wl >= d->win, "conv2d: logical size smaller than physical");
+    E2EFT_REQUIRE(al16(x1) && al16(w) && (d->c2 == 0 || al16(x2)), "conv2d: pointers must be 16-byte aligned");
+    E2EFT_REQUIRE((long)d->batch * d->hout * d->wout < 2147483647L, "conv2d: M overflows int32");
+    // the last output row/col must read at least one in-range tap row/col origin
+    E2EFT_REQUIRE((d->hout - 1) * d->stride - d->pad_t < d->hl && (d->wout - 1) * d->stride - d->pad_l < d->wl, "conv2d: output larger than padded input");
+
+    IgemmParams p = {};
+    p.x1 = x1; p.x2 = x2; p.w = w; p.bias = bias; p.rowadd = rowadd; p.residual = residual; p.out = out;
+    p.M = d->batch * d->hout * d->wout;
+    p.N = d->cout;
+    p.K = d->kh * d->kw * cin;
+    p.ldx1 = d->ldx1; p.ldx2 = d->ldx2; p.c1 = d->c1; p.cin = cin;
+    p.hin = d->hin; p.win = d->win; p.hl = d->hl; p.wl = d->wl;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.hout = d->hout; p.wout = d->wout;
+    p.up_sh = (float)d->hin / (float)d->hl;
+    p.up_sw = (float)d->win / (float)d->wl;
+    p.ldw = d->ldw; p.ldr = d->ldr; p.ldo = d->ldo;
+    p.bias_along_m = 0;
+    p.rows_per_img = d->hout * d->wout;
+    p.alpha = d->alpha;
+    p.nzi = 1;
+    const bool plain = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->c2 == 0 &&
+                       d->hl == d->hin && d->wl == d->win && d->hout == d->hin && d->wout == d->win;
+    return run_igemm(d->dtype, plain ? 0 : 1, p, 1, stream);
+}
+
+extern "C" int e2eft_gemm(const E2eftGemmDesc* d, const void* a, const void* w, const void* bias,
+                          const void* residual, void* out, void* stream) {
+    E2EFT_REQUIRE(d && a && w && out, "gemm: null pointer");
+    E2EFT_REQUIRE(d->dtype >= 0 && d->dtype <= 2, "gemm: bad dtype %d", d->dtype);
+    const int epc = 16 / (int)dtype_size(d->dtype);
+    E2EFT_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0, "gemm: empty problem");
+    E2EFT_REQUIRE(d->k % epc == 0, "gemm: k=%d must be a multiple of %d", d->k, epc);
+    E2EFT_REQUIRE(d->lda >= d->k && d->lda % epc == 0 && d->ldw >= d->k && d->ldw % epc == 0, "gemm: lda=%d ldw=%d", d->lda, d->ldw);
+    E2EFT_REQUIRE(d->ldo >= d->n, "gemm: ldo=%d < n=%d", d->ldo, d->n);
+    E2EFT_REQUIRE(d->nzo >= 1 && d->nzi >= 1, "gemm: batch counts");
+    E2EFT_REQUIRE(d->sa_o % epc == 0 && d->sa_i % epc == 0 && d->sw_o % epc == 0 && d->sw_i % epc == 0, "gemm: batch strides must keep 16-byte alignment");
+    E2EFT_REQUIRE(al16(a) && al16(w), "gemm: pointers must be 16-byte aligned");
+    IgemmParams p = {};
+    p.x1 = a; p.x2 = nullptr; p.w = w; p.bias = bias; p.rowadd = nullptr; p.residual = residual; p.out = out;
+    p.M = d->m; p.N = d->n; p.K = d->k;
+    p.ldx1 = d->lda; p.c1 = d->k; p.cin = d->k;
+    p.ldw = d->ldw; p.ldr = d->ldr; p.ldo = d->ldo;
+    p.bias_along_m = d->bias_along_m;
+    p.rows_per_img = 1;
+    p.alpha = d->alpha;
+    p.nzi = d->nzi;
+    p.sa_o = d->sa_o; p.sa_i = d->sa_i; p.sw_o = d->sw_o; p.sw_i = d->sw_i;
+    p.so_o = d->so_o; p.so_i = d->so_i; p.sr_o = d->sr_o; p.sr_i = d->sr_i;
+    return run_igemm(d->dtype, 0, p, d->nzo * d->nzi, stream);
+}

@@ -1,0 +1,400 @@
+// norm.hip — GroupNorm(+SiLU), LayerNorm, row softmax, GEGLU for NHWC / token tensors (HBM-bound streams).
+//
+// GroupNorm over NHWC: a group's channels are a short contiguous run at every pixel, so reading "one group at a
+// time" would touch 8-160 bytes per 256-2560-byte pixel row.  Instead every workgroup streams whole pixel rows
+// with 16-byte loads (thread <-> fixed channel chunk), keeps per-CHANNEL shifted sums in registers
+// (pivot = first sample, so sum(x-p) / sum((x-p)^2) do not cancel), merges them to (n, mean, M2) triples with
+// Chan's formula, and a tiny second kernel merges channels x slabs into per-(image, group) statistics and folds
+// gamma/beta into a per-(image, channel) affine pair (a, d).  The apply kernel is then y = silu(a*x + d).
+#include "common.h"
+
+namespace e2eft {
+
+struct Triple {
+    float n, mean, m2;
+};
+__device__ __forceinline__ Triple merge(const Triple& A, const Triple& B) {
+    if (B.n == 0.f) return A;
+    if (A.n == 0.f) return B;
+    Triple r;
+    r.n = A.n + B.n;
+    const float delta = B.mean - A.mean;
+    const float f = B.n / r.n;
+    r.mean = A.mean + delta * f;
+    r.m2 = A.m2 + B.m2 + delta * delta * A.n * f;
+    return r;
+}
+
+struct GnGeom {
+    int batch, hw, c1, ldx1, c2, ldx2, C;
+    int nchunks, cpb, nchb, pl;  // chunks per row, chunks per block, channel blocks, pixel lanes per block
+    int nslabs, slab;            // pixel slabs per image and pixels per slab
+};
+
+// grid (nslabs, batch, nchb), block 256
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(GnGeom g, const T* __restrict__ x1, const T* __restrict__ x2,
+                                                         float* __restrict__ partial /* [B][nslabs][C][3] */) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    __shared__ float sm[256 * 8 * 3];
+    const int tid = threadIdx.x;
+    const int chl = tid % g.cpb, pl = tid / g.cpb;
+    const int ch = blockIdx.z * g.cpb + chl;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * g.slab;
+    const int p1 = min(p0 + g.slab, g.hw);
+    const bool active = pl < g.pl;
+    const int c = ch * EPC;
+    const T* src;
+    int ld;
+    if (c < g.c1) { src = x1 + c; ld = g.ldx1; } else { src = x2 + (c - g.c1); ld = g.ldx2; }
+    float piv[EPC], s[EPC], ss[EPC];
+    float n = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) piv[e] = s[e] = ss[e] = 0.f;
+    if (active) {
+        for (int pix = p0 + pl; pix < p1; pix += g.pl) {
+            Vec16<T> v = ld16(src + ((long)b * g.hw + pix) * ld);
+            if (n == 0.f) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) piv[e] = to_f(v.e[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float d = to_f(v.e[e]) - piv[e];
+                s[e] += d;
+                ss[e] += d * d;
+            }
+            n += 1.f;
+        }
+    }
+    // per-thread triples -> LDS [pl][chl][e]
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float mean = 0.f, m2 = 0.f;
+            if (n > 0.f) {
+                const float ds = s[e] / n;
+                mean = piv[e] + ds;
+                m2 = fmaxf(ss[e] - s[e] * ds, 0.f);
+            }
+            float* o = sm + ((pl * g.cpb + chl) * EPC + e) * 3;
+            o[0] = n; o[1] = mean; o[2] = m2;
+        }
+    }
+    __syncthreads();
+    // merge across pixel lanes: one thread per channel of this block
+    const int cblk = g.cpb * EPC;
+    for (int cc = tid; cc < cblk; cc += 256) {
+        Triple acc = {0.f, 0.f, 0.f};
+        for (int q = 0; q < g.pl; ++q) {
+            const float* o = sm + (q * cblk + cc) * 3;
+            Triple t = {o[0], o[1], o[2]};
+            acc = merge(acc, t);
+        }
+        const int cg = blockIdx.z * cblk + cc;
+        float* o = partial + (((long)b * g.nslabs + blockIdx.x) * g.C + cg) * 3;
+        o[0] = acc.n; o[1] = acc.mean; o[2] = acc.m2;
+    }
+}
+
+// grid (groups, batch), block 256: merge slabs x channels-of-group, write affine pairs
+template <typename T>
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GnGeom g, int groups, float eps, const float* __restrict__ partial,
+                                                          const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                          float* __restrict__ ad /* [B][C][2] */) {
+    __shared__ float sm[256 * 3];
+    const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = g.C / groups;
+    const int items = g.nslabs * cpg;
+    Triple acc = {0.f, 0.f, 0.f};
+    for (int it = tid; it < items; it += 256) {
+        const int sl = it / cpg, cc = it - sl * cpg;
+        const float* o = partial + (((long)b * g.nslabs + sl) * g.C + grp * cpg + cc) * 3;
+        Triple t = {o[0], o[1], o[2]};
+        acc = merge(acc, t);
+    }
+    sm[tid * 3] = acc.n; sm[tid * 3 + 1] = acc.mean; sm[tid * 3 + 2] = acc.m2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            Triple A = {sm[tid * 3], sm[tid * 3 + 1], sm[tid * 3 + 2]};
+            Triple B = {sm[(tid + st) * 3], sm[(tid + st) * 3 + 1], sm[(tid + st) * 3 + 2]};
+            Triple r = merge(A, B);
+            sm[tid * 3] = r.n; sm[tid * 3 + 1] = r.mean; sm[tid * 3 + 2] = r.m2;
+        }
+        __syncthreads();
+    }
+    const float mean = sm[1];
+    const float var = sm[2] / sm[0];
+    const float rstd = rsqrtf(var + eps);
+    for (int cc = tid; cc < cpg; cc += 256) {
+        const int c = grp * cpg + cc;
+        const float ga = gamma ? to_f(gamma[c]) : 1.f;
+        const float be = beta ? to_f(beta[c]) : 0.f;
+        const float a = rstd * ga;
+        ad[((long)b * g.C + c) * 2] = a;
+        ad[((long)b * g.C + c) * 2 + 1] = be - mean * a;
+    }
+}
+
+// grid (nslabs, batch, nchb)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnGeom g, int silu, int ldy, const T* __restrict__ x1,
+                                                       const T* __restrict__ x2, const float* __restrict__ ad, T* __restrict__ y) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int tid = threadIdx.x;
+    const int chl = tid % g.cpb, pl = tid / g.cpb;
+    if (pl >= g.pl) return;
+    const int ch = blockIdx.z * g.cpb + chl;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * g.slab;
+    const int p1 = min(p0 + g.slab, g.hw);
+    const int c = ch * EPC;
+    const T* src;
+    int ld;
+    if (c < g.c1) { src = x1 + c; ld = g.ldx1; } else { src = x2 + (c - g.c1); ld = g.ldx2; }
+    float a[EPC], d[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        a[e] = ad[((long)b * g.C + c + e) * 2];
+        d[e] = ad[((long)b * g.C + c + e) * 2 + 1];
+    }
+    for (int pix = p0 + pl; pix < p1; pix += g.pl) {
+        const long row = (long)b * g.hw + pix;
+        Vec16<T> v = ld16(src + row * ld);
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float t = fmaf(to_f(v.e[e]), a[e], d[e]);
+            if (silu) t = silu_f(t);
+            o.e[e] = from_f<T>(t);
+        }
+        st16(y + row * ldy + c, o);
+    }
+}
+
+static int gn_geom(const E2eftGroupNormDesc* d, GnGeom& g) {
+    const int epc = 16 / (int)dtype_size(d->dtype);
+    g.batch = d->batch; g.hw = d->hw; g.c1 = d->c1; g.ldx1 = d->ldx1; g.c2 = d->c2; g.ldx2 = d->ldx2;
+    g.C = d->c1 + d->c2;
+    g.nchunks = g.C / epc;
+    int nb = 1;
+    while (g.nchunks % nb != 0 || g.nchunks / nb > 256) ++nb;
+    g.nchb = nb;
+    g.cpb = g.nchunks / nb;
+    g.pl = 256 / g.cpb;
+    long ns = ((long)d->hw + (long)g.pl * 16 - 1) / ((long)g.pl * 16);
+    if (ns < 1) ns = 1;
+    if (ns > 1024) ns = 1024;
+    g.slab = (int)((d->hw + ns - 1) / ns);
+    g.nslabs = (d->hw + g.slab - 1) / g.slab;
+    return 0;
+}
+
+template <typename T>
+static int gn_run(const E2eftGroupNormDesc* d, const GnGeom& g, const void* x1, const void* x2, const void* gamma,
+                  const void* beta, void* y, void* ws, hipStream_t s) {
+    float* partial = (float*)ws;
+    float* ad = partial + (size_t)g.batch * g.nslabs * g.C * 3;
+    dim3 grid(g.nslabs, g.batch, g.nchb);
+    hipLaunchKernelGGL((gn_partial_kernel<T>), grid, dim3(256), 0, s, g, (const T*)x1, (const T*)x2, partial);
+    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(d->groups, g.batch), dim3(256), 0, s, g, d->groups, d->eps, partial,
+                       (const T*)gamma, (const T*)beta, ad);
+    hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(256), 0, s, g, d->silu, d->ldy, (const T*)x1, (const T*)x2, ad, (T*)y);
+    return check_launch("groupnorm");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers, exact two-pass statistics.
+template <typename T, int MAXI>
+__global__ __launch_bounds__(256) void layernorm_kernel(long rows, int c, int ldx, int ldy, float eps, const T* __restrict__ x,
+                                                        const T* __restrict__ gamma, const T* __restrict__ beta, T* __restrict__ y) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunks = c / EPC;
+    float v[MAXI][EPC];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nchunks) {
+            Vec16<T> t = ld16(x + row * ldx + ch * EPC);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { v[i][e] = to_f(t.e[e]); sum += v[i][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[i][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)c;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nchunks) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { const float dd = v[i][e] - mean; sq += dd * dd; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)c + eps);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nchunks) {
+            Vec16<T> ga = ld16(gamma + ch * EPC), be = ld16(beta + ch * EPC), o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>((v[i][e] - mean) * rstd * to_f(ga.e[e]) + to_f(be.e[e]));
+            st16(y + row * ldy + ch * EPC, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row softmax in place (block per row; the row is L2/L1 resident between the three sweeps).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(int n, long lds, float scale, T* __restrict__ s) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    __shared__ float red[8];
+    T* row = s + (long)blockIdx.x * lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nfull = n / EPC;
+    const float sc = scale * 1.4426950408889634f;  // work in base 2
+    float mx = -INFINITY;
+    for (int ch = tid; ch < nfull; ch += 256) {
+        Vec16<T> v = ld16(row + ch * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) mx = fmaxf(mx, to_f(v.e[e]));
+    }
+    for (int j = nfull * EPC + tid; j < n; j += 256) mx = fmaxf(mx, to_f(row[j]));
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // scale may be negative in principle; we assume scale > 0 (checked on the host)
+    const float mb = mx * sc;
+    float sum = 0.f;
+    for (int ch = tid; ch < nfull; ch += 256) {
+        Vec16<T> v = ld16(row + ch * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) sum += exp2f(fmaf(to_f(v.e[e]), sc, -mb));
+    }
+    for (int j = nfull * EPC + tid; j < n; j += 256) sum += exp2f(fmaf(to_f(row[j]), sc, -mb));
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    for (int ch = tid; ch < nfull; ch += 256) {
+        Vec16<T> v = ld16(row + ch * EPC), o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(exp2f(fmaf(to_f(v.e[e]), sc, -mb)) * inv);
+        st16(row + ch * EPC, o);
+    }
+    const int npad = (n + EPC - 1) / EPC * EPC;
+    for (int j = nfull * EPC + tid; j < npad; j += 256)
+        row[j] = j < n ? from_f<T>(exp2f(fmaf(to_f(row[j]), sc, -mb)) * inv) : from_f<T>(0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GEGLU gate
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_kernel(long rows, int c, int ldh, int ldy, const T* __restrict__ hbuf, T* __restrict__ y) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int cch = c / EPC;
+    const long total = rows * cch;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const long r = it / cch;
+        const int ch = (int)(it - r * cch);
+        Vec16<T> a = ld16(hbuf + r * ldh + ch * EPC), gt = ld16(hbuf + r * ldh + c + ch * EPC), o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(to_f(a.e[e]) * gelu_erf_f(to_f(gt.e[e])));
+        st16(y + r * ldy + ch * EPC, o);
+    }
+}
+
+}  // namespace e2eft
+
+using namespace e2eft;
+
+static int gn_validate(const E2eftGroupNormDesc* d) {
+    E2EFT_REQUIRE(d, "groupnorm: null desc");
+    E2EFT_REQUIRE(d->dtype >= 0 && d->dtype <= 2, "groupnorm: bad dtype");
+    const int epc = 16 / (int)dtype_size(d->dtype);
+    const int C = d->c1 + d->c2;
+    E2EFT_REQUIRE(d->batch > 0 && d->hw > 0 && d->groups > 0, "groupnorm: geometry");
+    E2EFT_REQUIRE(d->c1 > 0 && d->c1 % epc == 0 && d->c2 >= 0 && d->c2 % epc == 0, "groupnorm: channels (%d,%d) must be multiples of %d", d->c1, d->c2, epc);
+    E2EFT_REQUIRE(C % d->groups == 0, "groupnorm: %d channels not divisible by %d groups", C, d->groups);
+    E2EFT_REQUIRE(d->ldx1 >= d->c1 && d->ldx1 % epc == 0 && d->ldy >= C && d->ldy % epc == 0, "groupnorm: strides");
+    E2EFT_REQUIRE(d->c2 == 0 || (d->ldx2 >= d->c2 && d->ldx2 % epc == 0), "groupnorm: ldx2");
+    return 0;
+}
+
+extern "C" size_t e2eft_groupnorm_workspace_bytes(const E2eftGroupNormDesc* d) {
+    if (gn_validate(d)) return 0;
+    GnGeom g;
+    gn_geom(d, g);
+    return ((size_t)g.batch * g.nslabs * g.C * 3 + (size_t)g.batch * g.C * 2) * sizeof(float);
+}
+
+extern "C" int e2eft_groupnorm_fwd(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma,
+                                   const void* beta, void* y, void* workspace, size_t ws_bytes, void* stream) {
+    if (int e = gn_validate(d)) return e;
+    E2EFT_REQUIRE(x1 && y && workspace, "groupnorm: null pointer");
+    E2EFT_REQUIRE(d->c2 == 0 || x2, "groupnorm: x2 missing");
+    GnGeom g;
+    gn_geom(d, g);
+    const size_t need = ((size_t)g.batch * g.nslabs * g.C * 3 + (size_t)g.batch * g.C * 2) * sizeof(float);
+    if (ws_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "groupnorm: workspace %zu < %zu", ws_bytes, need);
+    E2EFT_REQUIRE(g.batch <= 65535 && g.nchb <= 65535, "groupnorm: grid");
+    E2EFT_DISPATCH_DTYPE(d->dtype, T, return gn_run<T>(d, g, x1, x2, gamma, beta, y, workspace, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int e2eft_layernorm_fwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldx, int32_t ldy, float eps,
+                                   const void* x, const void* gamma, const void* beta, void* y, void* stream) {
+    E2EFT_REQUIRE(x && gamma && beta && y, "layernorm: null pointer");
+    E2EFT_REQUIRE(dtype >= 0 && dtype <= 2, "layernorm: bad dtype");
+    const int epc = 16 / (int)dtype_size(dtype);
+    E2EFT_REQUIRE(rows > 0 && c > 0 && c % epc == 0 && ldx >= c && ldy >= c && ldx % epc == 0 && ldy % epc == 0, "layernorm: shape c=%d ldx=%d ldy=%d", c, ldx, ldy);
+    const int nchunks = c / epc;
+    E2EFT_REQUIRE(nchunks <= 64 * 8, "layernorm: c=%d too large", c);
+    const long nblk = (rows + 3) / 4;
+    E2EFT_REQUIRE(nblk < 2147483647L, "layernorm: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    const int iters = (nchunks + 63) / 64;
+#define LN_LAUNCH(T, MAXI) hipLaunchKernelGGL((layernorm_kernel<T, MAXI>), dim3((unsigned)nblk), dim3(256), 0, s, (long)rows, c, ldx, ldy, eps, (const T*)x, (const T*)gamma, (const T*)beta, (T*)y)
+    E2EFT_DISPATCH_DTYPE(dtype, T, {
+        if (iters <= 1) LN_LAUNCH(T, 1);
+        else if (iters <= 2) LN_LAUNCH(T, 2);
+        else if (iters <= 4) LN_LAUNCH(T, 4);
+        else LN_LAUNCH(T, 8);
+    });
+#undef LN_LAUNCH
+    return check_launch("layernorm");
+}
+
+extern "C" int e2eft_softmax_rows(int32_t dtype, int64_t rows, int32_t n, int64_t lds, float scale, void* sbuf, void* stream) {
+    E2EFT_REQUIRE(sbuf, "softmax: null pointer");
+    E2EFT_REQUIRE(dtype >= 0 && dtype <= 2, "softmax: bad dtype");
+    const int epc = 16 / (int)dtype_size(dtype);
+    E2EFT_REQUIRE(rows > 0 && rows < 2147483647L && n > 0 && lds >= (n + epc - 1) / epc * epc && lds % epc == 0, "softmax: shape n=%d lds=%ld", n, (long)lds);
+    E2EFT_REQUIRE(scale > 0.f, "softmax: scale must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    E2EFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3((unsigned)rows), dim3(256), 0, s, n, (long)lds, scale, (T*)sbuf));
+    return check_launch("softmax_rows");
+}
+
+extern "C" int e2eft_geglu_fwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldh, int32_t ldy, const void* h, void* y, void* stream) {
+    E2EFT_REQUIRE(h && y, "geglu: null pointer");
+    E2EFT_REQUIRE(dtype >= 0 && dtype <= 2, "geglu: bad dtype");
+    const int epc = 16 / (int)dtype_size(dtype);
+    E2EFT_REQUIRE(rows > 0 && c > 0 && c % epc == 0 && ldh >= 2 * c && ldh % epc == 0 && ldy >= c && ldy % epc == 0, "geglu: shape");
+    const long total = rows * (c / epc);
+    long nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    E2EFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((geglu_kernel<T>), dim3((unsigned)nb), dim3(256), 0, s, (long)rows, c, ldh, ldy, (const T*)h, (T*)y));
+    return check_launch("geglu");
+}

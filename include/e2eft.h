@@ -1,0 +1,203 @@
+/*
+ * e2eft.h — C ABI of libe2eft.so: the MI355X (gfx950) kernels behind the single-step
+ * Marigold / GeoWizard denoising path.
+ *
+ * The reference (VisualComputingInstitute/diffusion-e2e-ft) is pure Python; the arithmetic of its hot path
+ * is executed by torch/diffusers leaf modules.  Each entry point below replaces one op class that those leaf
+ * modules dispatch (reference call sites are cited per function, paths relative to /root/reference).
+ *
+ * Conventions
+ *   - Every function returns 0 on success or an E2EFT_ERR_* code; e2eft_last_error() gives the message
+ *     (thread-local).  Nothing throws, nothing aborts.
+ *   - The caller owns ALL device memory (inputs, outputs, workspaces).  The library allocates nothing on
+ *     the device, keeps no pointers after return and never synchronises the host: every kernel is enqueued
+ *     on the hipStream_t passed as `void* stream` (0 = the legacy default stream).
+ *   - Activations are NHWC ("channels_last"): element (b,y,x,c) of a [B,H,W,C] tensor lives at
+ *     ((b*H + y)*W + x)*ld + c, where the pixel stride `ld` >= C lets a tensor be a channel slice of a wider
+ *     buffer (zero-copy concat).  Token tensors [B,N,C] are the same thing with H*W = N.
+ *   - dtype is one of E2EFT_F32 / E2EFT_F16 / E2EFT_BF16 for all tensors of a call; accumulation, statistics
+ *     and softmax are always fp32.
+ *   - Alignment: all base pointers 16-byte aligned; channel counts and pixel strides multiples of
+ *     16 bytes / sizeof(dtype) unless a function says otherwise.
+ */
+#ifndef E2EFT_H
+#define E2EFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E2EFT_VERSION 100 /* 0.1.0 */
+
+enum {
+    E2EFT_OK = 0,
+    E2EFT_ERR_BAD_ARG = 1,     /* shape / dtype / alignment rejected */
+    E2EFT_ERR_WORKSPACE = 2,   /* workspace too small */
+    E2EFT_ERR_LAUNCH = 3,      /* hipGetLastError() != hipSuccess after a launch */
+    E2EFT_ERR_UNSUPPORTED = 4, /* valid request this build has no kernel for */
+};
+
+enum { E2EFT_F32 = 0, E2EFT_F16 = 1, E2EFT_BF16 = 2 };
+
+int e2eft_version(void);
+const char* e2eft_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / GEMM (MFMA).
+ *   out[m, n] = alpha * ( sum_k A[m, k] * W[n, k] + bias[n] + rowadd[img(m), n] ) + residual[m, n]
+ * conv mode (kh*kw > 1 or stride/upsample/two sources): m = (b, oy, ox), k = ((ky*kw + kx)*cin + c),
+ *   A gathered on the fly from the NHWC input(s) with zero padding; weights pre-packed OHWI = W[n][k].
+ * Replaces: nn.Conv2d in diffusers ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D.conv,
+ *   Upsample2D (F.interpolate nearest + conv), conv_in/conv_out, VAE quant convs
+ *   (composition sites GeoWizard/geowizard/models/unet_2d_blocks.py:1064,1109,1211,2242,2285,2400;
+ *   unet_2d_condition.py:294,617,1084,1212; Marigold/marigold/marigold_pipeline.py:493-494,515-516),
+ *   and nn.Linear / batched matmul (attention.py:208-217,239-248,755,765; transformer_2d.py:153,215).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct E2eftConvDesc {
+    int32_t dtype;
+    /* input geometry: physical tensor [B, hin, win, *]; logical (virtually nearest-upsampled) size hl x wl
+     * (hl == hin and wl == win when there is no fused upsample; Upsample2D, unet_2d_blocks.py:2285). */
+    int32_t batch, hin, win, hl, wl;
+    int32_t c1, ldx1;         /* channels taken from x1 and its pixel stride */
+    int32_t c2, ldx2;         /* channels taken from x2 (0 = none): fused torch.cat([x1, x2], dim=1)
+                                 (unet_2d_blocks.py:2328,2456) */
+    int32_t kh, kw, stride;   /* kernel size, stride (same in y and x) */
+    int32_t pad_t, pad_l;     /* zero padding top/left; bottom/right implied by hout/wout
+                                 (VAE Downsample2D pads (0,1,0,1): pad_t = pad_l = 0) */
+    int32_t hout, wout;
+    int32_t cout, ldo;        /* output channels and output pixel stride */
+    int32_t ldr;              /* residual pixel stride (if residual != NULL) */
+    int32_t ldw;              /* weight row stride in elements (>= kh*kw*(c1+c2)) */
+    float alpha;
+} E2eftConvDesc;
+
+int e2eft_conv2d_fwd(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w,
+                     const void* bias /* [cout] or NULL */,
+                     const void* rowadd /* [batch, cout] per-image vector (time embedding) or NULL */,
+                     const void* residual /* [B,hout,wout,ldr] or NULL */, void* out, void* stream);
+
+/* Batched GEMM with two-level batch index z = zo*nzi + zi:
+ *   out_z[m, n] = alpha * ( sum_k A_z[m, k] * W_z[n, k] + bias ) + residual_z[m, n]
+ * bias is indexed by n (bias_along_m = 0) or by m (bias_along_m = 1). K-contiguous operands ("NT" GEMM). */
+typedef struct E2eftGemmDesc {
+    int32_t dtype;
+    int32_t m, n, k;
+    int32_t lda, ldw, ldo, ldr;
+    int32_t nzo, nzi;                      /* batch counts (>= 1) */
+    int64_t sa_o, sa_i, sw_o, sw_i, so_o, so_i, sr_o, sr_i; /* element strides per batch level */
+    int32_t bias_along_m;
+    float alpha;
+} E2eftGemmDesc;
+
+int e2eft_gemm(const E2eftGemmDesc* d, const void* a, const void* w, const void* bias, const void* residual,
+               void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU), NHWC, fp32 statistics (shifted/Welford-merged).
+ * Replaces nn.GroupNorm(+nn.SiLU) in ResnetBlock2D.norm1/norm2, conv_norm_out, Transformer2DModel.norm,
+ * VAE attention group_norm (unet_2d_condition.py:606; transformer_2d.py:151; unet_2d_blocks.py:589-601).
+ * The input may be the fused concat of two sources (c2 > 0), matching e2eft_conv2d_fwd.
+ * workspace: e2eft_groupnorm_workspace_bytes().  Output y has c1+c2 channels, pixel stride ldy.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct E2eftGroupNormDesc {
+    int32_t dtype;
+    int32_t batch, hw;        /* pixels per image */
+    int32_t c1, ldx1, c2, ldx2;
+    int32_t groups;
+    int32_t ldy;
+    int32_t silu;             /* 1 = fuse SiLU */
+    float eps;
+} E2eftGroupNormDesc;
+
+size_t e2eft_groupnorm_workspace_bytes(const E2eftGroupNormDesc* d);
+int e2eft_groupnorm_fwd(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma,
+                        const void* beta, void* y, void* workspace, size_t ws_bytes, void* stream);
+
+/* LayerNorm over the last dim of [rows, c] (row stride ldx / ldy), eps, affine.
+ * Replaces nn.LayerNorm norm1/2/3 of BasicTransformerBlock (attention.py:205,237,264). */
+int e2eft_layernorm_fwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldx, int32_t ldy, float eps,
+                        const void* x, const void* gamma, const void* beta, void* y, void* stream);
+
+/* GEGLU gate: y[r, j] = h[r, j] * gelu_erf(h[r, c + j]) for j < c, h = [rows, 2c] (row stride ldh).
+ * Replaces diffusers GEGLU activation after ff.net.0.proj (attention.py:755). */
+int e2eft_geglu_fwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldh, int32_t ldy, const void* h, void* y,
+                    void* stream);
+
+/* Row softmax in place: s[r, :n] = softmax(scale * s[r, :n]) for r < rows (row stride lds).
+ * Used by the unfused attention path (VAE mid-block d=512 attention and the strict-fp32 path). */
+int e2eft_softmax_rows(int32_t dtype, int64_t rows, int32_t n, int64_t lds, float scale, void* s, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Fused (flash-style) attention forward, head dim 64, fp16/bf16, MFMA + online softmax.
+ *   out[b, i, h*64:(h+1)*64] = softmax_j( scale * q[b,i,h,:] . k[kb(b),j,h,:] ) v[kb(b),j,h,:]
+ * q/out: [batch, nq, heads*64] (row strides ldq/ldo), k/v: [kv_batch, nk_seg, heads*64] (ldk/ldv).
+ * Joint (GeoWizard) attention: kv_nseg = 2 concatenates, along the key axis, the rows of kv batches
+ * (b % kv_bmod) and (b % kv_bmod) + kv_bmod  — XFormersJointAttnProcessor, attention.py:482-491.
+ * Plain attention: kv_nseg = 1, kv_bmod = batch.
+ * Replaces F.scaled_dot_product_attention / xformers.memory_efficient_attention
+ * (attention.py:338-343,375-380,497).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct E2eftAttnDesc {
+    int32_t dtype;            /* E2EFT_F16 or E2EFT_BF16 */
+    int32_t batch, heads, nq, nk_seg;
+    int32_t kv_nseg, kv_bmod;
+    int32_t ldq, ldk, ldv, ldo;
+    float scale;
+} E2eftAttnDesc;
+
+int e2eft_attn_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Elementwise / layout glue on the path.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* NCHW (any of the three dtypes, contiguous) -> NHWC dtype `dt_out`, channels zero-padded from c to cpad,
+ * y = x * mul + add.  Used for rgb_in -> encoder input and latent assembly. */
+int e2eft_nchw_to_nhwc(int32_t dt_in, int32_t dt_out, int32_t batch, int32_t c, int32_t hw, int32_t cpad,
+                       int32_t ldy, float mul, float add, const void* x, void* y, void* stream);
+/* NHWC (pixel stride ldx, first c channels) -> NCHW contiguous, y = x * mul + add. */
+int e2eft_nhwc_to_nchw(int32_t dt_in, int32_t dt_out, int32_t batch, int32_t c, int32_t hw, int32_t ldx,
+                       float mul, float add, const void* x, void* y, void* stream);
+/* Strided channel-slice copy/scale: y[p, 0:c] = x[p, 0:c] * mul + add  (concat assembly, latent scaling
+ * `mean * 0.18215` marigold_pipeline.py:495-497, v->x0 `-sqrt(1-abar) * v` :457-465 / train.py:509-512). */
+int e2eft_copy_scale(int32_t dtype, int64_t pixels, int32_t c, int32_t ldx, int32_t ldy, float mul, float add,
+                     const void* x, void* y, void* stream);
+/* y = a + b (same shape [pixels, c], strides lda/ldb/ldy). */
+int e2eft_add(int32_t dtype, int64_t pixels, int32_t c, int32_t lda, int32_t ldb, int32_t ldy, const void* a,
+              const void* b, void* y, void* stream);
+/* Sinusoidal timestep embedding Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0):
+ * out[b, :] = [cos(t_b f_i) | sin(t_b f_i)], f_i = exp(-ln(1e4) i / (dim/2)) (unet_2d_condition.py:310,974-979).
+ * t is int64 [batch] on the device. */
+int e2eft_timestep_embedding(int32_t dtype, int32_t batch, int32_t dim, const int64_t* t, void* out, void* stream);
+/* SiLU elementwise on [n] contiguous (time embedding act before time_emb_proj). */
+int e2eft_silu(int32_t dtype, int64_t n, const void* x, void* y, void* stream);
+/* Depth head: decoder output NHWC [pixels, ldx>=3] -> depth[pixels] = clip(mean_c(x), -1, 1) (* 0.5 + 0.5 when
+ * to_unit != 0)  (marigold_pipeline.py:518,476-477; train.py:533-534).  Output fp32 or dtype (dt_out). */
+int e2eft_depth_head(int32_t dt_in, int32_t dt_out, int64_t pixels, int32_t ldx, int32_t to_unit, const void* x,
+                     void* y, void* stream);
+/* Normal head: NHWC [B*hw, ldx>=3] -> NCHW [B,3,hw]: n / (||n||_2 + 1e-5), optional clamp to [-1,1] and sign
+ * (marigold_pipeline.py:471; train.py:537-539; geowizard_pipeline.py:341-342). */
+int e2eft_normal_head(int32_t dt_in, int32_t dt_out, int32_t batch, int32_t hw, int32_t ldx, int32_t clamp,
+                      float sign, const void* x, void* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Task losses (fp32), forward.  Replace training/util/loss.py:13-47 (ScaleAndShiftInvariantLoss) and
+ * :51-67 (AngularLoss).  pred/target fp32 NCHW contiguous, mask uint8 [B,1,H,W].
+ * ssi workspace: 8 floats per image + 2; out_loss: 1 float on the device.
+ * ---------------------------------------------------------------------------------------------------- */
+size_t e2eft_ssi_loss_workspace_bytes(int32_t batch);
+int e2eft_ssi_loss_fwd(int32_t batch, int32_t hw, const float* pred, const float* target, const uint8_t* mask,
+                       float* out_loss, float* out_scale_shift /* [batch,2] or NULL */, void* workspace,
+                       size_t ws_bytes, void* stream);
+size_t e2eft_angular_loss_workspace_bytes(int32_t batch);
+int e2eft_angular_loss_fwd(int32_t batch, int32_t hw, const float* pred /* [B,3,hw] */,
+                           const float* target /* [B,3,hw] */, const uint8_t* mask /* [B,hw] */, float* out_loss,
+                           void* workspace, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E2EFT_H */

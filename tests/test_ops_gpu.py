@@ -1,0 +1,336 @@
+"""GPU parity of every libe2eft kernel against plain torch fp32 CPU references of the same op (the
+reference has no tests, so the pyramid starts here).  All calls go through the C ABI (ops.py -> ctypes)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import DTYPES, TOL, assert_close, q, nhwc, to_nchw, pack_conv_weight
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from diffusion_e2e_ft_amd import ops as _ops
+    return _ops
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 136), (1000, 320, 320), (77, 64, 1024), (5, 1280, 320), (129, 129, 72)])
+def test_gemm(ops, dev, dtype, M, N, K):
+    g = _g(M * 7 + N)
+    a, w = q(torch.randn(M, K, generator=g), dtype), q(torch.randn(N, K, generator=g) / K ** 0.5, dtype)
+    bias, res = q(torch.randn(N, generator=g), dtype), q(torch.randn(M, N, generator=g), dtype)
+    ref = 0.5 * (a @ w.t() + bias) + res
+    out = ops.gemm(a.to(dtype).to(dev), w.to(dtype).to(dev), bias.to(dtype).to(dev), res.to(dtype).to(dev), alpha=0.5)
+    assert_close(out, ref, dtype, "gemm")
+    # no epilogue + bias along m
+    bm = q(torch.randn(M, generator=g), dtype)
+    out = ops.gemm(a.to(dtype).to(dev), w.to(dtype).to(dev), bm.to(dtype).to(dev), bias_along_m=True)
+    assert_close(out, a @ w.t() + bm[:, None], dtype, "gemm bias_m")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_strided_views(ops, dev, dtype):
+    g = _g(3)
+    M, K, N = 200, 64, 96
+    big = q(torch.randn(M, 3 * K, generator=g), dtype)
+    w = q(torch.randn(N, K, generator=g) / 8, dtype)
+    bd = big.to(dtype).to(dev)
+    outbuf = torch.zeros(M, 2 * N, dtype=dtype, device=dev)
+    ops.gemm(bd[:, K:2 * K], w.to(dtype).to(dev), out=outbuf[:, N:])
+    assert_close(outbuf[:, N:], big[:, K:2 * K] @ w.t(), dtype, "gemm views")
+    assert outbuf[:, :N].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bgemm(ops, dev, dtype):
+    """attention-shaped batched GEMM: S[b,h] = Q[b,:,h] K[b,:,h]^T with head-strided operands"""
+    g = _g(5)
+    B, H, N, Nk, D = 2, 3, 150, 77, 64
+    e = 4 if dtype == torch.float32 else 8
+    nkp = (Nk + e - 1) // e * e
+    qq, kk = q(torch.randn(B, N, H * D, generator=g), dtype), q(torch.randn(B, Nk, H * D, generator=g), dtype)
+    S = torch.zeros(B, H, N, nkp, dtype=dtype, device=dev)
+    ops.bgemm_raw(dtype, N, Nk, D, qq.to(dtype).to(dev), H * D, (N * H * D, D), kk.to(dtype).to(dev), H * D, (Nk * H * D, D), S, nkp,
+                  (H * N * nkp, N * nkp), B, H)
+    ref = torch.einsum("bnhd,bmhd->bhnm", qq.view(B, N, H, D), kk.view(B, Nk, H, D))
+    assert_close(S[..., :Nk], ref, dtype, "bgemm")
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def _conv_case(ops, dev, dtype, B, Ci, Co, H, W, k, stride, pad, up_to=None, c2=0, rowadd=False, residual=False, alpha=1.0, seed=0):
+    g = _g(seed + Ci * 3 + Co)
+    x = q(torch.randn(B, Ci, H, W, generator=g), dtype)
+    x2 = q(torch.randn(B, c2, H, W, generator=g), dtype) if c2 else None
+    w = q(torch.randn(Co, Ci + c2, k, k, generator=g) / ((Ci + c2) * k * k) ** 0.5, dtype)
+    b = q(torch.randn(Co, generator=g), dtype)
+    xin = x if x2 is None else torch.cat([x, x2], dim=1)
+    if up_to is not None:
+        if up_to == (2 * H, 2 * W):
+            xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+        else:
+            xin = F.interpolate(xin, size=up_to, mode="nearest")
+    xin = F.pad(xin, (pad[2], pad[3], pad[0], pad[1]))
+    ref = F.conv2d(xin.double(), w.double(), b.double(), stride=stride).float()
+    ra = q(torch.randn(B, Co, generator=g), dtype) if rowadd else None
+    rs = q(torch.randn(ref.shape, generator=g), dtype) if residual else None
+    if ra is not None:
+        ref = ref + ra[:, :, None, None]
+    ref = ref * alpha
+    if rs is not None:
+        ref = ref + rs
+    out = ops.conv2d(nhwc(x, dtype, dev), pack_conv_weight(w, dtype, dev), b.to(dtype).to(dev), Co, k, k, stride, pad,
+                     x2=None if x2 is None else nhwc(x2, dtype, dev), up_to=up_to,
+                     rowadd=None if ra is None else ra.to(dtype).to(dev),
+                     residual=None if rs is None else nhwc(rs, dtype, dev), alpha=alpha)
+    return assert_close(to_nchw(out), ref, dtype, "conv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_basic(ops, dev, dtype):
+    _conv_case(ops, dev, dtype, 2, 32, 48, 17, 13, 3, 1, (1, 1, 1, 1))
+    _conv_case(ops, dev, dtype, 1, 64, 128, 16, 16, 3, 1, (1, 1, 1, 1), rowadd=True, residual=True, alpha=0.7)
+    _conv_case(ops, dev, dtype, 2, 8, 64, 12, 12, 3, 1, (1, 1, 1, 1))      # K = 72: partial k-tile
+    _conv_case(ops, dev, dtype, 1, 128, 4, 20, 20, 3, 1, (1, 1, 1, 1))     # tiny Cout
+    _conv_case(ops, dev, dtype, 3, 320, 320, 12, 12, 3, 1, (1, 1, 1, 1), rowadd=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_stride2(ops, dev, dtype):
+    _conv_case(ops, dev, dtype, 2, 32, 32, 16, 16, 3, 2, (1, 1, 1, 1))     # UNet Downsample2D
+    _conv_case(ops, dev, dtype, 2, 32, 32, 15, 17, 3, 2, (1, 1, 1, 1))     # odd sizes
+    _conv_case(ops, dev, dtype, 2, 32, 32, 16, 16, 3, 2, (0, 1, 0, 1))     # VAE Downsample2D (asymmetric pad)
+    _conv_case(ops, dev, dtype, 1, 64, 32, 13, 9, 3, 2, (0, 1, 0, 1))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv1x1_and_concat(ops, dev, dtype):
+    _conv_case(ops, dev, dtype, 2, 64, 96, 9, 11, 1, 1, (0, 0, 0, 0))                      # plain GEMM mode
+    _conv_case(ops, dev, dtype, 2, 64, 96, 9, 11, 1, 1, (0, 0, 0, 0), c2=32, residual=True)  # shortcut on cat input
+    _conv_case(ops, dev, dtype, 2, 64, 64, 10, 10, 3, 1, (1, 1, 1, 1), c2=64, rowadd=True)   # up-block conv1 on cat input
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_fused_upsample(ops, dev, dtype):
+    _conv_case(ops, dev, dtype, 2, 32, 32, 8, 8, 3, 1, (1, 1, 1, 1), up_to=(16, 16))
+    _conv_case(ops, dev, dtype, 1, 64, 32, 6, 5, 3, 1, (1, 1, 1, 1), up_to=(12, 10))
+    _conv_case(ops, dev, dtype, 1, 32, 32, 8, 10, 3, 1, (1, 1, 1, 1), up_to=(15, 20))      # forced size (unet_2d_condition.py:920-930)
+
+
+def test_conv_identity_kat(ops, dev):
+    """analytic KAT: identity weights reproduce the input (asymmetric data catches transposes)"""
+    dtype = torch.float32
+    x = torch.randn(1, 32, 7, 9, generator=_g(1))
+    w = torch.zeros(32, 32, 3, 3)
+    for c in range(32):
+        w[c, c, 1, 1] = 1.0
+    out = ops.conv2d(nhwc(x, dtype, dev), pack_conv_weight(w, dtype, dev), None, 32, 3, 3, 1, (1, 1, 1, 1))
+    assert torch.equal(to_nchw(out), x)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,H,W,c2,silu,offset", [(64, 9, 7, 0, True, 0.0), (320, 12, 12, 0, True, 0.0), (128, 40, 36, 0, False, 0.0),
+                                                    (64, 8, 8, 64, True, 0.0), (2560 // 8, 5, 5, 0, False, 0.0), (128, 32, 32, 0, True, 30.0),
+                                                    (960, 6, 6, 0, True, 0.0)])
+def test_groupnorm(ops, dev, dtype, C, H, W, c2, silu, offset):
+    g = _g(C + H)
+    B = 2
+    x = q(torch.randn(B, C + c2, H, W, generator=g) * 2 + offset + torch.randn(1, C + c2, 1, 1, generator=g), dtype)
+    ga, be = q(1 + 0.3 * torch.randn(C + c2, generator=g), dtype), q(0.3 * torch.randn(C + c2, generator=g), dtype)
+    ref = F.group_norm(x.double(), 32, ga.double(), be.double(), 1e-5).float()
+    if silu:
+        ref = F.silu(ref)
+    xd = nhwc(x, dtype, dev)
+    if c2:
+        out = ops.groupnorm(xd[..., :C].contiguous(), ga.to(dtype).to(dev), be.to(dtype).to(dev), 32, 1e-5, silu, x2=xd[..., C:].contiguous())
+    else:
+        out = ops.groupnorm(xd, ga.to(dtype).to(dev), be.to(dtype).to(dev), 32, 1e-5, silu)
+    # with a large offset the input quantisation dominates in 16-bit: scale tolerance
+    assert_close(to_nchw(out), ref, dtype, "groupnorm", scale=(8.0 if offset else 1.5))
+
+
+def test_groupnorm_constant_kat(ops, dev):
+    """GroupNorm of a constant is beta (variance 0)"""
+    x = torch.full((1, 64, 6, 6), 3.25)
+    be = torch.randn(64, generator=_g(2))
+    out = ops.groupnorm(nhwc(x, torch.float32, dev), torch.ones(64, device=dev), be.to(dev), 32, 1e-6, False)
+    assert torch.allclose(to_nchw(out), be[None, :, None, None].expand(1, 64, 6, 6), atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(1000, 64), (333, 320), (70, 1280), (9, 640)])
+def test_layernorm(ops, dev, dtype, rows, C):
+    g = _g(rows)
+    x = q(torch.randn(rows, C, generator=g) * 3 + 1, dtype)
+    ga, be = q(1 + 0.3 * torch.randn(C, generator=g), dtype), q(0.3 * torch.randn(C, generator=g), dtype)
+    ref = F.layer_norm(x.double(), (C,), ga.double(), be.double(), 1e-5).float()
+    out = ops.layernorm(x.to(dtype).to(dev), ga.to(dtype).to(dev), be.to(dtype).to(dev), 1e-5)
+    assert_close(out, ref, dtype, "layernorm", scale=1.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_geglu(ops, dev, dtype):
+    g = _g(11)
+    h = q(torch.randn(300, 2 * 256, generator=g) * 2, dtype)
+    ref = h[:, :256] * F.gelu(h[:, 256:])
+    assert_close(ops.geglu(h.to(dtype).to(dev)), ref, dtype, "geglu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 2, 77, 144, 1000, 4100])
+def test_softmax_rows(ops, dev, dtype, n):
+    g = _g(n)
+    e = 4 if dtype == torch.float32 else 8
+    npad = (n + e - 1) // e * e
+    s = q(torch.randn(37, npad, generator=g) * 4, dtype)
+    ref = torch.softmax(s[:, :n].double() * 0.125, dim=-1).float()
+    buf = s.to(dtype).to(dev).contiguous()
+    ops.softmax_rows_(buf, n, 0.125)
+    assert_close(buf[:, :n], ref, dtype, "softmax")
+    if npad > n:
+        assert buf[:, n:].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(qq, kk, vv, heads):
+    B, N, Wd = qq.shape
+    d = Wd // heads
+    sp = lambda t: t.reshape(t.shape[0], t.shape[1], heads, d).transpose(1, 2).double()
+    o = F.scaled_dot_product_attention(sp(qq), sp(kk), sp(vv))
+    return o.transpose(1, 2).reshape(B, N, Wd).float()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,Nk", [(144, 144), (300, 300), (1024, 1024), (576, 2), (144, 77), (200, 1), (130, 64), (128, 129)])
+def test_attention(ops, dev, dtype, N, Nk):
+    g = _g(N + Nk)
+    B, heads = 2, 3
+    qq = q(torch.randn(B, N, heads * 64, generator=g), dtype)
+    kk = q(torch.randn(B, Nk, heads * 64, generator=g), dtype)
+    vv = q(torch.randn(B, Nk, heads * 64, generator=g), dtype)
+    out = ops.attention(qq.to(dtype).to(dev), kk.to(dtype).to(dev), vv.to(dtype).to(dev), heads, 64 ** -0.5)
+    assert_close(out, _attn_ref(qq, kk, vv, heads), dtype, "attention", scale=1.5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_attention_fused_qkv_views_and_spike(ops, dev, dtype):
+    """q/k/v as column slices of one [B,N,3C] buffer; one key spiked against one query to force a big running-max jump
+    late in the key sequence (online-softmax rescale path)."""
+    g = _g(21)
+    B, heads, N = 1, 2, 320
+    C = heads * 64
+    qkv = torch.randn(B, N, 3 * C, generator=g)
+    qkv[0, 5, :C] *= 6.0
+    qkv[0, 300, C:2 * C] = qkv[0, 5, :C]  # key 300 aligned with query 5
+    qkv = q(qkv, dtype)
+    d = qkv.to(dtype).to(dev)
+    out = ops.attention(d[..., :C], d[..., C:2 * C], d[..., 2 * C:], heads, 64 ** -0.5)
+    assert_close(out, _attn_ref(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads), dtype, "attention spike", scale=1.5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_attention_joint(ops, dev, dtype):
+    """GeoWizard joint attention (attention.py:482-491): both halves attend to the concatenation of both halves' keys"""
+    g = _g(33)
+    Bh, heads, N = 2, 2, 144
+    C = heads * 64
+    qq, kk, vv = (q(torch.randn(2 * Bh, N, C, generator=g), dtype) for _ in range(3))
+    k0, k1 = kk[:Bh], kk[Bh:]
+    v0, v1 = vv[:Bh], vv[Bh:]
+    kj = torch.cat([torch.cat([k0, k1], dim=1)] * 2, dim=0)
+    vj = torch.cat([torch.cat([v0, v1], dim=1)] * 2, dim=0)
+    ref = _attn_ref(qq, kj, vj, heads)
+    out = ops.attention(qq.to(dtype).to(dev), kk.to(dtype).to(dev), vv.to(dtype).to(dev), heads, 64 ** -0.5, kv_nseg=2, kv_bmod=Bh)
+    assert_close(out, ref, dtype, "joint attention", scale=1.5)
+
+
+# ------------------------------------------------------------------------------------------------ glue
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_and_scale(ops, dev, dtype):
+    g = _g(41)
+    x = q(torch.rand(2, 3, 10, 12, generator=g) * 2 - 1, dtype)
+    y = ops.nchw_to_nhwc(x.to(dev), dtype=dtype, mul=2.0, add=-0.5)
+    e = 4 if dtype == torch.float32 else 8
+    assert y.shape == (2, 10, 12, e if e >= 3 else 4)
+    assert_close(to_nchw(y[..., :3]), x * 2 - 0.5, dtype, "nchw_to_nhwc")
+    assert y[..., 3:].abs().max().item() == 0
+    back = ops.nhwc_to_nchw(y[..., :3], dtype=torch.float32)
+    assert_close(back, (x * 2 - 0.5), dtype, "nhwc_to_nchw")
+    # strided channel-slice copy (concat assembly) and add
+    a = q(torch.randn(2, 5, 6, 16, generator=g), dtype).to(dtype).to(dev)
+    buf = torch.zeros(2, 5, 6, 48, dtype=dtype, device=dev)
+    ops.copy_scale(a, buf[..., 16:32], mul=0.18215)
+    assert_close(buf[..., 16:32], a.float().cpu() * 0.18215, dtype, "copy_scale")
+    assert buf[..., :16].abs().max().item() == 0 and buf[..., 32:].abs().max().item() == 0
+    b4 = q(torch.randn(2, 5, 6, 4, generator=g), dtype).to(dtype).to(dev)
+    o4 = torch.zeros(2, 5, 6, 8, dtype=dtype, device=dev)
+    ops.copy_scale(b4, o4[..., :4], mul=-0.99766725)
+    assert_close(o4[..., :4], b4.float().cpu() * -0.99766725, dtype, "copy_scale c=4")
+    s = ops.add(a, a)
+    assert_close(s, 2 * a.float().cpu(), dtype, "add")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_timestep_embedding_and_silu(ops, dev, dtype):
+    from oracle.unet_ref import timestep_sinusoid
+    t = torch.tensor([999, 0, 1, 499], dtype=torch.int64)
+    ref = timestep_sinusoid(t, 320)
+    out = ops.timestep_embedding(t.to(dev), 320, dtype)
+    assert_close(out, ref, dtype, "timestep embedding", scale=(30 if dtype == torch.float32 else 1.0))
+    x = q(torch.randn(1000, generator=_g(1)) * 3, dtype)
+    assert_close(ops.silu(x.to(dtype).to(dev)), F.silu(x), dtype, "silu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_heads(ops, dev, dtype):
+    g = _g(51)
+    x = q(torch.randn(2, 3, 9, 11, generator=g), dtype)
+    xd = ops.nchw_to_nhwc(x.to(dev), dtype=dtype)
+    d = ops.depth_head(xd, to_unit=True, dtype=torch.float32)
+    assert_close(d, (torch.clip(x.mean(dim=1, keepdim=True), -1, 1) + 1) / 2, torch.float32, "depth head", scale=4)
+    d2 = ops.depth_head(xd, to_unit=False, dtype=torch.float32)
+    assert_close(d2, torch.clip(x.mean(dim=1, keepdim=True), -1, 1), torch.float32, "depth head raw", scale=4)
+    n = ops.normal_head(xd, clamp=True, sign=-1.0, dtype=torch.float32)
+    ref = -torch.clamp(x / (torch.norm(x, p=2, dim=1, keepdim=True) + 1e-5), -1, 1)
+    assert_close(n, ref, torch.float32, "normal head", scale=4)
+
+
+def test_losses(ops, dev):
+    from oracle.losses_ref import ssi_loss_ref, angular_loss_ref, compute_scale_and_shift_masked_ref
+    g = _g(61)
+    B, H, W = 3, 40, 56
+    tgt = torch.rand(B, 1, H, W, generator=g) * 2 - 1
+    pred = 0.6 * tgt + 0.2 + 0.05 * torch.randn(B, 1, H, W, generator=g)
+    mask = torch.rand(B, 1, H, W, generator=g) > 0.05
+    mask[2] = False  # an image with no valid pixel -> scale = shift = 0, no contribution
+    loss, ss = ops.ssi_loss(pred.to(dev), tgt.to(dev), mask.to(dev), return_scale_shift=True)
+    ref = ssi_loss_ref(pred, tgt, mask)
+    s, t = compute_scale_and_shift_masked_ref(pred.squeeze(1), tgt.squeeze(1), mask.squeeze(1))
+    assert abs(loss.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    assert torch.allclose(ss[:, 0].cpu(), s, rtol=2e-4, atol=1e-5) and torch.allclose(ss[:, 1].cpu(), t, rtol=2e-4, atol=1e-5)
+    # exact affine relation => zero loss (KAT)
+    l0 = ops.ssi_loss((2.0 * tgt - 0.3).to(dev), tgt.to(dev), mask.to(dev))
+    assert abs(l0.item()) < 1e-5
+    nrm = F.normalize(torch.randn(B, 3, H, W, generator=g), dim=1)
+    nt = F.normalize(nrm + 0.3 * torch.randn(B, 3, H, W, generator=g), dim=1)
+    la = ops.angular_loss(nrm.to(dev), nt.to(dev), mask.to(dev))
+    ra = angular_loss_ref(nrm, nt, mask)
+    assert abs(la.item() - ra.item()) <= 2e-5, (la.item(), ra.item())
+    lz = ops.angular_loss(nt.to(dev), nt.to(dev), mask.to(dev))
+    assert lz.item() < 1e-3  # acos near 1 is ill-conditioned in fp32 (reference has the same property)
+
+
+def test_errors_are_reported(ops, dev):
+    with pytest.raises(RuntimeError, match="libe2eft error"):
+        ops.gemm(torch.zeros(4, 6, device=dev, dtype=torch.float16), torch.zeros(4, 6, device=dev, dtype=torch.float16))  # k % 8 != 0
+    with pytest.raises(RuntimeError, match="device"):
+        ops.gemm(torch.zeros(8, 8), torch.zeros(8, 8))
