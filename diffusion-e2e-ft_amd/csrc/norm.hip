@@ -132,16 +132,17 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GnGeom g, int groups, 
         const int c = grp * cpg + cc;
         const float ga = gamma ? to_f(gamma[c]) : 1.f;
         const float be = beta ? to_f(beta[c]) : 0.f;
-        const float a = rstd * ga;
-        ad[((long)b * g.C + c) * 2] = a;
-        ad[((long)b * g.C + c) * 2 + 1] = be - mean * a;
+        (void)be;
+        ad[((long)b * g.C + c) * 2] = rstd * ga;   // y = (x - mean) * a + beta: no cancellation when |mean| >> std
+        ad[((long)b * g.C + c) * 2 + 1] = mean;
     }
 }
 
 // grid (nslabs, batch, nchb)
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnGeom g, int silu, int ldy, const T* __restrict__ x1,
-                                                       const T* __restrict__ x2, const float* __restrict__ ad, T* __restrict__ y) {
+                                                       const T* __restrict__ x2, const float* __restrict__ ad,
+                                                       const T* __restrict__ beta, T* __restrict__ y) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const int tid = threadIdx.x;
     const int chl = tid % g.cpb, pl = tid / g.cpb;
@@ -154,11 +155,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnGeom g, int silu, int l
     const T* src;
     int ld;
     if (c < g.c1) { src = x1 + c; ld = g.ldx1; } else { src = x2 + (c - g.c1); ld = g.ldx2; }
-    float a[EPC], d[EPC];
+    float a[EPC], mu[EPC], be[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         a[e] = ad[((long)b * g.C + c + e) * 2];
-        d[e] = ad[((long)b * g.C + c + e) * 2 + 1];
+        mu[e] = ad[((long)b * g.C + c + e) * 2 + 1];
+        be[e] = beta ? to_f(beta[c + e]) : 0.f;
     }
     for (int pix = p0 + pl; pix < p1; pix += g.pl) {
         const long row = (long)b * g.hw + pix;
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnGeom g, int silu, int l
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            float t = fmaf(to_f(v.e[e]), a[e], d[e]);
+            float t = fmaf(to_f(v.e[e]) - mu[e], a[e], be[e]);
             if (silu) t = silu_f(t);
             o.e[e] = from_f<T>(t);
         }
@@ -201,7 +203,7 @@ static int gn_run(const E2eftGroupNormDesc* d, const GnGeom& g, const void* x1, 
     hipLaunchKernelGGL((gn_partial_kernel<T>), grid, dim3(256), 0, s, g, (const T*)x1, (const T*)x2, partial);
     hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(d->groups, g.batch), dim3(256), 0, s, g, d->groups, d->eps, partial,
                        (const T*)gamma, (const T*)beta, ad);
-    hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(256), 0, s, g, d->silu, d->ldy, (const T*)x1, (const T*)x2, ad, (T*)y);
+    hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(256), 0, s, g, d->silu, d->ldy, (const T*)x1, (const T*)x2, ad, (const T*)beta, (T*)y);
     return check_launch("groupnorm");
 }
 

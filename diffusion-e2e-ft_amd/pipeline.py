@@ -1,0 +1,262 @@
+"""`MarigoldPipeline` surface (Marigold/marigold/marigold_pipeline.py:113-538) over the libe2eft UNet / VAE, plus the
+batched GeoWizard joint depth+normal inference (GeoWizard/geowizard/models/geowizard_pipeline.py:252-344).
+
+Same component slots (unet, vae, scheduler, text_encoder, tokenizer), same `__call__` keyword arguments, same
+`single_infer / encode_rgb / decode_depth / decode_normal` methods and `MarigoldDepthOutput` fields.  Host-side image
+pre/post-processing (resize, colourising) is SURVEY.md §8f "next"; it runs in torch on the host as in the reference.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .modules import to_nhwc, to_nchw_view, conv_nhwc
+
+
+@dataclass
+class MarigoldDepthOutput:
+    depth_np: Optional[np.ndarray]
+    depth_colored: object
+    uncertainty: Optional[np.ndarray]
+    normal_np: Optional[np.ndarray]
+    normal_colored: object
+
+
+class MarigoldPipeline:
+    rgb_latent_scale_factor = 0.18215    # marigold_pipeline.py:134
+    depth_latent_scale_factor = 0.18215  # marigold_pipeline.py:135
+
+    def __init__(self, unet, vae, scheduler, text_encoder=None, tokenizer=None):
+        self.unet, self.vae, self.scheduler = unet, vae, scheduler
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer
+        self.empty_text_embed = None
+
+    # ---- DiffusionPipeline-like surface (Marigold/run.py:274-290) ----
+    @property
+    def dtype(self):
+        return self.unet.dtype
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    def to(self, *args, **kwargs):
+        self.unet.to(*args, **kwargs)
+        self.vae.to(*args, **kwargs)
+        if self.text_encoder is not None:
+            self.text_encoder.to(*args, **kwargs)
+        if self.empty_text_embed is not None:
+            self.empty_text_embed = self.empty_text_embed.to(*args, **kwargs)
+        return self
+
+    def enable_xformers_memory_efficient_attention(self):
+        return None  # fused attention is the only path
+
+    # ---- marigold_pipeline.py:356-369 ----
+    def encode_empty_text(self):
+        if self.text_encoder is None or self.tokenizer is None:
+            raise RuntimeError("no text encoder: set pipe.empty_text_embed ([1, L, cross_attention_dim]) explicitly")
+        ids = self.tokenizer("", padding="do_not_pad", max_length=self.tokenizer.model_max_length, truncation=True,
+                             return_tensors="pt").input_ids.to(self.device)
+        self.empty_text_embed = self.text_encoder(ids)[0].to(self.dtype)
+
+    # ---- marigold_pipeline.py:481-498 ----
+    @torch.no_grad()
+    def encode_rgb(self, rgb_in):
+        h = self.vae.encoder(rgb_in)
+        moments = self.vae.quant_conv(h)
+        mean = moments[:, : moments.shape[1] // 2]  # torch.chunk(moments, 2, dim=1)[0]
+        return _scaled(mean, self.rgb_latent_scale_factor)
+
+    def _decode(self, latent):
+        z = self.vae.post_quant_conv(_scaled(latent, 1.0 / self.depth_latent_scale_factor))
+        return self.vae.decoder(z)
+
+    # ---- marigold_pipeline.py:501-519 ----
+    @torch.no_grad()
+    def decode_depth(self, depth_latent):
+        stacked = self._decode(depth_latent)
+        return ops.depth_head(stacked.permute(0, 2, 3, 1), to_unit=False)
+
+    # ---- marigold_pipeline.py:522-538 ----
+    @torch.no_grad()
+    def decode_normal(self, normal_latent):
+        return self._decode(normal_latent)
+
+    # ---- marigold_pipeline.py:372-478 ----
+    @torch.no_grad()
+    def single_infer(self, rgb_in, num_inference_steps, show_pbar=False, noise="gaussian", normals=False, generator=None):
+        device, dt = self.device, self.dtype
+        rgb_in = rgb_in.to(device=device, dtype=dt)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps = self.scheduler.timesteps
+        rgb_latent = self.encode_rgb(rgb_in)  # [B,4,h,w] logical NCHW
+        B, C, h, w = rgb_latent.shape
+        # UNet input buffer [B,h,w,8] NHWC: channels 0:4 rgb latent, 4:8 current latent ("this order is important" :447-449)
+        xin = torch.zeros((B, h, w, 2 * C), dtype=dt, device=device)
+        ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[..., :C])
+        if noise == "gaussian":
+            latent = torch.randn((B, C, h, w), device=device, dtype=dt, generator=generator)
+        elif noise == "pyramid":
+            latent = pyramid_noise_like(rgb_latent).to(device)
+        elif noise == "zeros":
+            latent = None  # xin[..., C:] is already zero
+        else:
+            raise ValueError("Unknown noise type: %s" % noise)
+        if latent is not None:
+            ops.copy_scale(latent.permute(0, 2, 3, 1).contiguous(), xin[..., C:])
+        if self.empty_text_embed is None:
+            self.encode_empty_text()
+        ctx = self.empty_text_embed.to(device=device, dtype=dt).repeat(B, 1, 1)
+        x0 = None
+        for i, t in enumerate(timesteps):
+            v = self.unet(to_nchw_view(xin), t, encoder_hidden_states=ctx).sample
+            if latent is None and len(timesteps) == 1:
+                # E2E-FT fast path: x_t = 0  =>  x0 = -sqrt(1 - abar_t) * v   (marigold_pipeline.py:457-465, train.py:509-512)
+                _, sb = self.scheduler.x0_coefficients(int(t))
+                x0 = _scaled(v, -sb)
+            else:
+                cur = latent if latent is not None else torch.zeros((B, C, h, w), dtype=dt, device=device)
+                step = self.scheduler.step(v, t, cur)
+                latent = step.prev_sample
+                x0 = step.pred_original_sample
+                if i == num_inference_steps - 1:
+                    latent = x0
+                ops.copy_scale(latent.permute(0, 2, 3, 1).contiguous(), xin[..., C:])
+        if normals:
+            dec = self.decode_normal(x0)
+            return ops.normal_head(dec.permute(0, 2, 3, 1), clamp=False)
+        stacked = self._decode(x0)
+        return ops.depth_head(stacked.permute(0, 2, 3, 1), to_unit=True)  # clip(mean_c, -1, 1) -> (x+1)/2  (:518,476-477)
+
+    # ---- marigold_pipeline.py:158-353 ----
+    @torch.no_grad()
+    def __call__(self, input_image, denoising_steps=10, ensemble_size=10, processing_res=768, match_input_res=True,
+                 resample_method="bilinear", batch_size=0, color_map="Spectral", show_progress_bar=True, ensemble_kwargs=None,
+                 noise="gaussian", normals=False):
+        assert processing_res >= 0 and ensemble_size >= 1
+        if isinstance(input_image, torch.Tensor):
+            rgb = input_image.squeeze()
+        else:  # PIL image
+            rgb = torch.from_numpy(np.asarray(input_image.convert("RGB"))).permute(2, 0, 1)
+        input_size = rgb.shape
+        assert rgb.dim() == 3 and input_size[0] == 3, "Wrong input shape %s, expected [rgb, H, W]" % (tuple(input_size),)
+        if processing_res > 0:
+            rgb = resize_max_res(rgb, processing_res, resample_method)
+        rgb_norm = (rgb / 255.0 * 2.0 - 1.0).to(self.dtype)
+        assert rgb_norm.min() >= -1.0 and rgb_norm.max() <= 1.0
+        dup = torch.stack([rgb_norm] * ensemble_size)
+        bs = batch_size if batch_size > 0 else ensemble_size
+        preds = []
+        for s in range(0, ensemble_size, bs):
+            preds.append(self.single_infer(dup[s:s + bs], denoising_steps, show_progress_bar, noise=noise, normals=normals))
+        preds = torch.cat(preds, dim=0).float().squeeze()
+        if ensemble_size > 1:
+            raise NotImplementedError("test-time ensembling (ensemble_size > 1) is SURVEY.md §8f 'next'; E2E-FT uses ensemble_size=1 "
+                                      "(marigold_pipeline.py:293-297)")
+        pred, pred_uncert = preds, None
+        if normals:
+            pred = pred / (torch.norm(pred, p=2, dim=0, keepdim=True) + 1e-5)
+        else:
+            mn, mx = torch.min(pred), torch.max(pred)
+            pred = torch.zeros_like(pred) if mx == mn else (pred - mn) / (mx - mn)
+        if match_input_res and tuple(pred.shape[-2:]) != tuple(input_size[-2:]):
+            p4 = pred[None] if normals else pred[None, None]
+            p4 = torch.nn.functional.interpolate(p4, size=tuple(input_size[-2:]), mode=resample_method,
+                                                 antialias=resample_method != "nearest",
+                                                 **({} if resample_method == "nearest" else {"align_corners": False}))
+            pred = p4[0] if normals else p4[0, 0]
+        pred = pred.cpu().numpy()
+        if not normals:
+            pred = pred.clip(0, 1)
+            return MarigoldDepthOutput(depth_np=pred, depth_colored=None, uncertainty=pred_uncert, normal_np=None, normal_colored=None)
+        pred = pred.clip(-1.0, 1.0)
+        return MarigoldDepthOutput(depth_np=None, depth_colored=None, uncertainty=pred_uncert, normal_np=pred, normal_colored=None)
+
+
+def _scaled(x, mul):
+    """y = x * mul for a logical-NCHW tensor, computed by libe2eft into NHWC storage; returns a logical-NCHW view."""
+    xv = x.permute(0, 2, 3, 1)
+    try:
+        ops._nhwc_ld(xv)
+    except ValueError:
+        xv = xv.contiguous()
+    out = torch.empty(xv.shape, dtype=x.dtype, device=x.device)
+    ops.copy_scale(xv, out, mul=mul)
+    return out.permute(0, 3, 1, 2)
+
+
+def resize_max_res(img, max_edge_resolution, resample_method="bilinear"):
+    """Marigold/marigold/util/image_util.py:79-108 — keep aspect ratio, longer edge = max_edge_resolution (host side)."""
+    assert img.dim() == 3
+    H, W = img.shape[-2:]
+    f = min(max_edge_resolution / W, max_edge_resolution / H)
+    nw, nh = int(W * f), int(H * f)
+    kw = {} if resample_method == "nearest" else {"align_corners": False}
+    out = torch.nn.functional.interpolate(img[None].float(), size=(nh, nw), mode=resample_method,
+                                          antialias=resample_method != "nearest", **kw)
+    return out[0]
+
+
+def pyramid_noise_like(x, discount=0.9):
+    """Multi-resolution noise (marigold_pipeline.py:76-86 / training/util/noise.py:8-18); non-default, host RNG."""
+    import random
+    b, c, w, h = x.shape
+    u = torch.nn.Upsample(size=(w, h), mode="bilinear")
+    noise = torch.randn_like(x)
+    for i in range(10):
+        r = random.random() * 2 + 2
+        w, h = max(1, int(w / (r ** i))), max(1, int(h / (r ** i)))
+        noise += u(torch.randn(b, c, w, h).to(x)) * discount ** i
+        if w == 1 or h == 1:
+            break
+    return noise / noise.std()
+
+
+class DepthNormalEstimationPipeline:
+    """GeoWizard joint depth + normal single-step inference, batched (rows [depth x B ; normal x B]) as in
+    GeoWizard/geowizard/training/train_depth_normal.py:687-704; per-image semantics of geowizard_pipeline.py:252-344.
+    The CLIP image encoder is SURVEY.md §8f 'next': pass `img_embed` [B,1,X] directly."""
+
+    def __init__(self, unet, vae, scheduler):
+        self.unet, self.vae, self.scheduler = unet, vae, scheduler
+        self._m = MarigoldPipeline(unet, vae, scheduler)
+
+    @property
+    def dtype(self):
+        return self.unet.dtype
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    @staticmethod
+    def class_embedding(batch, domain, dtype, device):
+        geo = torch.tensor([[0.0, 1.0], [1.0, 0.0]], dtype=torch.float32).repeat_interleave(batch, 0)
+        dom = {"indoor": [1.0, 0.0, 0.0], "outdoor": [0.0, 1.0, 0.0], "object": [0.0, 0.0, 1.0]}[domain]
+        dom = torch.tensor([dom], dtype=torch.float32).repeat(2 * batch, 1)
+        emb = torch.cat([torch.sin(geo), torch.cos(geo), torch.sin(dom), torch.cos(dom)], dim=-1)  # 10 constants, host
+        return emb.to(device=device, dtype=dtype)
+
+    @torch.no_grad()
+    def single_infer(self, input_rgb, img_embed, domain="indoor"):
+        device, dt = self.device, self.dtype
+        rgb = input_rgb.to(device=device, dtype=dt)
+        B = rgb.shape[0]
+        self.scheduler.set_timesteps(1, device=device)
+        t = self.scheduler.timesteps[0]
+        rgb_latent = self._m.encode_rgb(rgb)
+        _, C, h, w = rgb_latent.shape
+        xin = torch.zeros((2 * B, h, w, 2 * C), dtype=dt, device=device)  # geo latent half stays zero
+        ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[:B, ..., :C])
+        ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[B:, ..., :C])
+        ctx = img_embed.to(device=device, dtype=dt).repeat(2, 1, 1)
+        cls = self.class_embedding(B, domain, dt, device)
+        v = self.unet(to_nchw_view(xin), t.repeat(2 * B), encoder_hidden_states=ctx, class_labels=cls).sample
+        _, sb = self.scheduler.x0_coefficients(int(t))
+        x0 = _scaled(v, -sb)
+        depth = ops.depth_head(self._m._decode(x0[:B]).permute(0, 2, 3, 1), to_unit=True)
+        normal = ops.normal_head(self._m._decode(x0[B:]).permute(0, 2, 3, 1), clamp=False, sign=-1.0)  # :341-342
+        return depth, normal

@@ -1,0 +1,71 @@
+"""DDIM scheduler surface used by the pipelines (diffusers DDIMScheduler semantics; scaled_linear betas,
+v_prediction, trailing spacing — Marigold/run.py:157-162, training/train.py:509-518,613-617)."""
+import numpy as np
+import torch
+
+from .unet import Config
+
+
+class SchedulerOutput:
+    def __init__(self, prev_sample, pred_original_sample):
+        self.prev_sample = prev_sample
+        self.pred_original_sample = pred_original_sample
+
+
+class DDIMScheduler:
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 prediction_type="v_prediction", timestep_spacing="trailing", steps_offset=1, clip_sample=False,
+                 set_alpha_to_one=False, thresholding=False):
+        if beta_schedule != "scaled_linear":
+            raise NotImplementedError(beta_schedule)
+        self.config = Config(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                             beta_schedule=beta_schedule, prediction_type=prediction_type, timestep_spacing=timestep_spacing,
+                             steps_offset=steps_offset, clip_sample=clip_sample, set_alpha_to_one=set_alpha_to_one,
+                             thresholding=thresholding)
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        n, T = num_inference_steps, self.config.num_train_timesteps
+        self.num_inference_steps = n
+        sp = self.config.timestep_spacing
+        if sp == "trailing":
+            ts = np.round(np.arange(T, 0, -T / n)) - 1
+        elif sp == "leading":
+            ts = (np.arange(0, n) * (T // n)).round()[::-1].copy() + self.config.steps_offset
+        elif sp == "linspace":
+            ts = np.linspace(0, T - 1, n).round()[::-1].copy()
+        else:
+            raise ValueError(sp)
+        self.timesteps = torch.from_numpy(ts.astype(np.int64)).to(device)
+
+    def x0_coefficients(self, t):
+        """(sqrt(abar_t), sqrt(1 - abar_t)) as python floats computed in fp32 like the reference (train.py:509-512)."""
+        ac = self.alphas_cumprod[int(t)]
+        return float(ac ** 0.5), float((1 - ac) ** 0.5)
+
+    def step(self, model_output, timestep, sample, eta=0.0, **kw):
+        """DDIM step for epsilon / sample / v_prediction with eta = 0 (elementwise torch ops on tiny latents; the
+        pipelines' fused path uses ops.copy_scale instead)."""
+        t = int(timestep)
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t].item()
+        a_prev = (self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod).item()
+        b_t = 1 - a_t
+        pt = self.config.prediction_type
+        if pt == "epsilon":
+            x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+            eps = model_output
+        elif pt == "sample":
+            x0 = model_output
+            eps = (sample - a_t ** 0.5 * x0) / b_t ** 0.5
+        elif pt == "v_prediction":
+            x0 = a_t ** 0.5 * sample - b_t ** 0.5 * model_output
+            eps = a_t ** 0.5 * model_output + b_t ** 0.5 * sample
+        else:
+            raise ValueError(pt)
+        prev = a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
+        return SchedulerOutput(prev, x0)

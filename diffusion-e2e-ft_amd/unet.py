@@ -1,0 +1,242 @@
+"""SD-v2 / GeoWizard `UNet2DConditionModel` on libe2eft: same constructor config, parameter names, call signature
+and attribute surface the reference's callers use:
+  unet(sample, timestep, encoder_hidden_states[, class_labels=...][, return_dict=False]) -> .sample / [0]
+      Marigold/marigold/marigold_pipeline.py:452-454; training/train.py:500; geowizard_pipeline.py:319-321
+  .conv_in (nn.Conv2d), .config['in_channels']      training/util/unet_prep.py:7-20, training/train.py:299
+  .enable_gradient_checkpointing(), .enable_xformers_memory_efficient_attention(), .save_pretrained / from_pretrained
+Wiring follows GeoWizard/geowizard/models/unet_2d_condition.py:916-1221 and unet_2d_blocks.py (block classes cited below).
+"""
+import json
+import os
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import ops
+from .modules import (Conv2d, GroupNorm, ResnetBlock2D, Transformer2DModel, Downsample2D, Upsample2D, TimestepEmbedding,
+                      conv_nhwc, to_nhwc, to_nchw_view)
+
+
+class Config(OrderedDict):
+    """dict with attribute access (diffusers FrozenDict surface: cfg.x, cfg['x'], cfg['x'] = v)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+class UNet2DConditionOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+SD2_UNET_CONFIG = dict(
+    sample_size=96, in_channels=4, out_channels=4,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, attention_head_dim=(5, 10, 20, 20),
+    cross_attention_dim=1024, norm_num_groups=32, norm_eps=1e-5, use_linear_projection=True, flip_sin_to_cos=True,
+    freq_shift=0, class_embed_type=None, projection_class_embeddings_input_dim=None, joint_attention=False,
+)
+
+
+class _DownBlock(nn.Module):
+    """CrossAttnDownBlock2D (unet_2d_blocks.py:1027-1185) / DownBlock2D (:1188-1273)."""
+
+    def __init__(self, in_c, out_c, temb, layers, groups, eps, heads, xdim, cross, add_down, joint):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(in_c if j == 0 else out_c, out_c, temb, groups, eps) for j in range(layers)])
+        if cross:
+            self.attentions = nn.ModuleList([Transformer2DModel(out_c, heads, xdim, groups, joint) for _ in range(layers)])
+        self.has_cross_attention = cross
+        if add_down:
+            self.downsamplers = nn.ModuleList([Downsample2D(out_c, padding=1)])
+        self.add_down = add_down
+
+    def nhwc(self, h, temb_act, ctx):
+        outs = []
+        for j, res in enumerate(self.resnets):
+            h = res.nhwc(h, temb_act)
+            if self.has_cross_attention:
+                h = self.attentions[j].nhwc(h, ctx)
+            outs.append(h)
+        if self.add_down:
+            h = self.downsamplers[0].nhwc(h)
+            outs.append(h)
+        return h, outs
+
+
+class _MidBlock(nn.Module):
+    """UNetMidBlock2DCrossAttn (unet_2d_blocks.py:634-777): resnet -> transformer -> resnet."""
+
+    def __init__(self, c, temb, groups, eps, heads, xdim, joint):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb, groups, eps), ResnetBlock2D(c, c, temb, groups, eps)])
+        self.attentions = nn.ModuleList([Transformer2DModel(c, heads, xdim, groups, joint)])
+
+    def nhwc(self, h, temb_act, ctx):
+        h = self.resnets[0].nhwc(h, temb_act)
+        h = self.attentions[0].nhwc(h, ctx)
+        return self.resnets[1].nhwc(h, temb_act)
+
+
+class _UpBlock(nn.Module):
+    """CrossAttnUpBlock2D (unet_2d_blocks.py:2201-2371) / UpBlock2D (:2374-2481).  torch.cat([hidden, skip], dim=1)
+    (:2328,2456) is never materialised: GroupNorm, conv1 and the 1x1 shortcut read the two sources directly."""
+
+    def __init__(self, in_c, out_c, prev_c, temb, layers, groups, eps, heads, xdim, cross, add_up, joint):
+        super().__init__()
+        rs = []
+        for j in range(layers):
+            skip_c = in_c if j == layers - 1 else out_c
+            res_in = prev_c if j == 0 else out_c
+            rs.append(ResnetBlock2D(res_in + skip_c, out_c, temb, groups, eps))
+        self.resnets = nn.ModuleList(rs)
+        if cross:
+            self.attentions = nn.ModuleList([Transformer2DModel(out_c, heads, xdim, groups, joint) for _ in range(layers)])
+        self.has_cross_attention = cross
+        if add_up:
+            self.upsamplers = nn.ModuleList([Upsample2D(out_c)])
+        self.add_up = add_up
+
+    def nhwc(self, h, skips, temb_act, ctx, upsample_size=None):
+        for j, res in enumerate(self.resnets):
+            h = res.nhwc(h, temb_act, x2=skips.pop())
+            if self.has_cross_attention:
+                h = self.attentions[j].nhwc(h, ctx)
+        if self.add_up:
+            h = self.upsamplers[0].nhwc(h, size=upsample_size)
+        return h
+
+
+class UNet2DConditionModel(nn.Module):
+    config_name = "config.json"
+    weights_name = "diffusion_pytorch_model.safetensors"
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        cfg = Config(SD2_UNET_CONFIG)
+        cfg.update(kwargs)
+        for k in ("block_out_channels", "attention_head_dim", "down_block_types", "up_block_types"):
+            cfg[k] = tuple(cfg[k]) if isinstance(cfg[k], (list, tuple)) else (cfg[k],) * len(cfg["block_out_channels"])
+        if not cfg["use_linear_projection"]:
+            raise NotImplementedError("only use_linear_projection=True (SD-v2) is implemented")
+        self.config = cfg
+        boc, heads = cfg.block_out_channels, cfg.attention_head_dim
+        g, eps, X, L = cfg.norm_num_groups, cfg.norm_eps, cfg.cross_attention_dim, cfg.layers_per_block
+        joint = bool(cfg.joint_attention)
+        temb = boc[0] * 4
+        self.conv_in = Conv2d(cfg.in_channels, boc[0], 3, 1, 1)
+        self.time_embedding = TimestepEmbedding(boc[0], temb)
+        if cfg.class_embed_type == "projection":
+            self.class_embedding = TimestepEmbedding(cfg.projection_class_embeddings_input_dim, temb)
+        elif cfg.class_embed_type is None:
+            self.class_embedding = None
+        else:
+            raise NotImplementedError("class_embed_type=%r" % (cfg.class_embed_type,))
+        downs = []
+        out_c = boc[0]
+        for i, bt in enumerate(cfg.down_block_types):
+            in_c, out_c = out_c, boc[i]
+            downs.append(_DownBlock(in_c, out_c, temb, L, g, eps, heads[i], X, bt == "CrossAttnDownBlock2D", i != len(boc) - 1, joint))
+        self.down_blocks = nn.ModuleList(downs)
+        self.mid_block = _MidBlock(boc[-1], temb, g, eps, heads[-1], X, joint)
+        ups = []
+        rev, rheads = list(reversed(boc)), list(reversed(heads))
+        out_c = rev[0]
+        for i, bt in enumerate(cfg.up_block_types):
+            prev, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, len(boc) - 1)]
+            ups.append(_UpBlock(in_c, out_c, prev, temb, L + 1, g, eps, rheads[i], X, bt == "CrossAttnUpBlock2D", i != len(boc) - 1, joint))
+        self.up_blocks = nn.ModuleList(ups)
+        self.conv_norm_out = GroupNorm(g, boc[0], eps=eps, affine=True)
+        self.conv_out = Conv2d(boc[0], cfg.out_channels, 3, 1, 1)
+        self.gradient_checkpointing = False
+
+    # ---- attribute surface used by the reference's callers ----
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def enable_gradient_checkpointing(self):  # training/train.py:343
+        self.gradient_checkpointing = True
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):  # train.py:317, run.py:284-289: fused attention is always on
+        return None
+
+    def register_to_config(self, **kw):  # training/train.py:334-336
+        self.config.update(kw)
+
+    def save_pretrained(self, save_directory, **kw):  # training/train.py:326,612-630
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = dict(self.config)
+        cfg["_class_name"] = "UNet2DConditionModel"
+        with open(os.path.join(save_directory, self.config_name), "w") as f:
+            json.dump(cfg, f, indent=2)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}, os.path.join(save_directory, self.weights_name))
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **kw):  # training/train.py:292-296
+        from safetensors.torch import load_file
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, cls.config_name)) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_") and k in SD2_UNET_CONFIG}
+        m = cls(**cfg)
+        m.load_state_dict(load_file(os.path.join(d, cls.weights_name)))
+        return m.to(torch_dtype) if torch_dtype is not None else m
+
+    # ---- forward ----
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, return_dict=True, **unused):
+        cfg = self.config
+        dt = self.dtype
+        if sample.dtype != dt:
+            raise TypeError("sample dtype %s != model dtype %s" % (sample.dtype, dt))
+        B = sample.shape[0]
+        x = to_nhwc(sample)
+        # 1. time (+ class) embedding  (unet_2d_condition.py:960-1000)
+        t = torch.as_tensor(timestep, device=sample.device)
+        if t.dim() == 0:
+            t = t[None]
+        t = t.expand(B).to(torch.int64).contiguous()
+        emb = self.time_embedding(ops.timestep_embedding(t, cfg.block_out_channels[0], dt))
+        if self.class_embedding is not None:
+            if class_labels is None:
+                raise ValueError("class_labels should be provided for class_embed_type='projection'")
+            emb = ops.add(emb, self.class_embedding(class_labels.to(dt).contiguous()))
+        temb_act = ops.silu(emb)  # every ResnetBlock2D applies SiLU before its time_emb_proj
+        ctx = encoder_hidden_states.to(dt).contiguous()
+        n_up = len(cfg.block_out_channels) - 1
+        forward_upsample_size = any(s % (2 ** n_up) != 0 for s in sample.shape[-2:])
+        # 2-3. conv_in, down
+        h = conv_nhwc(self.conv_in, x)
+        skips = [h]
+        for blk in self.down_blocks:
+            h, outs = blk.nhwc(h, temb_act, ctx)
+            skips.extend(outs)
+        # 4. mid
+        h = self.mid_block.nhwc(h, temb_act, ctx)
+        # 5. up
+        for blk in self.up_blocks:
+            n = len(blk.resnets)
+            res = skips[-n:]
+            skips = skips[:-n]
+            size = skips[-1].shape[1:3] if (forward_upsample_size and blk.add_up) else None
+            h = blk.nhwc(h, res, temb_act, ctx, upsample_size=size)
+        # 6. out
+        h = self.conv_norm_out.nhwc(h, silu=True)
+        out = to_nchw_view(conv_nhwc(self.conv_out, h))
+        return UNet2DConditionOutput(out) if return_dict else (out,)
