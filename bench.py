@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py — images/s of the single-step Marigold denoising path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path (frozen VAE encode -> SD-v2 UNet @ t=999 on a zero latent -> x0 -> VAE decode ->
+depth) over one batch of synthetic 768x768 images per rank (BASELINE.json configs[1]: batch 8, fp16).  Inputs are
+resident in HBM when the timed region starts.  Weak scaling: every rank processes its own batch, no data-path
+collective; time = max over ranks between barrier + synchronize on both sides.
+
+Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel = implicit-GEMM MFMA kernel, per-launch HIP-event
+timing over the timed region) and `cpu_baseline` (the CPU oracle timed on the host cores) objects."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# algorithmic forward work per image, GFLOP
+WORK_GF = {768: dict(unet=2140.0, enc=2613.0, dec=5763.0), 576: dict(unet=1060.0, enc=1427.0, dec=3199.0),
+           256: dict(unet=177.0, enc=273.0, dec=623.0)}
+PEAK_TF = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per rank per step")
+    ap.add_argument("--res", type=int, default=768)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="tiny configs (plumbing check only, not a valid benchmark)")
+    return ap.parse_args()
+
+
+def build_pipeline(dev, dtype, tiny):
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    from diffusion_e2e_ft_amd.pipeline import MarigoldPipeline
+    from diffusion_e2e_ft_amd.synth import init_synthetic_
+    ucfg = dict(in_channels=8)
+    vcfg = {}
+    if tiny:
+        ucfg.update(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4), cross_attention_dim=128)
+        vcfg.update(block_out_channels=(32, 64, 128, 128))
+    with torch.device(dev):
+        unet = UNet2DConditionModel(**ucfg).to(dtype)
+        vae = AutoencoderKL(**vcfg).to(dtype)
+    init_synthetic_(unet, seed=1234)
+    init_synthetic_(vae, seed=4321)
+    pipe = MarigoldPipeline(unet.eval(), vae.eval(), DDIMScheduler())
+    xdim = unet.config.cross_attention_dim
+    g = torch.Generator(device=dev).manual_seed(0)
+    pipe.empty_text_embed = (0.5 * torch.randn((1, 2, xdim), generator=g, device=dev)).to(dtype)  # [1,2,1024] like the empty prompt
+    return pipe
+
+
+def cpu_baseline(res_hint):
+    """CPU oracle (oracle/ — the restatement of the reference's diffusers CPU path) on this host's cores, bounded sample."""
+    from oracle import config, unet_ref, vae_ref, pipeline_ref, synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    usd = synth.synth_state_dict(unet_ref.unet_param_shapes(config.SD2_UNET), seed=1234)
+    vsd = synth.synth_state_dict(vae_ref.vae_param_shapes(config.SD_VAE), seed=4321)
+
+    def run(res):
+        rgb, ctx = synth.synth_inputs(1, res, res, 2, 1024, seed=0)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            pipeline_ref.single_infer_ref(usd, config.SD2_UNET, vsd, config.SD_VAE, rgb, ctx)
+        return time.perf_counter() - t0
+
+    run(64)  # warm-up (thread pool, allocator)
+    t256 = run(256)
+    tf256 = sum(WORK_GF[256].values()) / 1e3
+    tf768 = sum(WORK_GF[768].values()) / 1e3
+    if t256 * tf768 / tf256 < 45.0:
+        t768 = run(768)
+        return dict(value=1.0 / t768, unit="images/s", cores=cores, kind="port",
+                    sample="CPU oracle (pure-torch fp32 restatement of the diffusers path), 1 image 768x768, 1 run, %d threads; "
+                           "256x256 image took %.2f s" % (cores, t256))
+    return dict(value=(tf256 / tf768) / t256, unit="images/s", cores=cores, kind="port",
+                sample="CPU oracle (pure-torch fp32), 1 image 256x256 in %.2f s, scaled to 768x768 by algorithmic FLOPs (%.2f/%.2f TFLOP), %d threads"
+                       % (t256, tf256, tf768, cores))
+
+
+def main():
+    args = parse()
+    from diffusion_e2e_ft_amd import dist as D
+    from diffusion_e2e_ft_amd import ops
+    rank, local_rank, world = D.init_from_env()
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+    pipe = build_pipeline(dev, dtype, args.tiny)
+    B, R = args.batch, args.res
+    g = torch.Generator(device=dev).manual_seed(rank)
+    img = torch.randint(0, 256, (B, 3, R, R), generator=g, device=dev, dtype=torch.int32)
+    rgb = (img.float() / 255.0 * 2.0 - 1.0).to(dtype)  # resident in HBM before the timed region (marigold_pipeline.py:245)
+
+    def step():
+        return pipe.single_infer(rgb, 1, noise="zeros", normals=False)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    assert torch.isfinite(out.float()).all(), "non-finite depth output"
+    elapsed = D.max_over_ranks(elapsed, device=dev)
+    ksum = timer.summary()
+
+    if rank == 0:
+        n_img = B * world * args.steps
+        value = n_img / elapsed
+        ig = ksum.get("igemm", dict(launches=0, ms=1e-9, flops=0.0))
+        achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        peak = PEAK_TF[args.dtype]
+        extra = {}
+        for k in ("attn", "groupnorm"):
+            if k in ksum and ksum[k]["ms"] > 0:
+                kk = ksum[k]
+                extra[k] = dict(launches_per_step=kk["launches"] / args.steps, ms_per_step=kk["ms"] / args.steps,
+                                tflops=kk["flops"] / (kk["ms"] * 1e-3) / 1e12, gbs=kk["bytes"] / (kk["ms"] * 1e-3) / 1e9)
+        line = {
+            "metric": "images/sec (768x768, 1-step UNet fwd) full path: VAE encode + SD-v2 UNet @t=999 + VAE decode",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.dtype == "fp16" else args.dtype, "data": "synthetic",
+            "config": {"workload": "marigold-e2e-ft-depth 1-step inference, batch=%d/GPU at %dx%d %s, random-init SD-v2 UNet (866M) + SD VAE (84M)%s"
+                                   % (B, R, R, args.dtype, " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
+                       "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world},
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, all launches of the timed region)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "launches_per_step": ig["launches"] / args.steps, "kernel_ms_per_step": ig["ms"] / args.steps,
+                         "algorithmic_gflop_per_step": ig["flops"] / args.steps / 1e9, "other_kernels": extra},
+        }
+        if R in WORK_GF and not args.tiny:
+            tot = sum(WORK_GF[R].values())
+            line["config"]["algorithmic_tflop_per_image"] = tot / 1e3
+            line["effective_tflops"] = value * tot / 1e3
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(R)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                line["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

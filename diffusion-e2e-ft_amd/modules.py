@@ -95,6 +95,12 @@ class Conv2d(nn.Conv2d):
 class Linear(nn.Linear):
     def forward(self, x):
         _no_grad_guard(self.weight, x)
+        K = self.in_features
+        e = ops.epc(self.weight.dtype)
+        if K % e != 0:  # e.g. GeoWizard's 10-dim class-embedding input: zero-pad K to a 16-byte multiple
+            kp = ops.round_up(K, e)
+            w = _cached(self, "wpad", (self.weight,), lambda: torch.nn.functional.pad(self.weight.detach(), (0, kp - K)).contiguous())
+            return ops.linear(torch.nn.functional.pad(x, (0, kp - K)), w, self.bias)
         return ops.linear(x, self.weight, self.bias)
 
 

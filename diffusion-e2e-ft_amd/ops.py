@@ -12,6 +12,46 @@ from . import _lib
 from ._lib import ConvDesc, GemmDesc, GroupNormDesc, AttnDesc, check, dtype_id
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (torch's current stream): bench.py uses it to
+    compute achieved TFLOP/s / GB/s per kernel family over the timed region.  Inactive (zero overhead) by default."""
+
+    def __init__(self):
+        self.rec = {}
+
+    def add(self, name, start, end, flops, nbytes):
+        self.rec.setdefault(name, []).append((start, end, flops, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, lst in self.rec.items():
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in lst)
+            out[name] = dict(launches=len(lst), ms=ms, flops=float(sum(f for _, _, f, _ in lst)), bytes=float(sum(b for _, _, _, b in lst)))
+        return out
+
+
+TIMER = None  # set to a KernelTimer to record
+
+
+class _timed:
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if TIMER is not None:
+            self.e.record()
+            TIMER.add(self.name, self.s, self.e, self.flops, self.nbytes)
+        return False
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -111,8 +151,9 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
         assert bias.dtype == x.dtype and bias.numel() == cout and bias.is_contiguous()
     if rowadd is not None:
         assert rowadd.dtype == x.dtype and tuple(rowadd.shape) == (B, cout) and rowadd.is_contiguous()
-    check(_lib.load().e2eft_conv2d_fwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(w_packed), _ptr(bias), _ptr(rowadd),
-                                       _ptr(residual), _ptr(out), _stream()))
+    with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2)):
+        check(_lib.load().e2eft_conv2d_fwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(w_packed), _ptr(bias), _ptr(rowadd),
+                                           _ptr(residual), _ptr(out), _stream()))
     return out
 
 
@@ -137,7 +178,8 @@ def gemm(a, w, bias=None, residual=None, out=None, alpha=1.0, bias_along_m=False
         assert bias.dtype == a.dtype and bias.is_contiguous() and bias.numel() == (M if bias_along_m else N)
     if residual is not None:
         assert tuple(residual.shape) == (M, N) and residual.dtype == a.dtype
-    check(_lib.load().e2eft_gemm(C.byref(d), _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), _stream()))
+    with _timed("igemm", 2.0 * M * N * K):
+        check(_lib.load().e2eft_gemm(C.byref(d), _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), _stream()))
     return out
 
 
@@ -156,7 +198,8 @@ def bgemm_raw(dtype, m, n, k, a, lda, sa, w, ldw, sw, out, ldo, so, nzo, nzi, bi
     d.sr_o = d.sr_i = 0
     d.bias_along_m = 1 if bias_along_m else 0
     d.alpha = alpha
-    check(_lib.load().e2eft_gemm(C.byref(d), _ptr(a), _ptr(w), _ptr(bias), _ptr(None), _ptr(out), _stream()))
+    with _timed("igemm", 2.0 * m * n * k * nzo * nzi):
+        check(_lib.load().e2eft_gemm(C.byref(d), _ptr(a), _ptr(w), _ptr(bias), _ptr(None), _ptr(out), _stream()))
     return out
 
 
@@ -212,7 +255,8 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None):
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     if gamma is not None:
         assert gamma.dtype == x.dtype and gamma.numel() == c1 + c2
-    check(lib.e2eft_groupnorm_fwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), nbytes, _stream()))
+    with _timed("groupnorm", 0.0, 2.0 * B * H * W * (c1 + c2) * x.element_size()):
+        check(lib.e2eft_groupnorm_fwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), nbytes, _stream()))
     return out
 
 
@@ -275,7 +319,8 @@ def attention(q, k, v, heads, scale, kv_nseg=1, kv_bmod=None, out=None):
 
     d.ldq, d.ldk, d.ldv, d.ldo = ld3(q), ld3(k), ld3(v), ld3(out)
     d.scale = scale
-    check(_lib.load().e2eft_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _stream()))
+    with _timed("attn", 4.0 * B * heads * Nq * Nk * kv_nseg * 64):
+        check(_lib.load().e2eft_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _stream()))
     return out
 
 

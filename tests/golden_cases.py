@@ -1,0 +1,111 @@
+"""Seeded cases shared by tests/golden/make_golden.py (which stores the oracle's / reference's outputs) and the tests
+(which regenerate the same inputs and weights from the seeds)."""
+import torch
+
+from oracle import config, unet_ref, vae_ref, pipeline_ref, synth
+
+LR_ITERS = [0, 1, 50, 99, 100, 101, 5000, 10050, 19999, 20000, 30000]
+
+
+def tiny_unet_sd():
+    return synth.synth_state_dict(unet_ref.unet_param_shapes(config.TINY_UNET), seed=1234)
+
+
+def tiny_vae_sd():
+    return synth.synth_state_dict(vae_ref.vae_param_shapes(config.TINY_VAE), seed=4321)
+
+
+def tiny_geo_sd():
+    return synth.synth_state_dict(unet_ref.unet_param_shapes(config.TINY_GEOWIZARD_UNET), seed=99)
+
+
+def unet_inputs(hw, batch=2, ctx_len=2, seed=7, xdim=128):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(batch, 8, *hw, generator=g), 0.5 * torch.randn(batch, ctx_len, xdim, generator=g)
+
+
+def vae_inputs():
+    g = torch.Generator().manual_seed(10)
+    return torch.rand(2, 3, 40, 56, generator=g) * 2 - 1, torch.randn(2, 4, 5, 7, generator=g)
+
+
+def geo_unet_inputs(Bh=2):
+    cfg = config.TINY_GEOWIZARD_UNET
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2 * Bh, 8, 16, 16, generator=g)
+    ctx = 0.5 * torch.randn(2 * Bh, 1, cfg["cross_attention_dim"], generator=g)
+    return x, ctx, pipeline_ref.geowizard_class_embedding(Bh, "outdoor")
+
+
+def geo_pipe_inputs():
+    cfg = config.TINY_GEOWIZARD_UNET
+    rgb, _ = synth.synth_inputs(2, 64, 64, 1, cfg["cross_attention_dim"], seed=5)
+    emb = 0.5 * torch.randn(2, 1, cfg["cross_attention_dim"], generator=torch.Generator().manual_seed(6))
+    return rgb, emb
+
+
+def ssi_inputs():
+    g = torch.Generator().manual_seed(61)
+    B, H, W = 3, 40, 56
+    tgt = torch.rand(B, 1, H, W, generator=g) * 2 - 1
+    pred = 0.6 * tgt + 0.2 + 0.05 * torch.randn(B, 1, H, W, generator=g)
+    mask = torch.rand(B, 1, H, W, generator=g) > 0.05
+    mask[2] = False
+    return pred, tgt, mask
+
+
+def angular_inputs():
+    g = torch.Generator().manual_seed(62)
+    B, H, W = 3, 40, 56
+    n = torch.nn.functional.normalize(torch.randn(B, 3, H, W, generator=g), dim=1)
+    nt = torch.nn.functional.normalize(n + 0.3 * torch.randn(B, 3, H, W, generator=g), dim=1)
+    mask = torch.rand(B, 1, H, W, generator=g) > 0.05
+    return n, nt, mask
+
+
+def _unet(hw, **kw):
+    x, ctx = unet_inputs(hw, **kw)
+    return {"out": unet_ref.unet_forward(tiny_unet_sd(), config.TINY_UNET, x, 999, ctx)}
+
+
+def _unet77():
+    x, ctx = unet_inputs((8, 8), batch=3, ctx_len=77, seed=8)
+    return {"out": unet_ref.unet_forward(tiny_unet_sd(), config.TINY_UNET, x, torch.full((3,), 999), ctx)}
+
+
+def _geo_unet():
+    x, ctx, cls = geo_unet_inputs()
+    return {"out": unet_ref.unet_forward(tiny_geo_sd(), config.TINY_GEOWIZARD_UNET, x, 999, ctx, class_labels=cls)}
+
+
+def _vae():
+    rgb, z = vae_inputs()
+    sd = tiny_vae_sd()
+    return {"moments": vae_ref.quant_conv(sd, vae_ref.encoder_forward(sd, config.TINY_VAE, rgb)),
+            "dec": vae_ref.decoder_forward(sd, config.TINY_VAE, vae_ref.post_quant_conv(sd, z))}
+
+
+def _pipe():
+    rgb, ctx = synth.synth_inputs(2, 64, 96, 2, 128, seed=3)
+    usd, vsd = tiny_unet_sd(), tiny_vae_sd()
+    d, x0 = pipeline_ref.single_infer_ref(usd, config.TINY_UNET, vsd, config.TINY_VAE, rgb, ctx, normals=False, return_latent=True)
+    n = pipeline_ref.single_infer_ref(usd, config.TINY_UNET, vsd, config.TINY_VAE, rgb, ctx, normals=True)
+    return {"depth": d, "x0": x0, "normal": n}
+
+
+def _geo_pipe():
+    rgb, emb = geo_pipe_inputs()
+    d, n, x0 = pipeline_ref.geowizard_infer_ref(tiny_geo_sd(), config.TINY_GEOWIZARD_UNET, tiny_vae_sd(), config.TINY_VAE, rgb, emb,
+                                                "indoor", return_latent=True)
+    return {"depth": d, "normal": n, "x0": x0}
+
+
+MODEL_CASES = {
+    "unet_16x16": lambda: _unet((16, 16)),
+    "unet_20x12": lambda: _unet((20, 12)),
+    "unet_ctx77": _unet77,
+    "geo_unet": _geo_unet,
+    "vae": _vae,
+    "pipe": _pipe,
+    "geo_pipe": _geo_pipe,
+}
