@@ -1,0 +1,105 @@
+"""Host-side logic of the product package on CPU (no kernels run): parameter layout, weight packing, config surface,
+scheduler, checkpoint round trip, rank sharding."""
+import os
+
+import pytest
+import torch
+
+from oracle import config, unet_ref, vae_ref
+
+
+def test_state_dict_keys_match_diffusers_layout():
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    for cfg in (config.TINY_UNET, config.TINY_GEOWIZARD_UNET):
+        sd = UNet2DConditionModel(**cfg).state_dict()
+        sh = unet_ref.unet_param_shapes(cfg)
+        assert set(sd) == set(sh) and all(tuple(sd[k].shape) == tuple(sh[k]) for k in sh)
+    sd = AutoencoderKL(**config.TINY_VAE).state_dict()
+    sh = vae_ref.vae_param_shapes(config.TINY_VAE)
+    assert set(sd) == set(sh) and all(tuple(sd[k].shape) == tuple(sh[k]) for k in sh)
+    with torch.device("meta"):
+        full = UNet2DConditionModel(in_channels=8)
+    assert sum(p.numel() for p in full.parameters()) == 865_922_244
+
+
+def test_packed_conv_weight_layout_and_cache():
+    from diffusion_e2e_ft_amd.modules import Conv2d, packed_conv_weight
+    c = Conv2d(3, 5, 3, 1, 1)
+    w = packed_conv_weight(c)
+    assert w.shape == (5, 9 * 4)  # fp32: Cin 3 -> 4
+    ref = torch.nn.functional.pad(c.weight.detach().permute(0, 2, 3, 1), (0, 1)).reshape(5, -1)
+    assert torch.equal(w, ref)
+    assert packed_conv_weight(c) is w           # cached
+    with torch.no_grad():
+        c.weight.mul_(2.0)                      # in-place update (optimizer step) bumps _version -> repack
+    w2 = packed_conv_weight(c)
+    assert w2 is not w and torch.equal(w2, 2 * ref)
+    h = Conv2d(3, 5, 3, 1, 1).half()
+    assert packed_conv_weight(h).shape == (5, 9 * 8)  # fp16: Cin 3 -> 8
+
+
+def test_config_surface_and_hooks():
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    m = UNet2DConditionModel(**dict(config.TINY_UNET, in_channels=4))
+    assert m.config["in_channels"] == 4 and m.config.in_channels == 4
+    assert isinstance(m.conv_in, torch.nn.Conv2d) and m.conv_in.out_channels == 64
+    ref_prep = "/root/reference/training/util/unet_prep.py"
+    if os.path.exists(ref_prep):  # run the reference's own hook on the product module
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ref_prep", ref_prep)
+        prep = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(prep)
+        w0, b0 = m.conv_in.weight.detach().clone(), m.conv_in.bias.detach().clone()
+        prep.replace_unet_conv_in(m, repeat=2)
+        assert m.config["in_channels"] == 8 and m.conv_in.weight.shape == (64, 8, 3, 3)
+        assert torch.allclose(m.conv_in.weight, w0.repeat(1, 2, 1, 1) / 2) and torch.allclose(m.conv_in.bias, b0 / 2)
+        assert "conv_in.weight" in m.state_dict()
+    m.enable_gradient_checkpointing()
+    m.enable_xformers_memory_efficient_attention()
+    m.register_to_config(sample_size=32)
+    assert m.config.sample_size == 32
+
+
+def test_save_and_load_pretrained_roundtrip(tmp_path):
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    m = UNet2DConditionModel(**config.TINY_UNET)
+    m.save_pretrained(str(tmp_path / "unet"))
+    m2 = UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet")
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    assert tuple(m2.config.block_out_channels) == tuple(config.TINY_UNET["block_out_channels"])
+    v = AutoencoderKL(**config.TINY_VAE)
+    v.save_pretrained(str(tmp_path / "vae"))
+    v2 = AutoencoderKL.from_pretrained(str(tmp_path / "vae"))
+    assert all(torch.equal(a, b) for a, b in zip(v.state_dict().values(), v2.state_dict().values()))
+    assert v2.config.scaling_factor == 0.18215
+
+
+def test_scheduler_matches_oracle_constants():
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    from oracle import pipeline_ref
+    s = DDIMScheduler()
+    s.set_timesteps(1)
+    assert s.timesteps.tolist() == [999]
+    s.set_timesteps(4)
+    assert s.timesteps.tolist() == [999, 749, 499, 249]
+    sa, sb = s.x0_coefficients(999)
+    assert abs(sa - 0.06826489) < 1e-7 and abs(sb - 0.99766725) < 1e-7
+    s.set_timesteps(1)
+    v, x = torch.randn(1, 4, 3, 3), torch.randn(1, 4, 3, 3)
+    assert torch.allclose(s.step(v, 999, x).pred_original_sample, pipeline_ref.v_to_x0(v, x, 999), atol=1e-6)
+    lead = DDIMScheduler(timestep_spacing="leading")
+    lead.set_timesteps(1)
+    assert lead.timesteps.tolist() == [1]  # why the reference forces trailing (Marigold/run.py:157-162)
+
+
+def test_shard_range():
+    from diffusion_e2e_ft_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 16, 17):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
