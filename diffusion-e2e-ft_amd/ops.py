@@ -19,15 +19,28 @@ class KernelTimer:
     def __init__(self):
         self.rec = {}
 
-    def add(self, name, start, end, flops, nbytes):
-        self.rec.setdefault(name, []).append((start, end, flops, nbytes))
+    def add(self, name, start, end, flops, nbytes, label=None):
+        self.rec.setdefault(name, []).append((start, end, flops, nbytes, label))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for name, lst in self.rec.items():
-            ms = sum(s.elapsed_time(e) for s, e, _, _ in lst)
-            out[name] = dict(launches=len(lst), ms=ms, flops=float(sum(f for _, _, f, _ in lst)), bytes=float(sum(b for _, _, _, b in lst)))
+            ms = sum(r[0].elapsed_time(r[1]) for r in lst)
+            out[name] = dict(launches=len(lst), ms=ms, flops=float(sum(r[2] for r in lst)), bytes=float(sum(r[3] for r in lst)))
+        return out
+
+    def by_label(self):
+        """{(name, label): dict(launches, ms, flops, bytes)} for shape-level analysis"""
+        torch.cuda.synchronize()
+        out = {}
+        for name, lst in self.rec.items():
+            for r in lst:
+                d = out.setdefault((name, r[4]), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+                d["launches"] += 1
+                d["ms"] += r[0].elapsed_time(r[1])
+                d["flops"] += r[2]
+                d["bytes"] += r[3]
         return out
 
 
@@ -35,8 +48,8 @@ TIMER = None  # set to a KernelTimer to record
 
 
 class _timed:
-    def __init__(self, name, flops=0.0, nbytes=0.0):
-        self.name, self.flops, self.nbytes = name, flops, nbytes
+    def __init__(self, name, flops=0.0, nbytes=0.0, label=None):
+        self.name, self.flops, self.nbytes, self.label = name, flops, nbytes, label
 
     def __enter__(self):
         if TIMER is not None:
@@ -48,7 +61,7 @@ class _timed:
     def __exit__(self, *a):
         if TIMER is not None:
             self.e.record()
-            TIMER.add(self.name, self.s, self.e, self.flops, self.nbytes)
+            TIMER.add(self.name, self.s, self.e, self.flops, self.nbytes, self.label)
         return False
 
 
@@ -151,7 +164,8 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
         assert bias.dtype == x.dtype and bias.numel() == cout and bias.is_contiguous()
     if rowadd is not None:
         assert rowadd.dtype == x.dtype and tuple(rowadd.shape) == (B, cout) and rowadd.is_contiguous()
-    with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2)):
+    with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2),
+                label="conv%dx%ds%d%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", B, hout, wout, d.c1 + d.c2, cout)):
         check(_lib.load().e2eft_conv2d_fwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(w_packed), _ptr(bias), _ptr(rowadd),
                                            _ptr(residual), _ptr(out), _stream()))
     return out
@@ -178,7 +192,7 @@ def gemm(a, w, bias=None, residual=None, out=None, alpha=1.0, bias_along_m=False
         assert bias.dtype == a.dtype and bias.is_contiguous() and bias.numel() == (M if bias_along_m else N)
     if residual is not None:
         assert tuple(residual.shape) == (M, N) and residual.dtype == a.dtype
-    with _timed("igemm", 2.0 * M * N * K):
+    with _timed("igemm", 2.0 * M * N * K, label="gemm M%d N%d K%d" % (M, N, K)):
         check(_lib.load().e2eft_gemm(C.byref(d), _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), _stream()))
     return out
 
@@ -198,7 +212,7 @@ def bgemm_raw(dtype, m, n, k, a, lda, sa, w, ldw, sw, out, ldo, so, nzo, nzi, bi
     d.sr_o = d.sr_i = 0
     d.bias_along_m = 1 if bias_along_m else 0
     d.alpha = alpha
-    with _timed("igemm", 2.0 * m * n * k * nzo * nzi):
+    with _timed("igemm", 2.0 * m * n * k * nzo * nzi, label="bgemm z%d M%d N%d K%d" % (nzo * nzi, m, n, k)):
         check(_lib.load().e2eft_gemm(C.byref(d), _ptr(a), _ptr(w), _ptr(bias), _ptr(None), _ptr(out), _stream()))
     return out
 
@@ -255,7 +269,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None):
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     if gamma is not None:
         assert gamma.dtype == x.dtype and gamma.numel() == c1 + c2
-    with _timed("groupnorm", 0.0, 2.0 * B * H * W * (c1 + c2) * x.element_size()):
+    with _timed("groupnorm", 0.0, 2.0 * B * H * W * (c1 + c2) * x.element_size(), label="gn B%d %dx%d C%d" % (B, H, W, c1 + c2)):
         check(lib.e2eft_groupnorm_fwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), nbytes, _stream()))
     return out
 
@@ -319,7 +333,7 @@ def attention(q, k, v, heads, scale, kv_nseg=1, kv_bmod=None, out=None):
 
     d.ldq, d.ldk, d.ldv, d.ldo = ld3(q), ld3(k), ld3(v), ld3(out)
     d.scale = scale
-    with _timed("attn", 4.0 * B * heads * Nq * Nk * kv_nseg * 64):
+    with _timed("attn", 4.0 * B * heads * Nq * Nk * kv_nseg * 64, label="attn B%d h%d Nq%d Nk%d" % (B, heads, Nq, Nk * kv_nseg)):
         check(_lib.load().e2eft_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _stream()))
     return out
 
