@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libe2eft.so")
-SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "loss.hip"]
+SOURCES = ["api.hip", "igemm.hip", "igemm2.hip", "norm.hip", "attn.hip", "elementwise.hip", "loss.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -44,7 +44,7 @@ def build(force=False, verbose=True):
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
-        deps = [srcp, os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "e2eft.h")]
+        deps = [srcp, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm.h"), os.path.join(HERE, "..", "include", "e2eft.h")]
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(d) for d in deps):
             return obj
         cmd = [hipcc] + FLAGS + ["-c", srcp, "-o", obj]

@@ -15,6 +15,8 @@
 // parity path.  blockIdx -> tile mapping is XCD-aware (bijective remap) so that the N-tiles sharing one A panel
 // run on the same XCD's L2.
 #include "common.h"
+#include "igemm.h"
+#include <stdlib.h>
 
 namespace e2eft {
 
@@ -23,26 +25,7 @@ constexpr int ROWB = 128;        // data bytes per LDS row = one k-tile
 constexpr int ROWS = ROWB + 16;  // padded LDS row stride (bytes)
 constexpr int TILE_BYTES = 128 * ROWS;
 
-struct IgemmParams {
-    const void* x1;
-    const void* x2;
-    const void* w;
-    const void* bias;
-    const void* rowadd;
-    const void* residual;
-    void* out;
-    int M, N, K;
-    int ldx1, ldx2, c1, cin;
-    int hin, win, hl, wl, kh, kw, stride, pad_t, pad_l, hout, wout;
-    float up_sh, up_sw;
-    int ldw, ldr, ldo;
-    int bias_along_m;
-    int rows_per_img;
-    float alpha;
-    int nzi;
-    long sa_o, sa_i, sw_o, sw_i, so_o, so_i, sr_o, sr_i;
-    int mtiles, ntiles;
-};
+
 
 template <typename T> struct Mma;
 template <> struct Mma<f16> {
@@ -258,6 +241,13 @@ static int run_igemm(int dtype, int mode, IgemmParams& p, int nz, void* stream) 
     if ((long)p.mtiles * p.ntiles > 2000000000L) return fail(E2EFT_ERR_BAD_ARG, "igemm: grid too large");
     if (nz > 65535) return fail(E2EFT_ERR_BAD_ARG, "igemm: batch %d > 65535", nz);
     hipStream_t s = (hipStream_t)stream;
+    {
+        // variant choice: the 256x128 LDS-DMA kernel needs enough tiles to fill 256 CUs; small problems keep the 128x128
+        // register-staged kernel (2 workgroups per CU).  E2EFT_IGEMM=1|2 forces a variant (A/B tests).
+        static const int forced = [] { const char* e = getenv("E2EFT_IGEMM"); return e ? atoi(e) : 0; }();
+        const long tiles2 = (long)cdiv(p.M, 256) * p.ntiles;
+        if (forced == 2 || (forced == 0 && tiles2 >= 192)) return launch_igemm_v2(dtype, mode, p, nz, s);
+    }
     if (dtype == E2EFT_F32) return mode ? launch_igemm<float, 1>(p, nz, s) : launch_igemm<float, 0>(p, nz, s);
     if (dtype == E2EFT_F16) return mode ? launch_igemm<f16, 1>(p, nz, s) : launch_igemm<f16, 0>(p, nz, s);
     if (dtype == E2EFT_BF16) return mode ? launch_igemm<bf16, 1>(p, nz, s) : launch_igemm<bf16, 0>(p, nz, s);

@@ -1,0 +1,260 @@
+// igemm2.hip — implicit-GEMM conv / NT-GEMM, large-problem variant: 256x128 tile, 8 waves, LDS-DMA 3-stage ring.
+//
+// Same contract as igemm.hip (out = alpha*(A W^T + bias + rowadd) + residual; im2col gather with zero padding, fused
+// nearest upsample, two-source channel concat).  What changes is how operands reach the MFMAs:
+//   * global -> LDS by `global_load_lds_dwordx4` (LDS-DMA, 1 KiB per wave-instruction, no staging VGPRs); the im2col
+//     gather is the per-lane SOURCE address, zero padding / ragged edges read a 16-byte zero block in device memory;
+//   * the LDS image of a piece is lane-linear (8 rows x 128 B), so bank conflicts are removed by an XOR swizzle applied
+//     to the source chunk index and to the fragment reads alike: slot = chunk ^ ((row >> 1) & 7) — 16 consecutive rows
+//     of one chunk column then cover all 16 sixteen-byte slots of the 256-byte bank row (conflict-free ds_read_b128);
+//   * 3-stage ring, prefetch distance 2 k-tiles: ~96 KiB of loads in flight per CU, counted `s_waitcnt vmcnt(6)`
+//     (never 0 in the main loop) and ONE raw s_barrier per k-tile;
+//   * 8 waves (4 x 2), each 64x64 = 2x2 MFMA 32x32 tiles: one workgroup per CU, two waves per SIMD.
+#include "igemm.h"
+
+namespace e2eft {
+
+constexpr int BM2 = 256, BN2 = 128;
+constexpr int A_STAGE = BM2 * 128;   // bytes: 256 rows x 128 B
+constexpr int B_STAGE = BN2 * 128;
+constexpr int STAGE2 = A_STAGE + B_STAGE;
+constexpr int NSTAGE = 3;
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <typename T> struct Mma2;
+template <> struct Mma2<f16> {
+    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma2<bf16> {
+    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bhalf8, a), __builtin_bit_cast(bhalf8, b), c, 0, 0, 0);
+    }
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE2];
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int BK = 128 / (int)sizeof(T);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int nblk = p.mtiles * p.ntiles;
+    int lid;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = lid / p.ntiles, nt = lid - mt * p.ntiles;
+    const int m0 = mt * BM2, n0 = nt * BN2;
+    const int z = blockIdx.y;
+    const int zo = z / p.nzi, zi = z - zo * p.nzi;
+
+    const T* __restrict__ X1 = (const T*)p.x1 + zo * p.sa_o + zi * p.sa_i;
+    const T* __restrict__ X2 = (const T*)p.x2;
+    const T* __restrict__ W = (const T*)p.w + zo * p.sw_o + zi * p.sw_i;
+    const T* zsrc = (const T*)g_zero16;
+
+    // ---- loader mapping: a wave-instruction fills one 1-KiB piece = 8 rows x 8 chunks; lane -> (row lane>>3, slot lane&7).
+    // A pieces: rows 8*wave + 64*i (i < 4); B pieces: rows 8*wave + 64*i (i < 2).  The lane's LOGICAL k-chunk is
+    // slot ^ ((row >> 1) & 7), identical for all of its pieces.
+    const int lrow = 8 * wave + (lane >> 3);
+    const int jc = (lane & 7) ^ ((lrow >> 1) & 7);
+    long a_base[4];
+    int a_iy0[4], a_ix0[4];
+    bool a_ok[4];
+    long w_base[2];
+    bool w_ok[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + lrow + 64 * i;
+        a_ok[i] = m < p.M;
+        if (MODE == 0) {
+            a_base[i] = (long)m * p.ldx1;
+            a_iy0[i] = a_ix0[i] = 0;
+        } else {
+            const int hw = p.hout * p.wout;
+            const int mm = a_ok[i] ? m : 0;
+            const int b = mm / hw;
+            const int rem = mm - b * hw;
+            const int oy = rem / p.wout, ox = rem - oy * p.wout;
+            a_base[i] = b;
+            a_iy0[i] = oy * p.stride - p.pad_t;
+            a_ix0[i] = ox * p.stride - p.pad_l;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + lrow + 64 * i;
+        w_ok[i] = n < p.N;
+        w_base[i] = (long)n * p.ldw;
+    }
+
+    // incremental k decomposition of this thread's chunk: k = kt*BK + jc*EPC = (ky*kw + kx)*cin + c
+    int k_cur = jc * EPC;
+    int c_cur = 0, kx_cur = 0, ky_cur = 0;
+    if (MODE == 1) {
+        const int kpos = k_cur / p.cin;
+        c_cur = k_cur - kpos * p.cin;
+        ky_cur = kpos / p.kw;
+        kx_cur = kpos - ky_cur * p.kw;
+    }
+
+    auto issue = [&](int stage) {   // issue the DMA of the NEXT k-tile (tiles are issued in order 0,1,2,...)
+        char* sa = smem + stage * STAGE2 + wave * 1024;
+        char* sb = sa + A_STAGE;
+        const bool kok = k_cur < p.K;
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const T* src = (kok && a_ok[i]) ? X1 + a_base[i] + k_cur : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + i * 8192), 16, 0, 0);
+            }
+        } else {
+            const bool second = c_cur >= p.c1;
+            const T* sbase = second ? X2 : X1;
+            const int ld = second ? p.ldx2 : p.ldx1;
+            const int cc = second ? c_cur - p.c1 : c_cur;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = a_iy0[i] + ky_cur, ix = a_ix0[i] + kx_cur;
+                const bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
+                int sy = iy, sx = ix;
+                if (p.hl != p.hin) sy = min((int)floorf(iy * p.up_sh), p.hin - 1);
+                if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
+                const long pix = (a_base[i] * p.hin + sy) * p.win + sx;
+                const T* src = ok ? sbase + pix * ld + cc : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + i * 8192), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const T* src = (kok && w_ok[i]) ? W + w_base[i] + k_cur : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + i * 8192), 16, 0, 0);
+        }
+        // advance to the next k-tile
+        k_cur += BK;
+        if (MODE == 1) {
+            c_cur += BK;
+            while (c_cur >= p.cin) {
+                c_cur -= p.cin;
+                if (++kx_cur == p.kw) { kx_cur = 0; ++ky_cur; }
+            }
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int sw = (l31 >> 1) & 7;   // read-side swizzle: rows wm*64 + i*32 + l31 -> ((row >> 1) & 7) == (l31 >> 1) & 7
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE2 + (wm * 64 + l31) * 128;
+        const char* sb = smem + stage * STAGE2 + A_STAGE + (wn * 64 + l31) * 128;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = ((ks * 2 + h) ^ sw) * 16;
+                u32x4 a0 = *reinterpret_cast<const u32x4*>(sa + off);
+                u32x4 a1 = *reinterpret_cast<const u32x4*>(sa + 32 * 128 + off);
+                u32x4 b0 = *reinterpret_cast<const u32x4*>(sb + off);
+                u32x4 b1 = *reinterpret_cast<const u32x4*>(sb + 32 * 128 + off);
+                acc[0][0] = Mma2<T>::run(a0, b0, acc[0][0]);
+                acc[0][1] = Mma2<T>::run(a0, b1, acc[0][1]);
+                acc[1][0] = Mma2<T>::run(a1, b0, acc[1][0]);
+                acc[1][1] = Mma2<T>::run(a1, b1, acc[1][1]);
+            }
+        } else {
+            // fp32: MFMA 32x32x2 step s pairs k-slot s of the lower half (lanes 0-31, chunks 0-3) with k-slot s of the
+            // upper half (lanes 32-63, chunks 4-7); the same pairing is used for A and W.
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int off = ((h * 4 + qd) ^ sw) * 16;
+                floatx4 a0 = *reinterpret_cast<const floatx4*>(sa + off);
+                floatx4 a1 = *reinterpret_cast<const floatx4*>(sa + 32 * 128 + off);
+                floatx4 b0 = *reinterpret_cast<const floatx4*>(sb + off);
+                floatx4 b1 = *reinterpret_cast<const floatx4*>(sb + 32 * 128 + off);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- main loop: ring of 3 stages, tiles kt+1 and kt+2 in flight while tile kt is multiplied ----
+    const int nk = (p.K + BK - 1) / BK;
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's DMA of tile kt has landed once at most the younger tile's 6 loads are still outstanding
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave's pieces of tile kt are in LDS; every wave is done reading tile kt-1
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) issue((kt + 2) % NSTAGE);   // overwrites the stage tile kt-1 lived in
+        compute(kt % NSTAGE);
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- epilogue (same as igemm.hip) ----
+    const T* __restrict__ bias = (const T*)p.bias;
+    const T* __restrict__ rowadd = (const T*)p.rowadd;
+    const T* __restrict__ res = p.residual ? (const T*)p.residual + zo * p.sr_o + zi * p.sr_i : nullptr;
+    T* __restrict__ out = (T*)p.out + zo * p.so_o + zi * p.so_i;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (n >= p.N) continue;
+        const float bn = (bias && !p.bias_along_m) ? to_f(bias[n]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bn;
+                if (bias && p.bias_along_m) v += to_f(bias[m]);
+                if (rowadd) v += to_f(rowadd[(long)(m / p.rows_per_img) * p.N + n]);
+                v *= p.alpha;
+                if (res) v += to_f(res[(long)m * p.ldr + n]);
+                out[(long)m * p.ldo + n] = from_f<T>(v);
+            }
+        }
+    }
+}
+
+template <typename T, int MODE> static int launch2(const IgemmParams& p, int nz, hipStream_t s) {
+    dim3 grid(p.mtiles * p.ntiles, nz, 1);
+    hipLaunchKernelGGL((igemm2_kernel<T, MODE>), grid, dim3(512), 0, s, p);
+    return check_launch("igemm2");
+}
+
+int launch_igemm_v2(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s) {
+    p.mtiles = cdiv(p.M, BM2);
+    p.ntiles = cdiv(p.N, BN2);
+    if (dtype == E2EFT_F32) return mode ? launch2<float, 1>(p, nz, s) : launch2<float, 0>(p, nz, s);
+    if (dtype == E2EFT_F16) return mode ? launch2<f16, 1>(p, nz, s) : launch2<f16, 0>(p, nz, s);
+    if (dtype == E2EFT_BF16) return mode ? launch2<bf16, 1>(p, nz, s) : launch2<bf16, 0>(p, nz, s);
+    return fail(E2EFT_ERR_BAD_ARG, "igemm2: bad dtype %d", dtype);
+}
+
+}  // namespace e2eft
