@@ -201,31 +201,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias / per-image row vector / alpha / residual, direct stores ----
-    const T* __restrict__ bias = (const T*)p.bias;
-    const T* __restrict__ rowadd = (const T*)p.rowadd;
-    const T* __restrict__ res = p.residual ? (const T*)p.residual + zo * p.sr_o + zi * p.sr_i : nullptr;
-    T* __restrict__ out = (T*)p.out + zo * p.so_o + zi * p.so_i;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
-        if (n >= p.N) continue;
-        const float bn = (bias && !p.bias_along_m) ? to_f(bias[n]) : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bn;
-                if (bias && p.bias_along_m) v += to_f(bias[m]);
-                if (rowadd) v += to_f(rowadd[(long)(m / p.rows_per_img) * p.N + n]);
-                v *= p.alpha;
-                if (res) v += to_f(res[(long)m * p.ldr + n]);
-                out[(long)m * p.ldo + n] = from_f<T>(v);
-            }
-        }
-    }
+    // ---- epilogue: LDS-staged, vectorised (igemm.h) ----
+    igemm_epilogue<T, BM, BN, 256>(p, smem, acc, wm, wn, l31, h, m0, n0, zo, zi);
 }
 
 template <typename T, int MODE> static int launch_igemm(const IgemmParams& p, int nz, hipStream_t s) {
