@@ -11,6 +11,7 @@
 //     (never 0 in the main loop) and ONE raw s_barrier per k-tile;
 //   * 8 waves (4 x 2), each 64x64 = 2x2 MFMA 32x32 tiles: one workgroup per CU, two waves per SIMD.
 #include "igemm.h"
+#include <stdlib.h>
 
 namespace e2eft {
 
@@ -37,7 +38,15 @@ template <> struct Mma2<bf16> {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T, int MODE>
+// FAST: every k-tile lies inside one filter tap and one source tensor (cin % BK == 0, c1 % BK == 0; GEMM: K % BK == 0).
+// Then tap / channel / source are wave-uniform scalars, a row's pixel offset is recomputed only when the tap changes,
+// and the per-DMA address work is ONE v_add: loads go through `buffer_load ... lds` with a 32-bit byte offset relative
+// to a per-workgroup base, invalid rows / padding taps carry an out-of-range offset and the buffer bounds check writes
+// the zeros.  !FAST keeps the fully general per-lane address path (global_load_lds from a pointer or the zero block).
+constexpr unsigned int OOB_SENTINEL = 0xF0000000u;
+constexpr unsigned int SRD_RECORDS = 0xE0000000u;
+
+template <typename T, int MODE, bool FAST>
 __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE2];
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -154,6 +163,78 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
         }
     };
 
+    // ---------------- FAST path state ----------------
+    unsigned int off1[4] = {0, 0, 0, 0}, off2[4] = {0, 0, 0, 0}, woff[2] = {0, 0};
+    int brel[4] = {0, 0, 0, 0};
+    int tile_c = 0, tap = 0;
+    unsigned int kbytes = 0;
+    __amdgpu_buffer_rsrc_t rs1, rs2, rsw;
+    if constexpr (FAST) {
+        const T* b1;
+        const T* b2 = X2;
+        if (MODE == 0) {
+            b1 = X1 + (long)m0 * p.ldx1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                off1[i] = a_ok[i] ? (unsigned)((lrow + 64 * i) * p.ldx1 + jc * EPC) * (unsigned)sizeof(T) : OOB_SENTINEL;
+        } else {
+            const int hw = p.hout * p.wout;
+            const int b0 = m0 / hw;                       // first image touched by this tile (uniform)
+            b1 = X1 + (long)b0 * p.hin * p.win * p.ldx1;
+            if (X2) b2 = X2 + (long)b0 * p.hin * p.win * p.ldx2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) brel[i] = (int)a_base[i] - b0;
+        }
+        rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, SRD_RECORDS, 0x00020000);
+        rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(b2 ? b2 : b1), 0, SRD_RECORDS, 0x00020000);
+        rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)n0 * p.ldw), 0, SRD_RECORDS, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            woff[i] = w_ok[i] ? (unsigned)((lrow + 64 * i) * p.ldw + jc * EPC) * (unsigned)sizeof(T) : OOB_SENTINEL;
+    }
+    auto retap = [&]() {   // per-row pixel offsets of the current filter tap (uniform branch, once per tap)
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
+            int sy = iy, sx = ix;
+            if (p.hl != p.hin) sy = min((int)floorf(iy * p.up_sh), p.hin - 1);
+            if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
+            const unsigned pix = (unsigned)((brel[i] * p.hin + sy) * p.win + sx);
+            off1[i] = ok ? (pix * (unsigned)p.ldx1 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T) : OOB_SENTINEL;
+            off2[i] = ok ? (pix * (unsigned)p.ldx2 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T) : OOB_SENTINEL;
+        }
+    };
+    auto issue_fast = [&](int stage) {
+        char* sa = smem + stage * STAGE2 + wave * 1024;
+        char* sb = sa + A_STAGE;
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(sa + i * 8192), 16, off1[i] + kbytes, 0, 0, 0);
+        } else {
+            if (tile_c == 0) retap();
+            if (tile_c < p.c1) {
+                const unsigned cb = (unsigned)tile_c * (unsigned)sizeof(T);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(sa + i * 8192), 16, off1[i] + cb, 0, 0, 0);
+            } else {
+                const unsigned cb = (unsigned)(tile_c - p.c1) * (unsigned)sizeof(T);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lptr_t)(sa + i * 8192), 16, off2[i] + cb, 0, 0, 0);
+            }
+            tile_c += BK;
+            if (tile_c >= p.cin) { tile_c = 0; ++tap; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(sb + i * 8192), 16, woff[i] + kbytes, 0, 0, 0);
+        kbytes += 128;
+    };
+
     floatx16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -202,15 +283,16 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
 
     // ---- main loop: ring of 3 stages, tiles kt+1 and kt+2 in flight while tile kt is multiplied ----
     const int nk = (p.K + BK - 1) / BK;
-    issue(0);
-    if (nk > 1) issue(1);
+    auto issue_any = [&](int stage) { if constexpr (FAST) issue_fast(stage); else issue(stage); };
+    issue_any(0);
+    if (nk > 1) issue_any(1);
     for (int kt = 0; kt < nk; ++kt) {
         // this wave's DMA of tile kt has landed once at most the younger tile's 6 loads are still outstanding
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // every wave's pieces of tile kt are in LDS; every wave is done reading tile kt-1
         asm volatile("" ::: "memory");
-        if (kt + 2 < nk) issue((kt + 2) % NSTAGE);   // overwrites the stage tile kt-1 lived in
+        if (kt + 2 < nk) issue_any((kt + 2) % NSTAGE);   // overwrites the stage tile kt-1 lived in
         compute(kt % NSTAGE);
         asm volatile("" ::: "memory");
     }
@@ -221,7 +303,18 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
 
 template <typename T, int MODE> static int launch2(const IgemmParams& p, int nz, hipStream_t s) {
     dim3 grid(p.mtiles * p.ntiles, nz, 1);
-    hipLaunchKernelGGL((igemm2_kernel<T, MODE>), grid, dim3(512), 0, s, p);
+    constexpr int BK = 128 / (int)sizeof(T);
+    bool fast;
+    if (MODE == 0) {
+        fast = p.K % BK == 0 && (long)256 * p.ldx1 * (long)sizeof(T) < 0x40000000L && (long)128 * p.ldw * (long)sizeof(T) < 0x40000000L;
+    } else {
+        const long img_bytes = (long)p.hin * p.win * (p.ldx1 > p.ldx2 ? p.ldx1 : p.ldx2) * (long)sizeof(T);
+        const long span_imgs = 256 / ((long)p.hout * p.wout) + 2;
+        fast = p.cin % BK == 0 && p.c1 % BK == 0 && img_bytes * span_imgs < 0xD0000000L && (long)128 * p.ldw * (long)sizeof(T) < 0x40000000L;
+    }
+    static const bool nofast = getenv("E2EFT_IGEMM_NOFAST") != nullptr;
+    if (fast && !nofast) hipLaunchKernelGGL((igemm2_kernel<T, MODE, true>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((igemm2_kernel<T, MODE, false>), grid, dim3(512), 0, s, p);
     return check_launch("igemm2");
 }
 
