@@ -206,33 +206,41 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
             off2[i] = ok ? (pix * (unsigned)p.ldx2 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T) : OOB_SENTINEL;
         }
     };
-    auto issue_fast = [&](int stage) {
-        char* sa = smem + stage * STAGE2 + wave * 1024;
-        char* sb = sa + A_STAGE;
+    // DMA of one k-tile = 6 pieces per wave (A0..A3, B0, B1).  prep_fast() computes the six 32-bit offsets (a v_add
+    // each); fire_fast(stage, piece) issues one piece — the main loop spreads them between the MFMA groups so that the
+    // ~60-180 cycle issue cost of an LDS-DMA instruction overlaps this wave's own MFMA execution.
+    unsigned int voff[6];
+    bool use2 = false;
+    auto prep_fast = [&]() {
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(sa + i * 8192), 16, off1[i] + kbytes, 0, 0, 0);
+            for (int i = 0; i < 4; ++i) voff[i] = off1[i] + kbytes;
         } else {
             if (tile_c == 0) retap();
-            if (tile_c < p.c1) {
-                const unsigned cb = (unsigned)tile_c * (unsigned)sizeof(T);
+            use2 = tile_c >= p.c1;
+            const unsigned cb = (unsigned)(use2 ? tile_c - p.c1 : tile_c) * (unsigned)sizeof(T);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(sa + i * 8192), 16, off1[i] + cb, 0, 0, 0);
-            } else {
-                const unsigned cb = (unsigned)(tile_c - p.c1) * (unsigned)sizeof(T);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lptr_t)(sa + i * 8192), 16, off2[i] + cb, 0, 0, 0);
-            }
+            for (int i = 0; i < 4; ++i) voff[i] = (use2 ? off2[i] : off1[i]) + cb;
             tile_c += BK;
             if (tile_c >= p.cin) { tile_c = 0; ++tap; }
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(sb + i * 8192), 16, woff[i] + kbytes, 0, 0, 0);
+        voff[4] = woff[0] + kbytes;
+        voff[5] = woff[1] + kbytes;
         kbytes += 128;
+    };
+    auto fire_fast = [&](int stage, int piece) {
+        char* sa = smem + stage * STAGE2 + wave * 1024;
+        if (piece < 4) {
+            if (MODE == 1 && use2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lptr_t)(sa + piece * 8192), 16, voff[piece], 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(sa + piece * 8192), 16, voff[piece], 0, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(sa + A_STAGE + (piece - 4) * 8192), 16, voff[piece], 0, 0, 0);
+        }
+    };
+    auto issue_fast = [&](int stage) {
+        prep_fast();
+#pragma unroll
+        for (int q = 0; q < 6; ++q) fire_fast(stage, q);
     };
 
     floatx16 acc[2][2];
@@ -244,32 +252,63 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int sw = (l31 >> 1) & 7;   // read-side swizzle: rows wm*64 + i*32 + l31 -> ((row >> 1) & 7) == (l31 >> 1) & 7
-    auto compute = [&](int stage) {
-        const char* sa = smem + stage * STAGE2 + (wm * 64 + l31) * 128;
-        const char* sb = smem + stage * STAGE2 + A_STAGE + (wn * 64 + l31) * 128;
+    // fragment byte offsets inside a stage (per lane, fixed for the whole kernel); second row-subtile = +32*128 immediate
+    int aoff[4], boff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int chunk = sizeof(T) == 2 ? (g * 2 + h) : (h * 4 + g);
+        aoff[g] = (wm * 64 + l31) * 128 + ((chunk ^ sw) * 16);
+        boff[g] = A_STAGE + (wn * 64 + l31) * 128 + ((chunk ^ sw) * 16);
+    }
+    // One k-tile of MFMAs out of LDS stage `stage`; when `dma` is set the six DMA pieces of a later k-tile (offsets already
+    // in voff[]) are issued between the MFMA groups: pieces (0,1) (2,3) (4,5) after the fragment reads of groups 0,1,2.
+    auto compute = [&](int stage, bool dma, int dstage) {
+        const char* sbase = smem + stage * STAGE2;
         if constexpr (sizeof(T) == 2) {
+            u32x4 a0[2], a1[2], b0[2], b1[2];
+            a0[0] = *reinterpret_cast<const u32x4*>(sbase + aoff[0]);
+            a1[0] = *reinterpret_cast<const u32x4*>(sbase + aoff[0] + 32 * 128);
+            b0[0] = *reinterpret_cast<const u32x4*>(sbase + boff[0]);
+            b1[0] = *reinterpret_cast<const u32x4*>(sbase + boff[0] + 32 * 128);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int off = ((ks * 2 + h) ^ sw) * 16;
-                u32x4 a0 = *reinterpret_cast<const u32x4*>(sa + off);
-                u32x4 a1 = *reinterpret_cast<const u32x4*>(sa + 32 * 128 + off);
-                u32x4 b0 = *reinterpret_cast<const u32x4*>(sb + off);
-                u32x4 b1 = *reinterpret_cast<const u32x4*>(sb + 32 * 128 + off);
-                acc[0][0] = Mma2<T>::run(a0, b0, acc[0][0]);
-                acc[0][1] = Mma2<T>::run(a0, b1, acc[0][1]);
-                acc[1][0] = Mma2<T>::run(a1, b0, acc[1][0]);
-                acc[1][1] = Mma2<T>::run(a1, b1, acc[1][1]);
+                const int c = ks & 1, nx = c ^ 1;
+                if constexpr (FAST) {
+                    if (dma && ks < 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        fire_fast(dstage, 2 * ks);
+                        fire_fast(dstage, 2 * ks + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (ks < 3) {
+                    a0[nx] = *reinterpret_cast<const u32x4*>(sbase + aoff[ks + 1]);
+                    a1[nx] = *reinterpret_cast<const u32x4*>(sbase + aoff[ks + 1] + 32 * 128);
+                    b0[nx] = *reinterpret_cast<const u32x4*>(sbase + boff[ks + 1]);
+                    b1[nx] = *reinterpret_cast<const u32x4*>(sbase + boff[ks + 1] + 32 * 128);
+                }
+                acc[0][0] = Mma2<T>::run(a0[c], b0[c], acc[0][0]);
+                acc[0][1] = Mma2<T>::run(a0[c], b1[c], acc[0][1]);
+                acc[1][0] = Mma2<T>::run(a1[c], b0[c], acc[1][0]);
+                acc[1][1] = Mma2<T>::run(a1[c], b1[c], acc[1][1]);
             }
         } else {
             // fp32: MFMA 32x32x2 step s pairs k-slot s of the lower half (lanes 0-31, chunks 0-3) with k-slot s of the
             // upper half (lanes 32-63, chunks 4-7); the same pairing is used for A and W.
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                const int off = ((h * 4 + qd) ^ sw) * 16;
-                floatx4 a0 = *reinterpret_cast<const floatx4*>(sa + off);
-                floatx4 a1 = *reinterpret_cast<const floatx4*>(sa + 32 * 128 + off);
-                floatx4 b0 = *reinterpret_cast<const floatx4*>(sb + off);
-                floatx4 b1 = *reinterpret_cast<const floatx4*>(sb + 32 * 128 + off);
+                floatx4 a0 = *reinterpret_cast<const floatx4*>(sbase + aoff[qd]);
+                floatx4 a1 = *reinterpret_cast<const floatx4*>(sbase + aoff[qd] + 32 * 128);
+                floatx4 b0 = *reinterpret_cast<const floatx4*>(sbase + boff[qd]);
+                floatx4 b1 = *reinterpret_cast<const floatx4*>(sbase + boff[qd] + 32 * 128);
+                if constexpr (FAST) {
+                    if (dma && qd < 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        fire_fast(dstage, 2 * qd);
+                        fire_fast(dstage, 2 * qd + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
@@ -292,8 +331,14 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // every wave's pieces of tile kt are in LDS; every wave is done reading tile kt-1
         asm volatile("" ::: "memory");
-        if (kt + 2 < nk) issue_any((kt + 2) % NSTAGE);   // overwrites the stage tile kt-1 lived in
-        compute(kt % NSTAGE);
+        const bool more = kt + 2 < nk;
+        if constexpr (FAST) {
+            if (more) prep_fast();                                   // offsets only; the DMA goes out inside compute()
+            compute(kt % NSTAGE, more, (kt + 2) % NSTAGE);           // overwrites the stage tile kt-1 lived in
+        } else {
+            if (more) issue((kt + 2) % NSTAGE);
+            compute(kt % NSTAGE, false, 0);
+        }
         asm volatile("" ::: "memory");
     }
 
