@@ -15,11 +15,22 @@
 
 namespace e2eft {
 
-constexpr int BM2 = 256, BN2 = 128;
-constexpr int A_STAGE = BM2 * 128;   // bytes: 256 rows x 128 B
+// Two geometries of the same kernel (NW = waves per workgroup, wave tile always 64x64, BN = 128):
+//   NW = 8: 256x128 tile, 3-stage ring (prefetch distance 2), one workgroup per CU;
+//   NW = 4: 128x128 tile, 2 stages (prefetch distance 1), 66 KiB of LDS -> TWO workgroups per CU whose barriers drift
+//           apart, so one workgroup's wait/barrier bubbles are filled by the other's MFMAs.
+constexpr int BN2 = 128;
 constexpr int B_STAGE = BN2 * 128;
-constexpr int STAGE2 = A_STAGE + B_STAGE;
-constexpr int NSTAGE = 3;
+template <int NW> struct Geo {
+    static constexpr int BM = NW * 32;
+    static constexpr int A_STAGE = BM * 128;
+    static constexpr int STAGE = A_STAGE + B_STAGE;
+    static constexpr int NSTAGE = NW == 8 ? 3 : 2;
+    static constexpr int BPIECES = 16 / NW;          // B pieces (8 rows each) per wave
+    static constexpr int NPIECES = 4 + BPIECES;      // DMA instructions per wave per k-tile
+    static constexpr int EPI_BYTES = BM * (BN2 + 4) * 4;
+    static constexpr int LDS_BYTES = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;
+};
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -46,9 +57,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr unsigned int OOB_SENTINEL = 0xF0000000u;
 constexpr unsigned int SRD_RECORDS = 0xE0000000u;
 
-template <typename T, int MODE, bool FAST>
-__global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE2];
+template <typename T, int MODE, bool FAST, int NW>
+__global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
+    using G = Geo<NW>;
+    constexpr int BM2 = G::BM, A_STAGE = G::A_STAGE, STAGE2 = G::STAGE, NSTAGE = G::NSTAGE, BPIECES = G::BPIECES, NPIECES = G::NPIECES;
+    constexpr int RSTEP = 8 * NW;   // row distance between a wave's consecutive pieces
+    __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int BK = 128 / (int)sizeof(T);
 
@@ -83,11 +97,11 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
     long a_base[4];
     int a_iy0[4], a_ix0[4];
     bool a_ok[4];
-    long w_base[2];
-    bool w_ok[2];
+    long w_base[BPIECES];
+    bool w_ok[BPIECES];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + lrow + 64 * i;
+        const int m = m0 + lrow + RSTEP * i;
         a_ok[i] = m < p.M;
         if (MODE == 0) {
             a_base[i] = (long)m * p.ldx1;
@@ -104,8 +118,8 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int n = n0 + lrow + 64 * i;
+    for (int i = 0; i < BPIECES; ++i) {
+        const int n = n0 + lrow + RSTEP * i;
         w_ok[i] = n < p.N;
         w_base[i] = (long)n * p.ldw;
     }
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const T* src = (kok && a_ok[i]) ? X1 + a_base[i] + k_cur : zsrc;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + i * 8192), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + i * (RSTEP * 128)), 16, 0, 0);
             }
         } else {
             const bool second = c_cur >= p.c1;
@@ -144,13 +158,13 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
                 if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
                 const long pix = (a_base[i] * p.hin + sy) * p.win + sx;
                 const T* src = ok ? sbase + pix * ld + cc : zsrc;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + i * 8192), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + i * (RSTEP * 128)), 16, 0, 0);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < BPIECES; ++i) {
             const T* src = (kok && w_ok[i]) ? W + w_base[i] + k_cur : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + i * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + i * (RSTEP * 128)), 16, 0, 0);
         }
         // advance to the next k-tile
         k_cur += BK;
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
     };
 
     // ---------------- FAST path state ----------------
-    unsigned int off1[4] = {0, 0, 0, 0}, off2[4] = {0, 0, 0, 0}, woff[2] = {0, 0};
+    unsigned int off1[4] = {0, 0, 0, 0}, off2[4] = {0, 0, 0, 0}, woff[BPIECES];
     int brel[4] = {0, 0, 0, 0};
     int tile_c = 0, tap = 0;
     unsigned int kbytes = 0;
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
             b1 = X1 + (long)m0 * p.ldx1;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                off1[i] = a_ok[i] ? (unsigned)((lrow + 64 * i) * p.ldx1 + jc * EPC) * (unsigned)sizeof(T) : OOB_SENTINEL;
+                off1[i] = a_ok[i] ? (unsigned)((lrow + RSTEP * i) * p.ldx1 + jc * EPC) * (unsigned)sizeof(T) : OOB_SENTINEL;
         } else {
             const int hw = p.hout * p.wout;
             const int b0 = m0 / hw;                       // first image touched by this tile (uniform)
@@ -189,8 +203,8 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
         rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(b2 ? b2 : b1), 0, SRD_RECORDS, 0x00020000);
         rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)n0 * p.ldw), 0, SRD_RECORDS, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            woff[i] = w_ok[i] ? (unsigned)((lrow + 64 * i) * p.ldw + jc * EPC) * (unsigned)sizeof(T) : OOB_SENTINEL;
+        for (int i = 0; i < BPIECES; ++i)
+            woff[i] = w_ok[i] ? (unsigned)((lrow + RSTEP * i) * p.ldw + jc * EPC) * (unsigned)sizeof(T) : OOB_SENTINEL;
     }
     auto retap = [&]() {   // per-row pixel offsets of the current filter tap (uniform branch, once per tap)
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
     // DMA of one k-tile = 6 pieces per wave (A0..A3, B0, B1).  prep_fast() computes the six 32-bit offsets (a v_add
     // each); fire_fast(stage, piece) issues one piece — the main loop spreads them between the MFMA groups so that the
     // ~60-180 cycle issue cost of an LDS-DMA instruction overlaps this wave's own MFMA execution.
-    unsigned int voff[6];
+    unsigned int voff[NPIECES];
     bool use2 = false;
     auto prep_fast = [&]() {
         if (MODE == 0) {
@@ -224,23 +238,23 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
             tile_c += BK;
             if (tile_c >= p.cin) { tile_c = 0; ++tap; }
         }
-        voff[4] = woff[0] + kbytes;
-        voff[5] = woff[1] + kbytes;
+#pragma unroll
+        for (int i = 0; i < BPIECES; ++i) voff[4 + i] = woff[i] + kbytes;
         kbytes += 128;
     };
     auto fire_fast = [&](int stage, int piece) {
         char* sa = smem + stage * STAGE2 + wave * 1024;
         if (piece < 4) {
-            if (MODE == 1 && use2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lptr_t)(sa + piece * 8192), 16, voff[piece], 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(sa + piece * 8192), 16, voff[piece], 0, 0, 0);
+            if (MODE == 1 && use2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lptr_t)(sa + piece * (RSTEP * 128)), 16, voff[piece], 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lptr_t)(sa + piece * (RSTEP * 128)), 16, voff[piece], 0, 0, 0);
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(sa + A_STAGE + (piece - 4) * 8192), 16, voff[piece], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)(sa + A_STAGE + (piece - 4) * (RSTEP * 128)), 16, voff[piece], 0, 0, 0);
         }
     };
     auto issue_fast = [&](int stage) {
         prep_fast();
 #pragma unroll
-        for (int q = 0; q < 6; ++q) fire_fast(stage, q);
+        for (int q = 0; q < NPIECES; ++q) fire_fast(stage, q);
     };
 
     floatx16 acc[2][2];
@@ -274,10 +288,10 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
             for (int ks = 0; ks < 4; ++ks) {
                 const int c = ks & 1, nx = c ^ 1;
                 if constexpr (FAST) {
-                    if (dma && ks < 3) {
+                    if (dma) {
                         __builtin_amdgcn_sched_barrier(0);
-                        fire_fast(dstage, 2 * ks);
-                        fire_fast(dstage, 2 * ks + 1);
+#pragma unroll
+                        for (int q = ks * 2; q < (ks == 3 ? NPIECES : ks * 2 + 2); ++q) fire_fast(dstage, q);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -302,10 +316,10 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
                 floatx4 b0 = *reinterpret_cast<const floatx4*>(sbase + boff[qd]);
                 floatx4 b1 = *reinterpret_cast<const floatx4*>(sbase + boff[qd] + 32 * 128);
                 if constexpr (FAST) {
-                    if (dma && qd < 3) {
+                    if (dma) {
                         __builtin_amdgcn_sched_barrier(0);
-                        fire_fast(dstage, 2 * qd);
-                        fire_fast(dstage, 2 * qd + 1);
+#pragma unroll
+                        for (int q = qd * 2; q < (qd == 3 ? NPIECES : qd * 2 + 2); ++q) fire_fast(dstage, q);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -320,33 +334,40 @@ __global__ __launch_bounds__(512) void igemm2_kernel(const IgemmParams p) {
         }
     };
 
-    // ---- main loop: ring of 3 stages, tiles kt+1 and kt+2 in flight while tile kt is multiplied ----
+    // ---- main loop: ring of NSTAGE stages, prefetch distance NSTAGE-1 k-tiles ----
     const int nk = (p.K + BK - 1) / BK;
     auto issue_any = [&](int stage) { if constexpr (FAST) issue_fast(stage); else issue(stage); };
     issue_any(0);
-    if (nk > 1) issue_any(1);
+    if (NSTAGE == 3 && nk > 1) issue_any(1);
     for (int kt = 0; kt < nk; ++kt) {
-        // this wave's DMA of tile kt has landed once at most the younger tile's 6 loads are still outstanding
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this wave's DMA of tile kt has landed once only the younger tile's NPIECES loads are still outstanding
+        if (NSTAGE == 3 && kt + 1 < nk) {
+            if constexpr (NPIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();   // every wave's pieces of tile kt are in LDS; every wave is done reading tile kt-1
         asm volatile("" ::: "memory");
-        const bool more = kt + 2 < nk;
+        const bool more = kt + (NSTAGE - 1) < nk;
+        const int dst = (kt + NSTAGE - 1) % NSTAGE;   // the stage tile kt-1 lived in
         if constexpr (FAST) {
-            if (more) prep_fast();                                   // offsets only; the DMA goes out inside compute()
-            compute(kt % NSTAGE, more, (kt + 2) % NSTAGE);           // overwrites the stage tile kt-1 lived in
+            if (more) prep_fast();                    // offsets only; the DMA goes out inside compute()
+            compute(kt % NSTAGE, more, dst);
         } else {
-            if (more) issue((kt + 2) % NSTAGE);
+            if (more) issue(dst);
             compute(kt % NSTAGE, false, 0);
         }
         asm volatile("" ::: "memory");
     }
 
     // ---- epilogue: LDS-staged, vectorised (igemm.h) ----
-    igemm_epilogue<T, BM2, BN2, 512>(p, smem, acc, wm, wn, l31, h, m0, n0, zo, zi);
+    igemm_epilogue<T, BM2, BN2, NW * 64>(p, smem, acc, wm, wn, l31, h, m0, n0, zo, zi);
 }
 
-template <typename T, int MODE> static int launch2(const IgemmParams& p, int nz, hipStream_t s) {
+template <typename T, int MODE, int NW> static int launch2(IgemmParams& p, int nz, hipStream_t s) {
+    p.mtiles = cdiv(p.M, Geo<NW>::BM);
+    p.ntiles = cdiv(p.N, BN2);
     dim3 grid(p.mtiles * p.ntiles, nz, 1);
     constexpr int BK = 128 / (int)sizeof(T);
     bool fast;
@@ -358,17 +379,22 @@ template <typename T, int MODE> static int launch2(const IgemmParams& p, int nz,
         fast = p.cin % BK == 0 && p.c1 % BK == 0 && img_bytes * span_imgs < 0xD0000000L && (long)128 * p.ldw * (long)sizeof(T) < 0x40000000L;
     }
     static const bool nofast = getenv("E2EFT_IGEMM_NOFAST") != nullptr;
-    if (fast && !nofast) hipLaunchKernelGGL((igemm2_kernel<T, MODE, true>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((igemm2_kernel<T, MODE, false>), grid, dim3(512), 0, s, p);
+    if (fast && !nofast) hipLaunchKernelGGL((igemm2_kernel<T, MODE, true, NW>), grid, dim3(NW * 64), 0, s, p);
+    else hipLaunchKernelGGL((igemm2_kernel<T, MODE, false, NW>), grid, dim3(NW * 64), 0, s, p);
     return check_launch("igemm2");
 }
 
+template <typename T> static int launch2_t(int mode, IgemmParams& p, int nz, hipStream_t s) {
+    static const int forced_nw = [] { const char* e = getenv("E2EFT_IGEMM2_NW"); return e ? atoi(e) : 0; }();
+    const int nw = forced_nw ? forced_nw : 8;
+    if (nw == 4) return mode ? launch2<T, 1, 4>(p, nz, s) : launch2<T, 0, 4>(p, nz, s);
+    return mode ? launch2<T, 1, 8>(p, nz, s) : launch2<T, 0, 8>(p, nz, s);
+}
+
 int launch_igemm_v2(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s) {
-    p.mtiles = cdiv(p.M, BM2);
-    p.ntiles = cdiv(p.N, BN2);
-    if (dtype == E2EFT_F32) return mode ? launch2<float, 1>(p, nz, s) : launch2<float, 0>(p, nz, s);
-    if (dtype == E2EFT_F16) return mode ? launch2<f16, 1>(p, nz, s) : launch2<f16, 0>(p, nz, s);
-    if (dtype == E2EFT_BF16) return mode ? launch2<bf16, 1>(p, nz, s) : launch2<bf16, 0>(p, nz, s);
+    if (dtype == E2EFT_F32) return launch2_t<float>(mode, p, nz, s);
+    if (dtype == E2EFT_F16) return launch2_t<f16>(mode, p, nz, s);
+    if (dtype == E2EFT_BF16) return launch2_t<bf16>(mode, p, nz, s);
     return fail(E2EFT_ERR_BAD_ARG, "igemm2: bad dtype %d", dtype);
 }
 
