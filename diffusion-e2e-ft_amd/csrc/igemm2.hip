@@ -60,11 +60,11 @@ constexpr unsigned int SRD_RECORDS = 0xE0000000u;
 template <typename T, int MODE, bool FAST, int NW>
 __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
     using G = Geo<NW>;
-    constexpr int BM2 = G::BM, A_STAGE = G::A_STAGE, STAGE2 = G::STAGE, NSTAGE = G::NSTAGE, BPIECES = G::BPIECES, NPIECES = G::NPIECES;
-    constexpr int RSTEP = 8 * NW;   // row distance between a wave's consecutive pieces
+    static constexpr int BM2 = G::BM, A_STAGE = G::A_STAGE, STAGE2 = G::STAGE, NSTAGE = G::NSTAGE, BPIECES = G::BPIECES, NPIECES = G::NPIECES;
+    static constexpr int RSTEP = 8 * NW;   // row distance between a wave's consecutive pieces
     __shared__ __attribute__((aligned(16))) char smem[G::LDS_BYTES];
-    constexpr int EPC = 16 / (int)sizeof(T);
-    constexpr int BK = 128 / (int)sizeof(T);
+    static constexpr int EPC = 16 / (int)sizeof(T);
+    static constexpr int BK = 128 / (int)sizeof(T);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
     long a_base[4];
     int a_iy0[4], a_ix0[4];
     bool a_ok[4];
-    long w_base[BPIECES];
-    bool w_ok[BPIECES];
+    long w_base[4];
+    bool w_ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + lrow + RSTEP * i;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
     };
 
     // ---------------- FAST path state ----------------
-    unsigned int off1[4] = {0, 0, 0, 0}, off2[4] = {0, 0, 0, 0}, woff[BPIECES];
+    unsigned int off1[4] = {0, 0, 0, 0}, off2[4] = {0, 0, 0, 0}, woff[4];
     int brel[4] = {0, 0, 0, 0};
     int tile_c = 0, tap = 0;
     unsigned int kbytes = 0;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
     // DMA of one k-tile = 6 pieces per wave (A0..A3, B0, B1).  prep_fast() computes the six 32-bit offsets (a v_add
     // each); fire_fast(stage, piece) issues one piece — the main loop spreads them between the MFMA groups so that the
     // ~60-180 cycle issue cost of an LDS-DMA instruction overlaps this wave's own MFMA execution.
-    unsigned int voff[NPIECES];
+    unsigned int voff[8];   // NPIECES <= 8 (literal size: a template-dependent bound breaks the host-side stub instantiation)
     bool use2 = false;
     auto prep_fast = [&]() {
         if (MODE == 0) {
