@@ -279,27 +279,32 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
     auto compute = [&](int stage, bool dma, int dstage) {
         const char* sbase = smem + stage * STAGE2;
         if constexpr (sizeof(T) == 2) {
-            u32x4 a0[2], a1[2], b0[2], b1[2];
-            a0[0] = *reinterpret_cast<const u32x4*>(sbase + aoff[0]);
-            a1[0] = *reinterpret_cast<const u32x4*>(sbase + aoff[0] + 32 * 128);
-            b0[0] = *reinterpret_cast<const u32x4*>(sbase + boff[0]);
-            b1[0] = *reinterpret_cast<const u32x4*>(sbase + boff[0] + 32 * 128);
+            // fragments are fetched TWO k-groups ahead of the MFMAs that consume them (3 register sets), so that the
+            // ~130-cycle ds_read_b128 latency is always covered by a full group of 4 MFMAs (128 pipe cycles)
+            u32x4 a0[3], a1[3], b0[3], b1[3];
+            auto rd = [&](int g, int slot) {
+                a0[slot] = *reinterpret_cast<const u32x4*>(sbase + aoff[g]);
+                a1[slot] = *reinterpret_cast<const u32x4*>(sbase + aoff[g] + 32 * 128);
+                b0[slot] = *reinterpret_cast<const u32x4*>(sbase + boff[g]);
+                b1[slot] = *reinterpret_cast<const u32x4*>(sbase + boff[g] + 32 * 128);
+            };
+            rd(0, 0);
+            rd(1, 1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int c = ks & 1, nx = c ^ 1;
+                const int c = ks % 3;
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 < 4) rd(ks + 2, (ks + 2) % 3);
                 if constexpr (FAST) {
                     if (dma) {
-                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int q = ks * 2; q < (ks == 3 ? NPIECES : ks * 2 + 2); ++q) fire_fast(dstage, q);
-                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if (ks < 3) {
-                    a0[nx] = *reinterpret_cast<const u32x4*>(sbase + aoff[ks + 1]);
-                    a1[nx] = *reinterpret_cast<const u32x4*>(sbase + aoff[ks + 1] + 32 * 128);
-                    b0[nx] = *reinterpret_cast<const u32x4*>(sbase + boff[ks + 1]);
-                    b1[nx] = *reinterpret_cast<const u32x4*>(sbase + boff[ks + 1] + 32 * 128);
+                __builtin_amdgcn_sched_barrier(0);
+                if (p.dbg & 1) {   // experiment: keep the fragment reads alive, skip the matrix pipe
+                    asm volatile("" ::"v"(a0[c]), "v"(a1[c]), "v"(b0[c]), "v"(b1[c]));
+                    continue;
                 }
                 acc[0][0] = Mma2<T>::run(a0[c], b0[c], acc[0][0]);
                 acc[0][1] = Mma2<T>::run(a0[c], b1[c], acc[0][1]);
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
         }
         __builtin_amdgcn_s_barrier();   // every wave's pieces of tile kt are in LDS; every wave is done reading tile kt-1
         asm volatile("" ::: "memory");
-        const bool more = kt + (NSTAGE - 1) < nk;
+        const bool more = kt + (NSTAGE - 1) < nk && !(p.dbg & 2);
         const int dst = (kt + NSTAGE - 1) % NSTAGE;   // the stage tile kt-1 lived in
         if constexpr (FAST) {
             if (more) prep_fast();                    // offsets only; the DMA goes out inside compute()
@@ -366,6 +371,8 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
 }
 
 template <typename T, int MODE, int NW> static int launch2(IgemmParams& p, int nz, hipStream_t s) {
+    static const int dbg = [] { const char* e = getenv("E2EFT_IGEMM_DBG"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
     p.mtiles = cdiv(p.M, Geo<NW>::BM);
     p.ntiles = cdiv(p.N, BN2);
     dim3 grid(p.mtiles * p.ntiles, nz, 1);
@@ -386,7 +393,9 @@ template <typename T, int MODE, int NW> static int launch2(IgemmParams& p, int n
 
 template <typename T> static int launch2_t(int mode, IgemmParams& p, int nz, hipStream_t s) {
     static const int forced_nw = [] { const char* e = getenv("E2EFT_IGEMM2_NW"); return e ? atoi(e) : 0; }();
-    const int nw = forced_nw ? forced_nw : 8;
+    // two 128-row workgroups per CU fill the machine better on mid-size problems; 256-row tiles halve the weight traffic on big ones
+    const long blocks256 = (long)cdiv(p.M, 256) * cdiv(p.N, BN2) * nz;
+    const int nw = forced_nw ? forced_nw : (blocks256 < 2048 ? 4 : 8);
     if (nw == 4) return mode ? launch2<T, 1, 4>(p, nz, s) : launch2<T, 0, 4>(p, nz, s);
     return mode ? launch2<T, 1, 8>(p, nz, s) : launch2<T, 0, 8>(p, nz, s);
 }
