@@ -23,6 +23,7 @@ struct IgemmParams {
     int nzi;
     long sa_o, sa_i, sw_o, sw_i, so_o, so_i, sr_o, sr_i;
     int mtiles, ntiles;
+    unsigned long long* dbgbuf;   // experiments only: per-wave cycle stamps (e2eft_igemm_debug_buffer)
     int dbg;   // experiments only (E2EFT_IGEMM_DBG): bit0 = skip MFMAs, bit1 = skip DMA issue in the main loop
 };
 
