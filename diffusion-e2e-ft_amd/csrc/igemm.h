@@ -23,8 +23,6 @@ struct IgemmParams {
     int nzi;
     long sa_o, sa_i, sw_o, sw_i, so_o, so_i, sr_o, sr_i;
     int mtiles, ntiles;
-    unsigned long long* dbgbuf;   // experiments only: per-wave cycle stamps (e2eft_igemm_debug_buffer)
-    int dbg;   // experiments only (E2EFT_IGEMM_DBG): bit0 = skip MFMAs, bit1 = skip DMA issue in the main loop
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -35,21 +33,24 @@ struct IgemmParams {
 //   out = alpha * (acc + bias + rowadd[img(m)]) + residual
 template <typename T, int BM_, int BN_, int NT_>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem, floatx16 (&acc)[2][2], int wm, int wn, int l31,
-                                               int h, int m0, int n0, int zo, int zi) {
+                                               int h, int m0, int n0, int zo, int zi, bool is_consumer = true) {
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int LDT = BN_ + 4;            // fp32 row stride of the staged tile (528 B for BN = 128)
     constexpr int CPR = BN_ / 8;            // 8-column chunks per row
     constexpr int RPP = NT_ / CPR;          // rows per pass
     float* tile = reinterpret_cast<float*>(smem);
     __syncthreads();                        // every wave is done reading the last k-tile
+    if (is_consumer) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                tile[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDT + wn * 64 + j * 32 + l31] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r)
+                    tile[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDT + wn * 64 + j * 32 + l31] = acc[i][j][r];
+    }
     __syncthreads();
+    if (!is_consumer) return;               // dedicated loader waves (igemm2 NL > 0) only take part in the barriers
 
     const T* __restrict__ bias = (const T*)p.bias;
     const T* __restrict__ rowadd = (const T*)p.rowadd;

@@ -57,6 +57,10 @@ constexpr unsigned int SRD_RECORDS = 0xE0000000u;
 
 template <int V> using IC = std::integral_constant<int, V>;
 
+// Tried and measured, not kept (conv 512->512 @192^2, B = 8, fp16; this kernel: 940-970 TF/s): a rotated loop that reads the next
+// tile's first fragments before the current tile's last MFMAs (820), a ping-pong schedule with the two waves of a SIMD in
+// opposite L/M phases (750), 4 dedicated LDS-DMA loader waves + 8 pure consumer waves (917), static s_setprio for either
+// half (no change), NW = 4 with two workgroups per CU (840).  See DESIGN.md §3 for the cycle-stamp breakdown.
 template <typename T, int MODE, bool FAST, int NW>
 __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
     using G = Geo<NW>;
@@ -418,7 +422,7 @@ template <typename T> static int launch2_t(int mode, IgemmParams& p, int nz, hip
     static const int forced_nw = [] { const char* e = getenv("E2EFT_IGEMM2_NW"); return e ? atoi(e) : 0; }();
     // two 128-row workgroups per CU fill the machine better on mid-size problems; 256-row tiles halve the weight traffic on big ones
     const long blocks256 = (long)cdiv(p.M, 256) * cdiv(p.N, BN2) * nz;
-    const int nw = forced_nw ? forced_nw : (blocks256 < 2048 ? 4 : 8);
+    const int nw = forced_nw ? forced_nw : (blocks256 < 256 ? 4 : 8);
     if (nw == 4) return mode ? launch2<T, 1, 4>(p, nz, s) : launch2<T, 0, 4>(p, nz, s);
     return mode ? launch2<T, 1, 8>(p, nz, s) : launch2<T, 0, 8>(p, nz, s);
 }
