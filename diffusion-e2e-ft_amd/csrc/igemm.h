@@ -23,6 +23,8 @@ struct IgemmParams {
     int nzi;
     long sa_o, sa_i, sw_o, sw_i, so_o, so_i, sr_o, sr_i;
     int mtiles, ntiles;
+    float* gn_partial;   // optional: [img][gn_nslabs][N][3] (n, mean, M2) GroupNorm partials of the rounded output
+    int gn_nslabs;       // row slabs (one per M-tile) per image
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -31,26 +33,29 @@ struct IgemmParams {
 // finished, its buffers are free) and is written back row-wise: every thread owns 8 consecutive columns of a row,
 // residual / output move as 16-byte vectors, a wave covers 4 full 256-byte rows per instruction.
 //   out = alpha * (acc + bias + rowadd[img(m)]) + residual
+// Optionally (p.gn_partial) the epilogue also emits the GroupNorm statistics of the tile it just wrote — per column, Welford
+// over each thread's rows, butterfly + LDS merge over the workgroup — so that the consuming GroupNorm skips its statistics
+// pass over HBM (one of its three passes).
 template <typename T, int BM_, int BN_, int NT_>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem, floatx16 (&acc)[2][2], int wm, int wn, int l31,
-                                               int h, int m0, int n0, int zo, int zi, bool is_consumer = true) {
+                                               int h, int m0, int n0, int zo, int zi) {
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int LDT = BN_ + 4;            // fp32 row stride of the staged tile (528 B for BN = 128)
     constexpr int CPR = BN_ / 8;            // 8-column chunks per row
     constexpr int RPP = NT_ / CPR;          // rows per pass
+    constexpr int NPASS = BM_ / RPP;        // rows per thread
+    constexpr int NWV = NT_ / 64;
     float* tile = reinterpret_cast<float*>(smem);
+    float* gst = tile + BM_ * LDT;          // [NWV][16 chunks][8 cols][2] wave partials of the GroupNorm statistics
     __syncthreads();                        // every wave is done reading the last k-tile
-    if (is_consumer) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    tile[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDT + wn * 64 + j * 32 + l31] = acc[i][j][r];
-    }
+            for (int r = 0; r < 16; ++r)
+                tile[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDT + wn * 64 + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
-    if (!is_consumer) return;               // dedicated loader waves (igemm2 NL > 0) only take part in the barriers
 
     const T* __restrict__ bias = (const T*)p.bias;
     const T* __restrict__ rowadd = (const T*)p.rowadd;
@@ -58,18 +63,22 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
     T* __restrict__ out = (T*)p.out + zo * p.so_o + zi * p.so_i;
     const int chunk = threadIdx.x % CPR, rbase = threadIdx.x / CPR;
     const int n = n0 + chunk * 8;
-    if (n >= p.N) return;
+    const bool col_ok = n < p.N;
     const bool vec = (p.N % 8 == 0) && (p.ldo % EPC == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                      (!res || (p.ldr % EPC == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0));
+    const bool stats = p.gn_partial != nullptr;   // host guarantees: vec, whole tile inside one image, all rows valid
     const int nv = min(8, p.N - n);
     float bv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (bias && !p.bias_along_m && e < nv) ? to_f(bias[n + e]) : 0.f;
-#pragma unroll 4
-    for (int pass = 0; pass < BM_ / RPP; ++pass) {
+    for (int e = 0; e < 8; ++e) bv[e] = (bias && !p.bias_along_m && col_ok && e < nv) ? to_f(bias[n + e]) : 0.f;
+    float s_mean[8], s_m2[8];   // Welford state over this thread's NPASS rows (per column)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_mean[e] = s_m2[e] = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
         const int row = rbase + pass * RPP;
         const int m = m0 + row;
-        if (m >= p.M) continue;
+        if (m >= p.M || !col_ok) continue;
         const floatx4 t0 = *reinterpret_cast<const floatx4*>(tile + row * LDT + chunk * 8);
         const floatx4 t1 = *reinterpret_cast<const floatx4*>(tile + row * LDT + chunk * 8 + 4);
         float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
@@ -99,6 +108,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(v[q * EPC + e]);
                 st16(out + (long)m * p.ldo + n + q * EPC, o);
+                if (stats) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {   // statistics of what GroupNorm will read back: the rounded value
+                        const float xr = to_f(o.e[e]);
+                        const float d = xr - s_mean[q * EPC + e];
+                        s_mean[q * EPC + e] += d * (1.0f / (float)(pass + 1));
+                        s_m2[q * EPC + e] += d * (xr - s_mean[q * EPC + e]);
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -111,6 +129,48 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
                     out[(long)m * p.ldo + n + e] = from_f<T>(x);
                 }
             }
+        }
+    }
+    if (stats) {   // uniform branch
+        // lanes l, l^16, l^32, l^48 own the same 8 columns (rbase differs): butterfly-merge equal-count triples
+        float cnt = (float)NPASS;
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float om = __shfl_xor(s_mean[e], off, 64), o2 = __shfl_xor(s_m2[e], off, 64);
+                const float dlt = om - s_mean[e];
+                s_m2[e] = s_m2[e] + o2 + dlt * dlt * cnt * 0.5f;
+                s_mean[e] = 0.5f * (s_mean[e] + om);
+            }
+            cnt *= 2.0f;
+        }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                gst[((wv * 16 + lane) * 8 + e) * 2] = s_mean[e];
+                gst[((wv * 16 + lane) * 8 + e) * 2 + 1] = s_m2[e];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < BN_ && n0 + (int)threadIdx.x < p.N) {   // one thread per column: merge the waves (4*NPASS rows each)
+            const int c = threadIdx.x;
+            float mean = gst[((0 * 16 + c / 8) * 8 + (c & 7)) * 2], m2 = gst[((0 * 16 + c / 8) * 8 + (c & 7)) * 2 + 1];
+            float na = 4.0f * NPASS;
+            const float nb = 4.0f * NPASS;
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) {
+                const float om = gst[((w * 16 + c / 8) * 8 + (c & 7)) * 2], o2 = gst[((w * 16 + c / 8) * 8 + (c & 7)) * 2 + 1];
+                const float dlt = om - mean, nt = na + nb;
+                mean += dlt * (nb / nt);
+                m2 += o2 + dlt * dlt * na * (nb / nt);
+                na = nt;
+            }
+            const int img = m0 / p.rows_per_img;
+            const int slab = (m0 - img * p.rows_per_img) / BM_;
+            float* o = p.gn_partial + (((long)img * p.gn_nslabs + slab) * p.N + n0 + c) * 3;
+            o[0] = na; o[1] = mean; o[2] = m2;
         }
     }
 }

@@ -219,12 +219,13 @@ static int run_igemm(int dtype, int mode, IgemmParams& p, int nz, void* stream) 
     if (nz > 65535) return fail(E2EFT_ERR_BAD_ARG, "igemm: batch %d > 65535", nz);
     hipStream_t s = (hipStream_t)stream;
     {
-        // variant choice: the 256x128 LDS-DMA kernel needs enough tiles to fill 256 CUs; small problems keep the 128x128
-        // register-staged kernel (2 workgroups per CU).  E2EFT_IGEMM=1|2 forces a variant (A/B tests).
+        // variant choice: the LDS-DMA kernel (igemm2.hip) serves everything (it picks 256- or 128-row tiles itself and beats
+        // this kernel on every shape of the path, including the 12^2 / 24^2 layers); this register-staged kernel stays as an
+        // independent second implementation of the same contract: E2EFT_IGEMM=1 selects it (A/B runs, cross-checks).
         static const int forced = [] { const char* e = getenv("E2EFT_IGEMM"); return e ? atoi(e) : 0; }();
-        const long tiles2 = (long)cdiv(p.M, 256) * p.ntiles;
-        if (forced == 2 || (forced == 0 && tiles2 >= 192)) return launch_igemm_v2(dtype, mode, p, nz, s);
+        if (forced != 1) return launch_igemm_v2(dtype, mode, p, nz, s);
     }
+    p.gn_partial = nullptr;   // this variant does not emit GroupNorm statistics
     if (dtype == E2EFT_F32) return mode ? launch_igemm<float, 1>(p, nz, s) : launch_igemm<float, 0>(p, nz, s);
     if (dtype == E2EFT_F16) return mode ? launch_igemm<f16, 1>(p, nz, s) : launch_igemm<f16, 0>(p, nz, s);
     if (dtype == E2EFT_BF16) return mode ? launch_igemm<bf16, 1>(p, nz, s) : launch_igemm<bf16, 0>(p, nz, s);
@@ -239,6 +240,13 @@ using namespace e2eft;
 
 extern "C" int e2eft_conv2d_fwd(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w,
                                 const void* bias, const void* rowadd, const void* residual, void* out, void* stream) {
+    return e2eft_conv2d_fwd_gnstats(d, x1, x2, w, bias, rowadd, residual, out, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int e2eft_conv2d_fwd_gnstats(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w,
+                                        const void* bias, const void* rowadd, const void* residual, void* out,
+                                        float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* stream) {
+    if (slab_rows) *slab_rows = 0;
     E2EFT_REQUIRE(d && x1 && w && out, "conv2d: null pointer");
     const int epc = 16 / (int)dtype_size(d->dtype);
     const int cin = d->c1 + d->c2;
@@ -274,11 +282,25 @@ extern "C" int e2eft_conv2d_fwd(const E2eftConvDesc* d, const void* x1, const vo
     p.nzi = 1;
     const bool plain = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->c2 == 0 &&
                        d->hl == d->hin && d->wl == d->win && d->hout == d->hin && d->wout == d->win;
-    return run_igemm(d->dtype, plain ? 0 : 1, p, 1, stream);
+    if (gn_partial && slab_rows) {
+        const size_t need = (size_t)d->batch * (size_t)cdiv(p.rows_per_img, 128) * (size_t)d->cout * 3 * sizeof(float);
+        if (gn_partial_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "conv2d: gn_partial %zu < %zu bytes", gn_partial_bytes, need);
+        p.gn_partial = gn_partial;
+    }
+    const int rc = run_igemm(d->dtype, plain ? 0 : 1, p, 1, stream);
+    if (rc == 0 && slab_rows && p.gn_partial) *slab_rows = p.rows_per_img / p.gn_nslabs;
+    return rc;
 }
 
 extern "C" int e2eft_gemm(const E2eftGemmDesc* d, const void* a, const void* w, const void* bias,
                           const void* residual, void* out, void* stream) {
+    return e2eft_gemm_gnstats(d, a, w, bias, residual, out, 0, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int e2eft_gemm_gnstats(const E2eftGemmDesc* d, const void* a, const void* w, const void* bias,
+                                  const void* residual, void* out, int32_t rows_per_image, float* gn_partial,
+                                  size_t gn_partial_bytes, int32_t* slab_rows, void* stream) {
+    if (slab_rows) *slab_rows = 0;
     E2EFT_REQUIRE(d && a && w && out, "gemm: null pointer");
     E2EFT_REQUIRE(d->dtype >= 0 && d->dtype <= 2, "gemm: bad dtype %d", d->dtype);
     const int epc = 16 / (int)dtype_size(d->dtype);
@@ -300,5 +322,13 @@ extern "C" int e2eft_gemm(const E2eftGemmDesc* d, const void* a, const void* w, 
     p.nzi = d->nzi;
     p.sa_o = d->sa_o; p.sa_i = d->sa_i; p.sw_o = d->sw_o; p.sw_i = d->sw_i;
     p.so_o = d->so_o; p.so_i = d->so_i; p.sr_o = d->sr_o; p.sr_i = d->sr_i;
-    return run_igemm(d->dtype, 0, p, d->nzo * d->nzi, stream);
+    if (gn_partial && slab_rows && rows_per_image > 0 && d->nzo * d->nzi == 1 && !d->bias_along_m && d->m % rows_per_image == 0) {
+        const size_t need = (size_t)(d->m / rows_per_image) * (size_t)cdiv(rows_per_image, 128) * (size_t)d->n * 3 * sizeof(float);
+        if (gn_partial_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "gemm: gn_partial %zu < %zu bytes", gn_partial_bytes, need);
+        p.gn_partial = gn_partial;
+        p.rows_per_img = rows_per_image;
+    }
+    const int rc = run_igemm(d->dtype, 0, p, d->nzo * d->nzi, stream);
+    if (rc == 0 && slab_rows && p.gn_partial) *slab_rows = p.rows_per_img / p.gn_nslabs;
+    return rc;
 }

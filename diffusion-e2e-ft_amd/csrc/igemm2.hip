@@ -31,7 +31,7 @@ template <int NW> struct Geo {
     static constexpr int NSTAGE = NW == 8 ? 3 : 2;
     static constexpr int BPIECES = 16 / NW;          // B pieces (8 rows each) per wave
     static constexpr int NPIECES = 4 + BPIECES;      // DMA instructions per wave per k-tile
-    static constexpr int EPI_BYTES = BM * (BN2 + 4) * 4;
+    static constexpr int EPI_BYTES = BM * (BN2 + 4) * 4 + NW * 1024;   // staged fp32 tile + GroupNorm-statistics scratch
     static constexpr int LDS_BYTES = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;
 };
 
@@ -402,6 +402,13 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
 template <typename T, int MODE, int NW> static int launch2(IgemmParams& p, int nz, hipStream_t s) {
     p.mtiles = cdiv(p.M, Geo<NW>::BM);
     p.ntiles = cdiv(p.N, BN2);
+    if (p.gn_partial) {   // statistics need whole tiles inside one image and the vector epilogue
+        const bool ok = nz == 1 && p.rows_per_img % Geo<NW>::BM == 0 && p.M % p.rows_per_img == 0 && p.N % 8 == 0 &&
+                        p.ldo % (16 / (int)sizeof(T)) == 0 && (((uintptr_t)p.out) & 15) == 0 &&
+                        (!p.residual || (p.ldr % (16 / (int)sizeof(T)) == 0 && (((uintptr_t)p.residual) & 15) == 0));
+        if (ok) p.gn_nslabs = p.rows_per_img / Geo<NW>::BM;
+        else p.gn_partial = nullptr;
+    }
     dim3 grid(p.mtiles * p.ntiles, nz, 1);
     constexpr int BK = 128 / (int)sizeof(T);
     bool fast;

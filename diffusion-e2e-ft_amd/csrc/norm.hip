@@ -98,19 +98,30 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnGeom g, const T* __re
     }
 }
 
-// grid (groups, batch), block 256: merge slabs x channels-of-group, write affine pairs
+// grid (groups, batch), block 256: merge slabs x channels-of-group (the channels of a group may straddle the two sources,
+// each source has its own slab count), write (rstd*gamma, mean) pairs
 template <typename T>
-__global__ __launch_bounds__(256) void gn_finalize_kernel(GnGeom g, int groups, float eps, const float* __restrict__ partial,
-                                                          const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                          float* __restrict__ ad /* [B][C][2] */) {
+__global__ __launch_bounds__(256) void gn_finalize_kernel(int C, int c1, int groups, float eps, const float* __restrict__ pa,
+                                                          int nsa, const float* __restrict__ pb, int nsb,
+                                                          const T* __restrict__ gamma, float* __restrict__ ad /* [B][C][2] */) {
     __shared__ float sm[256 * 3];
     const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int cpg = g.C / groups;
-    const int items = g.nslabs * cpg;
+    const int cpg = C / groups;
+    const int cbeg = grp * cpg, cend = cbeg + cpg;
+    const int na = max(0, min(cend, c1) - cbeg);          // channels of this group that live in source 1
+    const int items_a = na * nsa, items = items_a + (cpg - na) * nsb;
+    const int c2 = C - c1;
     Triple acc = {0.f, 0.f, 0.f};
     for (int it = tid; it < items; it += 256) {
-        const int sl = it / cpg, cc = it - sl * cpg;
-        const float* o = partial + (((long)b * g.nslabs + sl) * g.C + grp * cpg + cc) * 3;
+        const float* o;
+        if (it < items_a) {
+            const int cc = it / nsa, sl = it - cc * nsa;
+            o = pa + (((long)b * nsa + sl) * c1 + cbeg + cc) * 3;
+        } else {
+            const int j = it - items_a;
+            const int cc = j / nsb, sl = j - cc * nsb;
+            o = pb + (((long)b * nsb + sl) * c2 + (cbeg + na + cc - c1)) * 3;
+        }
         Triple t = {o[0], o[1], o[2]};
         acc = merge(acc, t);
     }
@@ -129,12 +140,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GnGeom g, int groups, 
     const float var = sm[2] / sm[0];
     const float rstd = rsqrtf(var + eps);
     for (int cc = tid; cc < cpg; cc += 256) {
-        const int c = grp * cpg + cc;
+        const int c = cbeg + cc;
         const float ga = gamma ? to_f(gamma[c]) : 1.f;
-        const float be = beta ? to_f(beta[c]) : 0.f;
-        (void)be;
-        ad[((long)b * g.C + c) * 2] = rstd * ga;   // y = (x - mean) * a + beta: no cancellation when |mean| >> std
-        ad[((long)b * g.C + c) * 2 + 1] = mean;
+        ad[((long)b * C + c) * 2] = rstd * ga;   // y = (x - mean) * a + beta: no cancellation when |mean| >> std
+        ad[((long)b * C + c) * 2 + 1] = mean;
     }
 }
 
@@ -194,17 +203,55 @@ static int gn_geom(const E2eftGroupNormDesc* d, GnGeom& g) {
     return 0;
 }
 
+static void gn_geom_one(int dtype, int batch, int hw, int c, int ld, GnGeom& g) {
+    E2eftGroupNormDesc d1 = {};
+    d1.dtype = dtype; d1.batch = batch; d1.hw = hw; d1.c1 = c; d1.ldx1 = ld; d1.c2 = 0; d1.ldx2 = 0;
+    gn_geom(&d1, g);
+}
+
 template <typename T>
 static int gn_run(const E2eftGroupNormDesc* d, const GnGeom& g, const void* x1, const void* x2, const void* gamma,
-                  const void* beta, void* y, void* ws, hipStream_t s) {
-    float* partial = (float*)ws;
-    float* ad = partial + (size_t)g.batch * g.nslabs * g.C * 3;
-    dim3 grid(g.nslabs, g.batch, g.nchb);
-    hipLaunchKernelGGL((gn_partial_kernel<T>), grid, dim3(256), 0, s, g, (const T*)x1, (const T*)x2, partial);
-    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(d->groups, g.batch), dim3(256), 0, s, g, d->groups, d->eps, partial,
-                       (const T*)gamma, (const T*)beta, ad);
-    hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(256), 0, s, g, d->silu, d->ldy, (const T*)x1, (const T*)x2, ad, (const T*)beta, (T*)y);
+                  const void* beta, void* y, const float* pre1, int ns1, const float* pre2, int ns2, void* ws, hipStream_t s) {
+    // workspace: [partial of source 1 (if computed here)] [partial of source 2 (if computed here)] [ad]
+    float* wsp = (float*)ws;
+    GnGeom g1, g2;
+    gn_geom_one(d->dtype, d->batch, d->hw, d->c1, d->ldx1, g1);
+    const float* pa = pre1;
+    int nsa = ns1;
+    if (!pa) {
+        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(g1.nslabs, g1.batch, g1.nchb), dim3(256), 0, s, g1, (const T*)x1, (const T*)nullptr, wsp);
+        pa = wsp; nsa = g1.nslabs;
+    }
+    wsp += (size_t)d->batch * g1.nslabs * d->c1 * 3;
+    const float* pb = pre2;
+    int nsb = ns2;
+    if (d->c2 > 0) {
+        gn_geom_one(d->dtype, d->batch, d->hw, d->c2, d->ldx2, g2);
+        if (!pb) {
+            hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(g2.nslabs, g2.batch, g2.nchb), dim3(256), 0, s, g2, (const T*)x2, (const T*)nullptr, wsp);
+            pb = wsp; nsb = g2.nslabs;
+        }
+        wsp += (size_t)d->batch * g2.nslabs * d->c2 * 3;
+    } else {
+        pb = pa; nsb = 1;
+    }
+    float* ad = wsp;
+    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(d->groups, g.batch), dim3(256), 0, s, g.C, d->c1, d->groups, d->eps, pa, nsa, pb, nsb,
+                       (const T*)gamma, ad);
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(g.nslabs, g.batch, g.nchb), dim3(256), 0, s, g, d->silu, d->ldy, (const T*)x1, (const T*)x2, ad, (const T*)beta, (T*)y);
     return check_launch("groupnorm");
+}
+
+static size_t gn_ws_bytes(const E2eftGroupNormDesc* d) {
+    GnGeom g1, g2;
+    gn_geom_one(d->dtype, d->batch, d->hw, d->c1, d->ldx1, g1);
+    size_t f = (size_t)d->batch * g1.nslabs * d->c1 * 3;
+    if (d->c2 > 0) {
+        gn_geom_one(d->dtype, d->batch, d->hw, d->c2, d->ldx2, g2);
+        f += (size_t)d->batch * g2.nslabs * d->c2 * 3;
+    }
+    f += (size_t)d->batch * (d->c1 + d->c2) * 2;
+    return f * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -335,23 +382,29 @@ static int gn_validate(const E2eftGroupNormDesc* d) {
 
 extern "C" size_t e2eft_groupnorm_workspace_bytes(const E2eftGroupNormDesc* d) {
     if (gn_validate(d)) return 0;
+    return gn_ws_bytes(d);
+}
+
+extern "C" int e2eft_groupnorm_fwd_pre(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma,
+                                       const void* beta, void* y, const float* partial1, int32_t nslabs1,
+                                       const float* partial2, int32_t nslabs2, void* workspace, size_t ws_bytes, void* stream) {
+    if (int e = gn_validate(d)) return e;
+    E2EFT_REQUIRE(x1 && y && workspace, "groupnorm: null pointer");
+    E2EFT_REQUIRE(d->c2 == 0 || x2, "groupnorm: x2 missing");
+    E2EFT_REQUIRE((!partial1 || nslabs1 > 0) && (!partial2 || nslabs2 > 0), "groupnorm: precomputed statistics need a slab count");
     GnGeom g;
     gn_geom(d, g);
-    return ((size_t)g.batch * g.nslabs * g.C * 3 + (size_t)g.batch * g.C * 2) * sizeof(float);
+    const size_t need = gn_ws_bytes(d);
+    if (ws_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "groupnorm: workspace %zu < %zu", ws_bytes, need);
+    E2EFT_REQUIRE(g.batch <= 65535 && g.nchb <= 65535, "groupnorm: grid");
+    E2EFT_DISPATCH_DTYPE(d->dtype, T, return gn_run<T>(d, g, x1, x2, gamma, beta, y, partial1, nslabs1, d->c2 > 0 ? partial2 : nullptr, nslabs2,
+                                                      workspace, (hipStream_t)stream));
+    return 0;
 }
 
 extern "C" int e2eft_groupnorm_fwd(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma,
                                    const void* beta, void* y, void* workspace, size_t ws_bytes, void* stream) {
-    if (int e = gn_validate(d)) return e;
-    E2EFT_REQUIRE(x1 && y && workspace, "groupnorm: null pointer");
-    E2EFT_REQUIRE(d->c2 == 0 || x2, "groupnorm: x2 missing");
-    GnGeom g;
-    gn_geom(d, g);
-    const size_t need = ((size_t)g.batch * g.nslabs * g.C * 3 + (size_t)g.batch * g.C * 2) * sizeof(float);
-    if (ws_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "groupnorm: workspace %zu < %zu", ws_bytes, need);
-    E2EFT_REQUIRE(g.batch <= 65535 && g.nchb <= 65535, "groupnorm: grid");
-    E2EFT_DISPATCH_DTYPE(d->dtype, T, return gn_run<T>(d, g, x1, x2, gamma, beta, y, workspace, (hipStream_t)stream));
-    return 0;
+    return e2eft_groupnorm_fwd_pre(d, x1, x2, gamma, beta, y, nullptr, 0, nullptr, 0, workspace, ws_bytes, stream);
 }
 
 extern "C" int e2eft_layernorm_fwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldx, int32_t ldy, float eps,

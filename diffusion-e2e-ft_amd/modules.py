@@ -45,7 +45,7 @@ def packed_conv_weight(conv):
     return _cached(conv, "packed", (w,), build)
 
 
-def conv_nhwc(conv, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0, pad=None, out=None):
+def conv_nhwc(conv, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0, pad=None, out=None, gn_stats=True):
     """Run any nn.Conv2d-shaped module (weight/bias/stride/padding) on NHWC input through the implicit-GEMM kernel.
     Works for plain torch.nn.Conv2d objects too (training/util/unet_prep.py:6-20 swaps conv_in for one)."""
     _no_grad_guard(conv.weight, x)
@@ -56,8 +56,9 @@ def conv_nhwc(conv, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.
         pad = (p, p, p, p)
     if x2 is None:
         x = ops.pad_channels(x)
+    # gn_stats: nearly every conv output of the path is consumed by a GroupNorm next; the epilogue then emits its statistics
     return ops.conv2d(x, packed_conv_weight(conv), conv.bias, conv.weight.shape[0], kh, kw, stride, pad, x2=x2, up_to=up_to,
-                      rowadd=rowadd, residual=residual, alpha=alpha, out=out)
+                      rowadd=rowadd, residual=residual, alpha=alpha, out=out, gn_stats=gn_stats)
 
 
 def _no_grad_guard(*tensors):
@@ -327,8 +328,12 @@ class Transformer2DModel(nn.Module):
         h = self.proj_in(h)
         for blk in self.transformer_blocks:
             h = blk(h, ctx)
-        out = ops.linear(h, self.proj_out.weight, self.proj_out.bias, residual=x)
-        return out.view(B, H, W, C)
+        out = ops.linear(h, self.proj_out.weight, self.proj_out.bias, residual=x, gn_rows_per_image=H * W)
+        res = out.view(B, H, W, C)
+        st = getattr(out, "_e2eft_gn", None)
+        if st is not None:
+            res._e2eft_gn = st   # the next ResnetBlock2D.norm1 reads this tensor
+        return res
 
 
 class VaeAttention(nn.Module):
@@ -349,5 +354,9 @@ class VaeAttention(nn.Module):
         n = self.group_norm.nhwc(x).view(B, H * W, C)
         a = attention_unfused(n, n, self.to_q.weight, self.to_q.bias, self.to_k.weight, self.to_k.bias, self.to_v.weight,
                               self.to_v.bias, 1, C ** -0.5)
-        out = ops.linear(a, self.to_out[0].weight, self.to_out[0].bias, residual=x)
-        return out.view(B, H, W, C)
+        out = ops.linear(a, self.to_out[0].weight, self.to_out[0].bias, residual=x, gn_rows_per_image=H * W)
+        res = out.view(B, H, W, C)
+        st = getattr(out, "_e2eft_gn", None)
+        if st is not None:
+            res._e2eft_gn = st
+        return res

@@ -127,9 +127,32 @@ def pad_channels(x):
     return out  # full padded view: consumers index weights packed with the same padding
 
 
+class GnStats:
+    """GroupNorm partial statistics emitted by the producer of a tensor (e2eft_*_gnstats): [images, nslabs, C, 3] fp32."""
+    __slots__ = ("partial", "nslabs")
+
+    def __init__(self, partial, nslabs):
+        self.partial, self.nslabs = partial, nslabs
+
+
+GN_STATS_ENABLED = True   # tests flip this to cross-check the fused statistics against the stand-alone pass
+
+
+def _gn_buffer(images, rows_per_image, cout, device):
+    nbytes = images * ((rows_per_image + 127) // 128) * cout * 12
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device), nbytes
+
+
+def _attach_stats(out, buf, slab_rows, images, rows_per_image, cout):
+    if slab_rows > 0:
+        nslabs = rows_per_image // slab_rows
+        out._e2eft_gn = GnStats(buf[: images * nslabs * cout * 3], nslabs)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None, up_to=None, rowadd=None,
-           residual=None, alpha=1.0, out=None):
+           residual=None, alpha=1.0, out=None, gn_stats=False):
     """Implicit-GEMM convolution. x: [B,H,W,C1] (C1 % epc == 0), x2: optional [B,H,W,C2] fused channel concat,
     w_packed: [cout, ldw] rows = (ky,kx,c) K-contiguous, pad = (top, bottom, left, right), up_to=(hl,wl) fused
     nearest upsample, rowadd: [B,cout] per-image vector added before alpha, residual: [B,hout,wout,cout]."""
@@ -164,15 +187,24 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
         assert bias.dtype == x.dtype and bias.numel() == cout and bias.is_contiguous()
     if rowadd is not None:
         assert rowadd.dtype == x.dtype and tuple(rowadd.shape) == (B, cout) and rowadd.is_contiguous()
+    want = gn_stats and GN_STATS_ENABLED and cout % 8 == 0
     with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2),
                 label="conv%dx%ds%d%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", B, hout, wout, d.c1 + d.c2, cout)):
-        check(_lib.load().e2eft_conv2d_fwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(w_packed), _ptr(bias), _ptr(rowadd),
-                                           _ptr(residual), _ptr(out), _stream()))
+        if want:
+            buf, nbytes = _gn_buffer(B, hout * wout, cout, x.device)
+            slab = C.c_int32(0)
+            check(_lib.load().e2eft_conv2d_fwd_gnstats(C.byref(d), _ptr(x), _ptr(x2), _ptr(w_packed), _ptr(bias), _ptr(rowadd),
+                                                       _ptr(residual), _ptr(out), _ptr(buf), nbytes, C.byref(slab), _stream()))
+            _attach_stats(out, buf, slab.value, B, hout * wout, cout)
+        else:
+            check(_lib.load().e2eft_conv2d_fwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(w_packed), _ptr(bias), _ptr(rowadd),
+                                               _ptr(residual), _ptr(out), _stream()))
     return out
 
 
-def gemm(a, w, bias=None, residual=None, out=None, alpha=1.0, bias_along_m=False):
-    """out[m,n] = alpha*(sum_k a[m,k] w[n,k] + bias) + residual.  a: [M,K] view, w: [N,K] view."""
+def gemm(a, w, bias=None, residual=None, out=None, alpha=1.0, bias_along_m=False, gn_rows_per_image=0):
+    """out[m,n] = alpha*(sum_k a[m,k] w[n,k] + bias) + residual.  a: [M,K] view, w: [N,K] view.
+    gn_rows_per_image > 0: also emit GroupNorm partial statistics of `out` (attached as out._e2eft_gn)."""
     _check_cuda(a, w, bias, residual, out)
     M, K = a.shape
     N, K2 = w.shape
@@ -192,8 +224,16 @@ def gemm(a, w, bias=None, residual=None, out=None, alpha=1.0, bias_along_m=False
         assert bias.dtype == a.dtype and bias.is_contiguous() and bias.numel() == (M if bias_along_m else N)
     if residual is not None:
         assert tuple(residual.shape) == (M, N) and residual.dtype == a.dtype
+    want = gn_rows_per_image > 0 and GN_STATS_ENABLED and N % 8 == 0 and M % gn_rows_per_image == 0 and not bias_along_m
     with _timed("igemm", 2.0 * M * N * K, label="gemm M%d N%d K%d" % (M, N, K)):
-        check(_lib.load().e2eft_gemm(C.byref(d), _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), _stream()))
+        if want:
+            buf, nbytes = _gn_buffer(M // gn_rows_per_image, gn_rows_per_image, N, a.device)
+            slab = C.c_int32(0)
+            check(_lib.load().e2eft_gemm_gnstats(C.byref(d), _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), gn_rows_per_image,
+                                                 _ptr(buf), nbytes, C.byref(slab), _stream()))
+            _attach_stats(out, buf, slab.value, M // gn_rows_per_image, gn_rows_per_image, N)
+        else:
+            check(_lib.load().e2eft_gemm(C.byref(d), _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), _stream()))
     return out
 
 
@@ -217,7 +257,7 @@ def bgemm_raw(dtype, m, n, k, a, lda, sa, w, ldw, sw, out, ldo, so, nzo, nzi, bi
     return out
 
 
-def linear(x, weight, bias=None, residual=None, out=None, alpha=1.0):
+def linear(x, weight, bias=None, residual=None, out=None, alpha=1.0, gn_rows_per_image=0):
     """nn.Linear on the last dim of x [..., K] (dense rows); weight [N, K]."""
     K = x.shape[-1]
     a = x.reshape(-1, K) if x.is_contiguous() else _as_rows(x)
@@ -228,8 +268,12 @@ def linear(x, weight, bias=None, residual=None, out=None, alpha=1.0):
     o2 = None
     if out is not None:
         o2 = out.reshape(-1, N) if out.is_contiguous() else _as_rows(out)
-    y = gemm(a, weight, bias, r, o2, alpha)
-    return y.reshape(*x.shape[:-1], N) if out is None else out
+    y = gemm(a, weight, bias, r, o2, alpha, gn_rows_per_image=gn_rows_per_image)
+    res = y.reshape(*x.shape[:-1], N) if out is None else out
+    st = getattr(y, "_e2eft_gn", None)
+    if st is not None:
+        res._e2eft_gn = st
+    return res
 
 
 def _as_rows(t):
@@ -269,8 +313,12 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None):
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     if gamma is not None:
         assert gamma.dtype == x.dtype and gamma.numel() == c1 + c2
+    s1 = getattr(x, "_e2eft_gn", None) if GN_STATS_ENABLED else None
+    s2 = getattr(x2, "_e2eft_gn", None) if (x2 is not None and GN_STATS_ENABLED) else None
     with _timed("groupnorm", 0.0, 2.0 * B * H * W * (c1 + c2) * x.element_size(), label="gn B%d %dx%d C%d" % (B, H, W, c1 + c2)):
-        check(lib.e2eft_groupnorm_fwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), nbytes, _stream()))
+        check(lib.e2eft_groupnorm_fwd_pre(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out),
+                                          _ptr(s1.partial) if s1 else C.c_void_p(0), s1.nslabs if s1 else 0,
+                                          _ptr(s2.partial) if s2 else C.c_void_p(0), s2.nslabs if s2 else 0, _ptr(ws), nbytes, _stream()))
     return out
 
 

@@ -95,6 +95,20 @@ typedef struct E2eftGemmDesc {
 int e2eft_gemm(const E2eftGemmDesc* d, const void* a, const void* w, const void* bias, const void* residual,
                void* out, void* stream);
 
+/* Same as e2eft_conv2d_fwd / e2eft_gemm, and the epilogue additionally emits the GroupNorm partial statistics of the tensor
+ * it writes (of the ROUNDED values), so that the GroupNorm consuming `out` can skip its statistics pass over HBM:
+ *   gn_partial [images][nslabs][cout][3] float triples (count, mean, M2) per row slab and channel,
+ *   gn_partial_bytes >= images * ceil(rows_per_image / 128) * cout * 12,
+ *   *slab_rows receives the rows per slab the kernel used (nslabs = rows_per_image / *slab_rows), or 0 when this launch could
+ *   not emit statistics (rows_per_image not a multiple of the tile height, cout % 8 != 0, unaligned output): the caller then
+ *   simply runs e2eft_groupnorm_fwd.  rows_per_image for the GEMM form = tokens per image (m % rows_per_image == 0). */
+int e2eft_conv2d_fwd_gnstats(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w, const void* bias,
+                             const void* rowadd, const void* residual, void* out, float* gn_partial,
+                             size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
+int e2eft_gemm_gnstats(const E2eftGemmDesc* d, const void* a, const void* w, const void* bias, const void* residual,
+                       void* out, int32_t rows_per_image, float* gn_partial, size_t gn_partial_bytes,
+                       int32_t* slab_rows, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU), NHWC, fp32 statistics (shifted/Welford-merged).
  * Replaces nn.GroupNorm(+nn.SiLU) in ResnetBlock2D.norm1/norm2, conv_norm_out, Transformer2DModel.norm,
@@ -115,6 +129,11 @@ typedef struct E2eftGroupNormDesc {
 size_t e2eft_groupnorm_workspace_bytes(const E2eftGroupNormDesc* d);
 int e2eft_groupnorm_fwd(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma,
                         const void* beta, void* y, void* workspace, size_t ws_bytes, void* stream);
+/* GroupNorm whose statistics pass was (partly) done by the producer (e2eft_*_gnstats): partialK / nslabsK describe source K
+ * ([batch][nslabsK][cK][3]); a NULL partial is computed here.  Same workspace size as e2eft_groupnorm_fwd. */
+int e2eft_groupnorm_fwd_pre(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma,
+                            const void* beta, void* y, const float* partial1, int32_t nslabs1, const float* partial2,
+                            int32_t nslabs2, void* workspace, size_t ws_bytes, void* stream);
 
 /* LayerNorm over the last dim of [rows, c] (row stride ldx / ldy), eps, affine.
  * Replaces nn.LayerNorm norm1/2/3 of BasicTransformerBlock (attention.py:205,237,264). */

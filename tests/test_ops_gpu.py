@@ -158,6 +158,49 @@ def test_groupnorm(ops, dev, dtype, C, H, W, c2, silu, offset):
     assert_close(to_nchw(out), ref, dtype, "groupnorm", scale=(8.0 if offset else 1.5))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,W,Ci,Co,k,c2", [(16, 16, 64, 128, 3, 0), (32, 16, 64, 320, 3, 0), (16, 32, 128, 64, 1, 0), (16, 16, 64, 64, 3, 64)])
+def test_groupnorm_with_producer_statistics(ops, dev, dtype, H, W, Ci, Co, k, c2):
+    """conv / linear epilogues emit the GroupNorm partial statistics of their output; GroupNorm fed with them must match both
+    the torch reference and the stand-alone statistics pass (two sources: one with, one without producer statistics)."""
+    g = _g(H * 3 + Co)
+    B = 3
+    x = q(torch.randn(B, Ci, H, W, generator=g) + 0.5, dtype)
+    w = q(torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5, dtype)
+    b = q(torch.randn(Co, generator=g), dtype)
+    res = q(torch.randn(B, Co, H, W, generator=g), dtype)
+    pad = (k // 2,) * 4
+    conv_out = ops.conv2d(nhwc(x, dtype, dev), pack_conv_weight(w, dtype, dev), b.to(dtype).to(dev), Co, k, k, 1, pad,
+                          residual=nhwc(res, dtype, dev), gn_stats=True)
+    assert getattr(conv_out, "_e2eft_gn", None) is not None, "statistics were not emitted (H*W multiple of 128/256 expected)"
+    C = Co + c2
+    ga, be = q(1 + 0.3 * torch.randn(C, generator=g), dtype), q(0.3 * torch.randn(C, generator=g), dtype)
+    skip = q(torch.randn(B, c2, H, W, generator=g) * 2 - 1, dtype) if c2 else None
+    skip_d = nhwc(skip, dtype, dev) if c2 else None
+    y = ops.groupnorm(conv_out, ga.to(dtype).to(dev), be.to(dtype).to(dev), 32, 1e-5, True, x2=skip_d)
+    full = to_nchw(conv_out) if not c2 else torch.cat([to_nchw(conv_out), skip], dim=1)
+    ref = F.silu(F.group_norm(full.double(), 32, ga.double(), be.double(), 1e-5)).float()
+    assert_close(to_nchw(y), ref, dtype, "groupnorm on producer statistics", scale=1.5)
+    ops.GN_STATS_ENABLED = False
+    try:
+        y2 = ops.groupnorm(conv_out, ga.to(dtype).to(dev), be.to(dtype).to(dev), 32, 1e-5, True, x2=skip_d)
+    finally:
+        ops.GN_STATS_ENABLED = True
+    assert_close(to_nchw(y), to_nchw(y2), dtype, "fused vs stand-alone statistics", scale=0.5)
+    # GEMM form (transformer proj_out + residual -> next GroupNorm)
+    t = q(torch.randn(B, H * W, 64, generator=g), dtype)
+    wl = q(torch.randn(128, 64, generator=g) / 8, dtype)
+    lo = ops.linear(t.to(dtype).to(dev), wl.to(dtype).to(dev), gn_rows_per_image=H * W)
+    assert getattr(lo, "_e2eft_gn", None) is not None
+    g2, b2 = q(1 + 0.3 * torch.randn(128, generator=g), dtype), q(0.3 * torch.randn(128, generator=g), dtype)
+    yl = ops.groupnorm(lo.view(B, H, W, 128), g2.to(dtype).to(dev), b2.to(dtype).to(dev), 32, 1e-6, False) if False else None
+    lv = lo.view(B, H, W, 128)
+    lv._e2eft_gn = lo._e2eft_gn
+    yl = ops.groupnorm(lv, g2.to(dtype).to(dev), b2.to(dtype).to(dev), 32, 1e-6, False)
+    refl = F.group_norm(lo.float().cpu().view(B, H, W, 128).permute(0, 3, 1, 2).double(), 32, g2.double(), b2.double(), 1e-6).float()
+    assert_close(to_nchw(yl), refl, dtype, "groupnorm on gemm statistics", scale=1.5)
+
+
 def test_groupnorm_constant_kat(ops, dev):
     """GroupNorm of a constant is beta (variance 0)"""
     x = torch.full((1, 64, 6, 6), 3.25)
