@@ -75,6 +75,27 @@ SIGNATURES = {
     "e2eft_ssi_loss_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "e2eft_angular_loss_workspace_bytes": (_Z, [_I]),
     "e2eft_angular_loss_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    # backward / optimizer
+    "e2eft_conv2d_dgrad": (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _I, _P, _I, _P]),
+    "e2eft_conv2d_im2col_t": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _L, _P]),
+    "e2eft_transpose": (_I, [_I, _I, _L, _I, _L, _L, _L, _L, _L, _P, _P, _P]),
+    "e2eft_colsum_workspace_bytes": (_Z, [_I, _L, _I]),
+    "e2eft_colsum": (_I, [_I, _I, _L, _I, _L, _F, _P, _P, _P, _Z, _P]),
+    "e2eft_upsample_nearest_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "e2eft_groupnorm_bwd_workspace_bytes": (_Z, [C.POINTER(GroupNormDesc)]),
+    "e2eft_groupnorm_bwd": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "e2eft_layernorm_bwd_workspace_bytes": (_Z, [_L, _I]),
+    "e2eft_layernorm_bwd": (_I, [_I, _L, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "e2eft_geglu_bwd": (_I, [_I, _L, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "e2eft_softmax_bwd_rows": (_I, [_I, _L, _I, _L, _F, _P, _P, _P]),
+    "e2eft_silu_bwd": (_I, [_I, _L, _P, _P, _P, _P]),
+    "e2eft_depth_head_bwd": (_I, [_I, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "e2eft_normal_head_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "e2eft_ssi_loss_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "e2eft_angular_loss_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "e2eft_sumsq": (_I, [_L, _P, _P, _P]),
+    "e2eft_adamw_step": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _F, _F, _P]),
+    "e2eft_cast": (_I, [_I, _I, _L, _F, _I, _P, _P, _P]),
 }
 
 
@@ -100,7 +121,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.e2eft_version() < 100:
+    if lib.e2eft_version() < 110:
         raise RuntimeError("libe2eft.so is stale (version %d)" % lib.e2eft_version())
     _LIB = lib
     return lib

@@ -1,0 +1,573 @@
+"""torch.autograd plumbing of the E2E-FT training step (training/train.py:470-568).
+
+The reference gets its gradients from torch autograd over diffusers modules.  Here every differentiable op of the host
+layer is a `torch.autograd.Function` whose forward AND backward are libe2eft (HIP) launches; torch only records the graph,
+owns the memory and accumulates `.grad`.  Entry points `conv / linear / groupnorm / layernorm / geglu / silu / attention /
+depth_head / normal_head / ssi_loss / angular_loss` pick the Function when a gradient is required and the plain inference
+wrapper of ops.py otherwise (so the inference path keeps its fused GroupNorm statistics and pays nothing).
+
+Activations keep the NHWC / token layout of the forward; parameters keep the diffusers layout (conv weights OIHW), their
+gradients are returned in the parameter's dtype and shape.  Compute dtype follows the activations: fp32 parameters with 16-bit
+activations are cast once per parameter version (cached).
+"""
+import torch
+
+from . import ops
+
+
+def needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# per-parameter derived tensors (packed / transposed / cast weights): rebuilt when the parameter changes
+PARAM_EPOCH = 0   # bumped by the flat-buffer optimizer (training.py), which updates parameters behind torch's version counters
+
+
+def bump_param_epoch():
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
+
+
+def _key(*params):
+    return (PARAM_EPOCH,) + tuple((p._version, p.data_ptr(), p.dtype, str(p.device)) for p in params)
+
+
+def cached(owner, name, params, builder):
+    cache = owner.__dict__.setdefault("_e2eft_cache", {})
+    k = _key(*params)
+    hit = cache.get(name)
+    if hit is None or hit[0] != k:
+        with torch.no_grad():
+            hit = (k, builder())
+        cache[name] = hit
+    return hit[1]
+
+
+def _vec(p, dtype):
+    """bias / gamma / beta in the compute dtype"""
+    if p is None:
+        return None
+    p = p.detach()
+    return p if p.dtype == dtype else p.to(dtype)
+
+
+def packed_conv_weight(conv, dtype):
+    """[Co,Ci,kh,kw] -> OHWI rows [Co, kh*kw*Ci_pad] in `dtype` (Ci padded with zeros to a 16-byte multiple)."""
+    w = conv.weight
+
+    def build():
+        Co, Ci, kh, kw = w.shape
+        cp = ops.round_up(Ci, ops.epc(dtype))
+        t = w.detach().to(dtype).permute(0, 2, 3, 1)
+        if cp != Ci:
+            t = torch.nn.functional.pad(t, (0, cp - Ci))
+        return t.reshape(Co, kh * kw * cp).contiguous()
+
+    return cached(conv, "packed_%s" % dtype, (w,), build)
+
+
+def packed_conv_weight_dgrad(conv, dtype):
+    """w_dgrad[ci][(kh-1-ky, kw-1-kx, co)] with ci / co padded to 16-byte multiples (include/e2eft.h e2eft_conv2d_dgrad)."""
+    w = conv.weight
+
+    def build():
+        Co, Ci, kh, kw = w.shape
+        e = ops.epc(dtype)
+        cip, cop = ops.round_up(Ci, e), ops.round_up(Co, e)
+        t = w.detach().to(dtype).flip(2, 3).permute(1, 2, 3, 0)        # [Ci, kh, kw, Co]
+        t = torch.nn.functional.pad(t, (0, cop - Co, 0, 0, 0, 0, 0, cip - Ci))
+        return t.reshape(cip, kh * kw * cop).contiguous()
+
+    return cached(conv, "packed_dgrad_%s" % dtype, (w,), build)
+
+
+def _dense_nhwc(g, cpad):
+    """gradient tensor [B,H,W,C] -> pixel-dense NHWC view/copy whose channel extent is padded to `cpad` with zeros"""
+    B, H, W, Cc = g.shape
+    ok = True
+    try:
+        ld = ops._nhwc_ld(g)
+        ok = ld % ops.epc(g.dtype) == 0 and g.data_ptr() % 16 == 0
+    except ValueError:
+        ok = False
+    if ok and Cc == cpad:
+        return g
+    out = torch.zeros((B, H, W, cpad), dtype=g.dtype, device=g.device) if cpad != Cc else torch.empty((B, H, W, cpad), dtype=g.dtype, device=g.device)
+    if ok:
+        ops.copy_scale(g, out[..., :Cc])
+    else:
+        out[..., :Cc].copy_(g)
+    return out
+
+
+def _rows(t):
+    """[..., C] tensor -> 2-D row view [M, C] (copy only when the leading dims are not dense)"""
+    Cc = t.shape[-1]
+    if t.is_contiguous():
+        return t.reshape(-1, Cc)
+    try:
+        v = ops._as_rows(t)
+        if v.stride(0) % ops.epc(t.dtype) == 0 and v.data_ptr() % 16 == 0:
+            return v
+    except ValueError:
+        pass
+    return t.contiguous().reshape(-1, Cc)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _Conv2dFn(torch.autograd.Function):
+    """out = alpha * (conv(cat(x, x2)) + bias + rowadd[b]) + residual — forward e2eft_conv2d_fwd, backward e2eft_conv2d_dgrad
+    (+ e2eft_upsample_nearest_bwd), e2eft_transpose + e2eft_conv2d_im2col_t + e2eft_gemm (wgrad), e2eft_colsum (bias / rowadd)."""
+
+    @staticmethod
+    def forward(ctx, x, x2, weight, bias, rowadd, residual, conv, stride, pad, up_to, alpha):
+        dt = x.dtype
+        kh, kw = weight.shape[2:]
+        cout = weight.shape[0]
+        xp = ops.pad_channels(x) if x2 is None else x     # 3/4-channel inputs: zero padded copy (weights are packed to match)
+        out = ops.conv2d(xp, packed_conv_weight(conv, dt), _vec(bias, dt), cout, kh, kw, stride, pad, x2=x2, up_to=up_to,
+                         rowadd=rowadd, residual=residual, alpha=alpha, gn_stats=False)
+        ctx.save_for_backward(xp, x2, weight, bias)
+        ctx.conv, ctx.geom = conv, (stride, pad, up_to, alpha, x.shape[3])
+        ctx.has = (rowadd is not None, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, x2, weight, bias = ctx.saved_tensors
+        stride, pad, up_to, alpha, c_orig = ctx.geom
+        conv = ctx.conv
+        dt = xp.dtype
+        Co, Ci, kh, kw = weight.shape
+        B, H, W, c1 = xp.shape
+        c2 = 0 if x2 is None else x2.shape[3]
+        need = ctx.needs_input_grad
+        e = ops.epc(dt)
+        cop = ops.round_up(Co, e)
+        dyp = _dense_nhwc(dy, cop)
+        dx = dx2 = dw = dbias = drow = dres = None
+        if ctx.has[1] and need[5]:
+            dres = dy
+        if (bias is not None and need[3]) or (ctx.has[0] and need[4]):
+            s = ops.colsum(ops._as_rows(dyp), groups=B, alpha=alpha)[:, :Co]       # [B, Co] fp32
+            if ctx.has[0] and need[4]:
+                drow = s.to(dt)
+            if bias is not None and need[3]:
+                dbias = s.sum(0).to(bias.dtype)
+        if need[0] or (x2 is not None and need[1]):
+            dxl = ops.conv2d_dgrad(dyp, packed_conv_weight_dgrad(conv, dt), (B, H, W, c1), c2, kh, kw, stride, pad, up_to, alpha)
+            if up_to is not None:
+                dxl = ops.upsample_nearest_bwd(dxl, H, W)
+            if need[0]:
+                dx = dxl[..., :c_orig]
+            if x2 is not None and need[1]:
+                dx2 = dxl[..., c1:]
+        if need[2]:
+            dyT = ops.transpose(ops._as_rows(dyp))                              # [cop, Pp]
+            col, P, Pp = ops.im2col_t(xp, x2, kh, kw, stride, pad, up_to)       # [kh*kw*cin, Pp]
+            assert dyT.shape[1] == Pp
+            dwp = ops.gemm(dyT[:Co], col, alpha=alpha)                          # [Co, kh*kw*cin] = OHWI
+            dw = dwp.view(Co, kh, kw, c1 + c2)[..., :Ci].permute(0, 3, 1, 2)
+            if dw.dtype != weight.dtype:
+                dw = dw.to(weight.dtype)
+        return dx, dx2, dw, dbias, drow, dres, None, None, None, None, None
+
+
+def conv(conv_mod, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0, pad=None, gn_stats=True):
+    """nn.Conv2d-shaped module on NHWC input (see modules.conv_nhwc); differentiable when a gradient is required."""
+    kh, kw = conv_mod.weight.shape[2:]
+    stride = conv_mod.stride[0] if isinstance(conv_mod.stride, tuple) else conv_mod.stride
+    if pad is None:
+        p = conv_mod.padding[0] if isinstance(conv_mod.padding, tuple) else conv_mod.padding
+        pad = (p, p, p, p)
+    if needs_grad(x, x2, conv_mod.weight, conv_mod.bias, rowadd, residual):
+        return _Conv2dFn.apply(x, x2, conv_mod.weight, conv_mod.bias, rowadd, residual, conv_mod, stride, tuple(pad), up_to, alpha)
+    dt = x.dtype
+    if x2 is None:
+        x = ops.pad_channels(x)
+    return ops.conv2d(x, packed_conv_weight(conv_mod, dt), _vec(conv_mod.bias, dt), conv_mod.weight.shape[0], kh, kw, stride, pad, x2=x2,
+                      up_to=up_to, rowadd=rowadd, residual=residual, alpha=alpha, gn_stats=gn_stats)
+
+
+# ------------------------------------------------------------------------------------------------------------
+def _cat_weight(owner, name, weights, dtype, kpad):
+    def build():
+        w = torch.cat([p.detach().to(dtype) for p in weights], dim=0) if len(weights) > 1 else weights[0].detach().to(dtype)
+        if kpad != w.shape[1]:
+            w = torch.nn.functional.pad(w, (0, kpad - w.shape[1]))
+        return w.contiguous()
+
+    if len(weights) == 1 and weights[0].dtype == dtype and kpad == weights[0].shape[1]:
+        return weights[0].detach()
+    return cached(owner, "%s_%s" % (name, dtype), tuple(weights), build)
+
+
+def _cat_weight_t(owner, name, weights, dtype, kpad):
+    """[K_pad, N_pad64] transpose of the concatenated weight: the W operand of dX = dY · W"""
+    return cached(owner, "%s_t_%s" % (name, dtype), tuple(weights), lambda: ops.transpose(_cat_weight(owner, name, weights, dtype, kpad)))
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = alpha * (x W^T + b) + residual with W = cat(weights) along the output dim (fused q/k/v projections)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, owner, name, alpha, *weights):
+        dt = x.dtype
+        K = x.shape[-1]
+        kp = ops.round_up(K, ops.epc(dt))
+        xp = torch.nn.functional.pad(x, (0, kp - K)) if kp != K else x
+        w = _cat_weight(owner, name, weights, dt, kp)
+        y = ops.linear(xp, w, _vec(bias, dt), residual=residual, alpha=alpha)
+        ctx.save_for_backward(xp, bias, *weights)
+        ctx.meta = (owner, name, alpha, K, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, bias, *weights = ctx.saved_tensors
+        owner, name, alpha, K, has_res = ctx.meta
+        dt = xp.dtype
+        kp = xp.shape[-1]
+        need = ctx.needs_input_grad
+        g = _rows(dy)                                    # [M, N]
+        M, N = g.shape
+        dx = dbias = dres = None
+        dws = [None] * len(weights)
+        if has_res and need[2]:
+            dres = dy
+        if need[0]:
+            wt = _cat_weight_t(owner, name, weights, dt, kp)        # [kp, N64]
+            n64 = wt.shape[1]
+            if n64 != N:   # contraction length must match: zero-extend dy's columns (N is a multiple of 64 for every UNet layer)
+                g64 = torch.zeros((M, n64), dtype=dt, device=g.device)
+                g64[:, :N].copy_(g)
+            else:
+                g64 = g
+            dxp = ops.gemm(g64, wt, alpha=alpha)                    # [M, kp]
+            dx = dxp.view(*xp.shape[:-1], kp)[..., :K]
+        if any(need[6:]):
+            gT = ops.transpose(g)                                   # [N, M64]
+            xT = ops.transpose(_rows(xp))                           # [kp, M64]
+            dw = ops.gemm(gT, xT, alpha=alpha)                      # [N, kp]
+            o = 0
+            for i, wgt in enumerate(weights):
+                n = wgt.shape[0]
+                if need[6 + i]:
+                    t = dw[o:o + n, :K]
+                    dws[i] = t if t.dtype == wgt.dtype else t.to(wgt.dtype)
+                o += n
+        if bias is not None and need[1]:
+            dbias = ops.colsum(g, groups=1, alpha=alpha)[0].to(bias.dtype)
+        return (dx, dbias, dres, None, None, None, *dws)
+
+
+def linear(x, weights, bias=None, residual=None, alpha=1.0, owner=None, name="w", gn_rows_per_image=0):
+    """nn.Linear on the last dim; `weights` is a Parameter or a tuple of Parameters concatenated along the output dim.
+    `owner` (a module) holds the cache of the concatenated / cast / transposed weight."""
+    if not isinstance(weights, (tuple, list)):
+        weights = (weights,)
+    if needs_grad(x, bias, residual, *weights):
+        return _LinearFn.apply(x, bias, residual, owner, name, alpha, *weights)
+    dt = x.dtype
+    K = x.shape[-1]
+    kp = ops.round_up(K, ops.epc(dt))
+    if kp != K:
+        x = torch.nn.functional.pad(x, (0, kp - K))
+    return ops.linear(x, _cat_weight(owner, name, weights, dt, kp), _vec(bias, dt), residual=residual, alpha=alpha, gn_rows_per_image=gn_rows_per_image)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, x2, gamma, beta, groups, eps, silu):
+        dt = x.dtype
+        y, ws = ops.groupnorm_fwd_ws(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, x2=x2)
+        ctx.save_for_backward(x, x2, gamma, beta, ws)
+        ctx.meta = (groups, eps, silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, gamma, beta, ws = ctx.saved_tensors
+        groups, eps, silu = ctx.meta
+        dt = x.dtype
+        need = ctx.needs_input_grad
+        c1 = x.shape[3]
+        Cc = c1 + (0 if x2 is None else x2.shape[3])
+        g = _dense_nhwc(dy, Cc)
+        want_dx = need[0] or (x2 is not None and need[1])
+        want_p = need[2] or need[3]
+        dx, dg, db = ops.groupnorm_bwd(x, x2, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu, g, ws, need_dx=want_dx, need_dparams=want_p)
+        d1 = dx[..., :c1] if (need[0] and dx is not None) else None
+        d2 = dx[..., c1:] if (x2 is not None and need[1]) else None
+        return d1, d2, (dg.to(gamma.dtype) if need[2] else None), (db.to(beta.dtype) if need[3] else None), None, None, None
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None):
+    if needs_grad(x, x2, gamma, beta):
+        return _GroupNormFn.apply(x, x2, gamma, beta, groups, eps, silu)
+    dt = x.dtype
+    return ops.groupnorm(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, x2=x2)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        dt = x.dtype
+        y = ops.layernorm(x, _vec(gamma, dt), _vec(beta, dt), eps)
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        g = dy if dy.is_contiguous() else dy.contiguous()
+        dx, dg, db = ops.layernorm_bwd(x, _vec(gamma, x.dtype), ctx.eps, g, need_dx=need[0])
+        return dx, (dg.to(gamma.dtype) if need[1] else None), (db.to(beta.dtype) if need[2] else None), None
+
+
+def layernorm(x, gamma, beta, eps):
+    if needs_grad(x, gamma, beta):
+        return _LayerNormFn.apply(x, gamma, beta, eps)
+    return ops.layernorm(x, _vec(gamma, x.dtype), _vec(beta, x.dtype), eps)
+
+
+class _GegluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return ops.geglu(h)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        return ops.geglu_bwd(h, dy if dy.stride(-1) == 1 else dy.contiguous())
+
+
+def geglu(h):
+    return _GegluFn.apply(h) if needs_grad(h) else ops.geglu(h)
+
+
+class _SiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.silu(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.silu_bwd(x, dy)
+
+
+def silu(x):
+    return _SiluFn.apply(x) if needs_grad(x) else ops.silu(x)
+
+
+def add(a, b):
+    """tiny [B, temb] additions of the embedding path: torch's own op records the graph when one is needed"""
+    return a + b if needs_grad(a, b) else ops.add(a, b)
+
+
+# ------------------------------------------------------------------------------------------------------------
+def _attn_views(qkv, kv, C):
+    if kv is None:
+        return qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:3 * C]
+    return qkv, kv[..., :C], kv[..., C:2 * C]
+
+
+def _scores(q, k, heads, dt):
+    """S[b,h] = q_h k_h^T as [B, heads, N, nkp] (pad columns unwritten)"""
+    B, N, C = q.shape
+    Nk = k.shape[1]
+    d = C // heads
+    nkp = ops.round_up(Nk, ops.epc(dt))
+    s = torch.empty((B, heads, N, nkp), dtype=dt, device=q.device)
+    ops.bgemm_raw(dt, N, Nk, d, q, q.stride(1), (q.stride(0), d), k, k.stride(1), (k.stride(0), d), s, nkp, (heads * N * nkp, N * nkp), B, heads)
+    return s, nkp
+
+
+def _attn_core_unfused(q, k, v, heads, scale):
+    """softmax(q k^T * scale) v through batched MFMA GEMMs (any head dim, exact fp32 capable). q [B,N,C], k/v [B,Nk,C] views."""
+    B, N, C = q.shape
+    Nk = k.shape[1]
+    d = C // heads
+    dt = q.dtype
+    s, nkp = _scores(q, k, heads, dt)
+    ops.softmax_rows_(s.view(-1, nkp), Nk, scale)
+    vt = ops.transpose(v, rows_pad=nkp)                                         # [B, C, nkp]
+    o = torch.empty((B, N, C), dtype=dt, device=q.device)
+    ops.bgemm_raw(dt, N, d, nkp, s, nkp, (heads * N * nkp, N * nkp), vt, nkp, (C * nkp, d * nkp), o, C, (N * C, d), B, heads)
+    return o
+
+
+class _AttentionFn(torch.autograd.Function):
+    """Attention core on packed projections: self-attention takes qkv [B,N,3C]; cross-attention q [B,N,C] + kv [B,L,2C].
+    Forward: the flash kernel (16-bit, d = 64) or the GEMM + softmax form.  Backward recomputes P = softmax(q k^T) and runs
+        dP = dO V^T,  dS = P o (dP - rowsum(dP o P)) * scale,  dQ = dS K,  dK = dS^T Q,  dV = P^T dO
+    as batched MFMA GEMMs; the pixel-major operands (K^T, Q^T, dO^T, P^T, dS^T) come from e2eft_transpose."""
+
+    @staticmethod
+    def forward(ctx, qkv, kv, heads, scale):
+        C = qkv.shape[-1] // 3 if kv is None else qkv.shape[-1]
+        q, k, v = _attn_views(qkv, kv, C)
+        if qkv.dtype != torch.float32 and C // heads == 64:
+            o = ops.attention(q, k, v, heads, scale)
+        else:
+            o = _attn_core_unfused(q, k, v, heads, scale)
+        ctx.save_for_backward(qkv, kv)
+        ctx.meta = (heads, scale, C)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, kv = ctx.saved_tensors
+        heads, scale, C = ctx.meta
+        q, k, v = _attn_views(qkv, kv, C)
+        B, N, _ = q.shape
+        Nk = k.shape[1]
+        d = C // heads
+        dt = q.dtype
+        do = do.contiguous()
+        z = B * heads
+        # P = softmax(scale * q k^T)
+        p, nkp = _scores(q, k, heads, dt)
+        ops.softmax_rows_(p.view(-1, nkp), Nk, scale)
+        # dP = dO V^T   (contraction over d, contiguous in both)
+        dp = torch.empty_like(p)
+        ops.bgemm_raw(dt, N, Nk, d, do, C, (N * C, d), v, v.stride(1), (v.stride(0), d), dp, nkp, (heads * N * nkp, N * nkp), B, heads)
+        ops.softmax_bwd_rows_(p.view(-1, nkp), dp.view(-1, nkp), Nk, scale)      # dp <- dS (pad columns zero)
+        if kv is None:
+            dqkv = torch.empty_like(qkv) if qkv.is_contiguous() else torch.empty(qkv.shape, dtype=dt, device=qkv.device)
+            dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+            dkv = None
+        else:
+            dqkv = torch.empty(q.shape, dtype=dt, device=q.device)
+            dkv = torch.empty(kv.shape, dtype=dt, device=q.device)
+            dq, dk, dv = dqkv, dkv[..., :C], dkv[..., C:]
+        # dQ = dS K: contraction over keys -> K^T [B, C, nkp]
+        kt = ops.transpose(k, rows_pad=nkp)
+        ops.bgemm_raw(dt, N, d, nkp, dp, nkp, (heads * N * nkp, N * nkp), kt, nkp, (C * nkp, d * nkp), dq, dq.stride(1), (dq.stride(0), d), B, heads)
+        # dK = dS^T Q, dV = P^T dO: contraction over queries -> transposed score matrices [z, nkp, Np] and Q^T / dO^T [B, C, Np]
+        np_ = ops.round_up(N, 64)
+        qt = ops.transpose(q, rows_pad=np_)
+        dot = ops.transpose(do, rows_pad=np_)
+        st = ops.transpose(dp.view(z, N, nkp), rows_pad=np_)                     # dS^T
+        ops.bgemm_raw(dt, Nk, d, np_, st, np_, (heads * nkp * np_, nkp * np_), qt, np_, (C * np_, d * np_), dk, dk.stride(1), (dk.stride(0), d), B, heads)
+        ops.transpose(p.view(z, N, nkp), rows_pad=np_, out=st)                   # P^T (reuses the buffer)
+        ops.bgemm_raw(dt, Nk, d, np_, st, np_, (heads * nkp * np_, nkp * np_), dot, np_, (C * np_, d * np_), dv, dv.stride(1), (dv.stride(0), d), B, heads)
+        return dqkv, dkv, None, None
+
+
+def attention(qkv, kv, heads, scale):
+    """qkv [B,N,3C] (self) or q [B,N,C] with kv [B,L,2C] (cross) -> [B,N,C]"""
+    if needs_grad(qkv, kv):
+        return _AttentionFn.apply(qkv, kv, heads, scale)
+    C = qkv.shape[-1] // 3 if kv is None else qkv.shape[-1]
+    q, k, v = _attn_views(qkv, kv, C)
+    if qkv.dtype != torch.float32 and C // heads == 64:
+        return ops.attention(q, k, v, heads, scale)
+    return _attn_core_unfused(q, k, v, heads, scale)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _NchwToNhwcFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cpad):
+        ctx.c = x.shape[1]
+        return ops.nchw_to_nhwc(x.contiguous(), cpad=cpad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.nhwc_to_nchw(_dense_nhwc(dy, dy.shape[3])[..., :ctx.c]), None
+
+
+def nchw_to_nhwc(x, cpad):
+    return _NchwToNhwcFn.apply(x, cpad) if needs_grad(x) else ops.nchw_to_nhwc(x.contiguous(), cpad=cpad)
+
+
+class _DepthHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, to_unit):
+        ctx.save_for_backward(x)
+        ctx.to_unit = to_unit
+        return ops.depth_head(x, to_unit)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.depth_head_bwd(x, dy, ctx.to_unit), None
+
+
+def depth_head(x, to_unit=False):
+    """decoder output NHWC [B,H,W,3] -> [B,1,H,W] = clamp(mean_c, -1, 1)  (train.py:531-533)"""
+    return _DepthHeadFn.apply(x, to_unit) if needs_grad(x) else ops.depth_head(x, to_unit)
+
+
+class _NormalHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, clamp, sign):
+        ctx.save_for_backward(x)
+        ctx.meta = (clamp, sign)
+        return ops.normal_head(x, clamp=clamp, sign=sign)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.normal_head_bwd(x, dy, ctx.meta[0], ctx.meta[1]), None, None
+
+
+def normal_head(x, clamp=True, sign=1.0):
+    """decoder output NHWC [B,H,W,3] -> [B,3,H,W] = clamp(x / (|x| + 1e-5), -1, 1)  (train.py:535-538)"""
+    return _NormalHeadFn.apply(x, clamp, sign) if needs_grad(x) else ops.normal_head(x, clamp=clamp, sign=sign)
+
+
+class _SsiLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        B = pred.shape[0]
+        p = pred.reshape(B, -1).float().contiguous()
+        t = target.reshape(B, -1).float().contiguous()
+        m = mask.reshape(B, -1).to(torch.uint8).contiguous()
+        out, ss, ws = ops.ssi_loss_fwd_saved(p, t, m)
+        ctx.save_for_backward(p, t, m, ss, ws)
+        ctx.shape, ctx.dtype = pred.shape, pred.dtype
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, m, ss, ws = ctx.saved_tensors
+        dp = ops.ssi_loss_bwd(p, t, m, ss, ws, g)
+        return dp.view(ctx.shape).to(ctx.dtype), None, None
+
+
+def ssi_loss(pred, target, mask):
+    """ScaleAndShiftInvariantLoss (training/util/loss.py:13-47) with its gradient"""
+    return _SsiLossFn.apply(pred, target, mask) if needs_grad(pred) else ops.ssi_loss(pred, target, mask)
+
+
+class _AngularLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        B = pred.shape[0]
+        p = pred.reshape(B, 3, -1).float().contiguous()
+        t = target.reshape(B, 3, -1).float().contiguous()
+        m = mask[:, 0].reshape(B, -1).to(torch.uint8).contiguous()
+        out, ws = ops.angular_loss_fwd_saved(p, t, m)
+        ctx.save_for_backward(p, t, m, ws)
+        ctx.shape, ctx.dtype = pred.shape, pred.dtype
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, m, ws = ctx.saved_tensors
+        dp = ops.angular_loss_bwd(p, t, m, ws, g)
+        return dp.view(ctx.shape).to(ctx.dtype), None, None
+
+
+def angular_loss(pred, target, mask):
+    """AngularLoss (training/util/loss.py:51-67) with its gradient"""
+    return _AngularLossFn.apply(pred, target, mask) if needs_grad(pred) else ops.angular_loss(pred, target, mask)

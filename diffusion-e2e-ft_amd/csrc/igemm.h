@@ -16,6 +16,8 @@ struct IgemmParams {
     int ldx1, ldx2, c1, cin;
     int hin, win, hl, wl, kh, kw, stride, pad_t, pad_l, hout, wout;
     float up_sh, up_sw;
+    int zins;            // > 1: the source is read through a zero-insertion grid (dgrad of a strided conv): logical (y, x) is
+                         // source (y / zins, x / zins) when both are multiples of zins and zero otherwise
     int ldw, ldr, ldo;
     int bias_along_m;
     int rows_per_img;

@@ -119,10 +119,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-                const bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
+                bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
                 int sy = iy, sx = ix;
-                if (p.hl != p.hin) sy = min((int)floorf(iy * p.up_sh), p.hin - 1);
-                if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
+                if (p.zins > 1) {
+                    ok = ok && (iy % p.zins == 0) && (ix % p.zins == 0);
+                    sy = iy / p.zins; sx = ix / p.zins;
+                } else {
+                    if (p.hl != p.hin) sy = min((int)floorf(iy * p.up_sh), p.hin - 1);
+                    if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
+                }
                 const long pix = (a_base[i] * p.hin + sy) * p.win + sx;
                 ra[i] = ok ? *reinterpret_cast<const u32x4*>(src + pix * ld + cc) : zero4;
             }
@@ -290,6 +295,46 @@ extern "C" int e2eft_conv2d_fwd_gnstats(const E2eftConvDesc* d, const void* x1, 
     const int rc = run_igemm(d->dtype, plain ? 0 : 1, p, 1, stream);
     if (rc == 0 && slab_rows && p.gn_partial) *slab_rows = p.rows_per_img / p.gn_nslabs;
     return rc;
+}
+
+
+// Data gradient of the convolution `fwd` describes (forward: out = alpha*(conv(x) + ...) + residual):
+//   dx[b, i, j, ci] = alpha * sum_{ky,kx,co} dy_z[b, i + pad_t - ky, j + pad_l - kx, co] * w[co][ky][kx][ci]
+// i.e. a stride-1 convolution of dy (read through a zero-insertion grid when fwd->stride > 1) with the spatially flipped,
+// channel-transposed weights w_dgrad[ci][(kh-1-ky, kw-1-kx, co)] — the same implicit-GEMM kernel with K = kh*kw*cout.
+// dx is the gradient w.r.t. the LOGICAL input [B, hl, wl, c1+c2] (before the fused nearest upsample; reduce with
+// e2eft_upsample_nearest_bwd), both concat sources in one buffer.
+extern "C" int e2eft_conv2d_dgrad(const E2eftConvDesc* d, const void* dy, int32_t lddy, int32_t cout_pad, const void* w_dgrad, int32_t ldwd, void* dx,
+                                  int32_t lddx, void* stream) {
+    E2EFT_REQUIRE(d && dy && w_dgrad && dx, "conv2d_dgrad: null pointer");
+    E2EFT_REQUIRE(d->dtype >= 0 && d->dtype <= 2, "conv2d_dgrad: bad dtype %d", d->dtype);
+    const int epc = 16 / (int)dtype_size(d->dtype);
+    const int cin = d->c1 + d->c2;
+    E2EFT_REQUIRE(d->batch > 0 && d->hl > 0 && d->wl > 0 && d->hout > 0 && d->wout > 0 && d->cout > 0 && cin > 0, "conv2d_dgrad: bad geometry");
+    E2EFT_REQUIRE(cout_pad >= d->cout && cout_pad % epc == 0 && lddy >= cout_pad && lddy % epc == 0, "conv2d_dgrad: dy channels %d (ld %d) must be padded to %d", cout_pad, lddy, epc);
+    E2EFT_REQUIRE(ldwd >= d->kh * d->kw * cout_pad && ldwd % epc == 0, "conv2d_dgrad: ldwd=%d", ldwd);
+    E2EFT_REQUIRE(lddx >= cin, "conv2d_dgrad: lddx=%d < cin=%d", lddx, cin);
+    E2EFT_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad_t < d->kh && d->pad_l < d->kw, "conv2d_dgrad: kernel/stride/padding");
+    E2EFT_REQUIRE(al16(dy) && al16(w_dgrad), "conv2d_dgrad: pointers must be 16-byte aligned");
+    E2EFT_REQUIRE((long)d->batch * d->hl * d->wl < 2147483647L, "conv2d_dgrad: M overflows int32");
+    IgemmParams p = {};
+    p.x1 = dy; p.w = w_dgrad; p.out = dx;
+    p.M = d->batch * d->hl * d->wl;
+    p.N = cin;
+    p.K = d->kh * d->kw * cout_pad;
+    p.ldx1 = lddy; p.c1 = cout_pad; p.cin = cout_pad;
+    p.hin = d->hout; p.win = d->wout;
+    p.zins = d->stride;
+    p.hl = (d->hout - 1) * d->stride + 1; p.wl = (d->wout - 1) * d->stride + 1;
+    p.kh = d->kh; p.kw = d->kw; p.stride = 1; p.pad_t = d->kh - 1 - d->pad_t; p.pad_l = d->kw - 1 - d->pad_l;
+    p.hout = d->hl; p.wout = d->wl;
+    p.up_sh = p.up_sw = 1.f;
+    p.ldw = ldwd; p.ldo = lddx;
+    p.rows_per_img = d->hl * d->wl;
+    p.alpha = d->alpha;
+    p.nzi = 1;
+    const bool plain = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->hout == d->hl && d->wout == d->wl;
+    return run_igemm(d->dtype, plain ? 0 : 1, p, 1, stream);
 }
 
 extern "C" int e2eft_gemm(const E2eftGemmDesc* d, const void* a, const void* w, const void* bias,

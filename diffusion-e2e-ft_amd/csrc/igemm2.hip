@@ -214,10 +214,15 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
+                bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
                 int sy = iy, sx = ix;
-                if (p.hl != p.hin) sy = min((int)floorf(iy * p.up_sh), p.hin - 1);
-                if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
+                if (p.zins > 1) {
+                    ok = ok && (iy % p.zins == 0) && (ix % p.zins == 0);
+                    sy = iy / p.zins; sx = ix / p.zins;
+                } else {
+                    if (p.hl != p.hin) sy = min((int)floorf(iy * p.up_sh), p.hin - 1);
+                    if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
+                }
                 const unsigned pix = (unsigned)((brel[i] * p.hin + sy) * p.win + sx);
                 off1[i] = ok ? (pix * (unsigned)p.ldx1 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T) : OOB_SENTINEL;
                 off2[i] = ok ? (pix * (unsigned)p.ldx2 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T) : OOB_SENTINEL;
@@ -352,10 +357,15 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int iy = a_iy0[i] + ky_cur, ix = a_ix0[i] + kx_cur;
-                    const bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
+                    bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
                     int sy = iy, sx = ix;
-                    if (p.hl != p.hin) sy = min((int)floorf(iy * p.up_sh), p.hin - 1);
-                    if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
+                    if (p.zins > 1) {
+                        ok = ok && (iy % p.zins == 0) && (ix % p.zins == 0);
+                        sy = iy / p.zins; sx = ix / p.zins;
+                    } else {
+                        if (p.hl != p.hin) sy = min((int)floorf(iy * p.up_sh), p.hin - 1);
+                        if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
+                    }
                     const long pix = (a_base[i] * p.hin + sy) * p.win + sx;
                     const T* src = ok ? sbase + pix * ld + cc : zsrc;
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + i * (RSTEP * 128)), 16, 0, 0);

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnGeom g, const T* __re
 template <typename T>
 __global__ __launch_bounds__(256) void gn_finalize_kernel(int C, int c1, int groups, float eps, const float* __restrict__ pa,
                                                           int nsa, const float* __restrict__ pb, int nsb,
-                                                          const T* __restrict__ gamma, float* __restrict__ ad /* [B][C][2] */) {
+                                                          const T* __restrict__ gamma, float* __restrict__ ad /* [B][C][2] */,
+                                                          float* __restrict__ rstd_out /* [B][groups] */) {
     __shared__ float sm[256 * 3];
     const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int cpg = C / groups;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(int C, int c1, int gro
     const float mean = sm[1];
     const float var = sm[2] / sm[0];
     const float rstd = rsqrtf(var + eps);
+    if (tid == 0) rstd_out[(long)b * groups + grp] = rstd;   // kept for the backward pass
     for (int cc = tid; cc < cpg; cc += 256) {
         const int c = cbeg + cc;
         const float ga = gamma ? to_f(gamma[c]) : 1.f;
@@ -236,8 +238,9 @@ static int gn_run(const E2eftGroupNormDesc* d, const GnGeom& g, const void* x1, 
         pb = pa; nsb = 1;
     }
     float* ad = wsp;
+    float* rstd = ad + (size_t)d->batch * g.C * 2;
     hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(d->groups, g.batch), dim3(256), 0, s, g.C, d->c1, d->groups, d->eps, pa, nsa, pb, nsb,
-                       (const T*)gamma, ad);
+                       (const T*)gamma, ad, rstd);
     hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(g.nslabs, g.batch, g.nchb), dim3(256), 0, s, g, d->silu, d->ldy, (const T*)x1, (const T*)x2, ad, (const T*)beta, (T*)y);
     return check_launch("groupnorm");
 }
@@ -250,8 +253,201 @@ static size_t gn_ws_bytes(const E2eftGroupNormDesc* d) {
         gn_geom_one(d->dtype, d->batch, d->hw, d->c2, d->ldx2, g2);
         f += (size_t)d->batch * g2.nslabs * d->c2 * 3;
     }
-    f += (size_t)d->batch * (d->c1 + d->c2) * 2;
+    f += (size_t)d->batch * (d->c1 + d->c2) * 2 + (size_t)d->batch * d->groups;   // (a, mean) pairs, then rstd per (image, group)
     return f * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm(+SiLU) backward.  With z = xhat*gamma + beta, dz = dy * act'(z):
+//   S1[b,c] = sum_p dz, S2[b,c] = sum_p dz*xhat;  dgamma = sum_b S2, dbeta = sum_b S1;
+//   m1[b,g] = sum_{c in g} gamma_c S1 / n, m2 likewise with S2;  dx = rstd * (dz*gamma - m1 - xhat*m2).
+// Same streaming geometry as the forward (thread <-> 16-byte channel chunk, pixel lanes), the forward's (a, mean, rstd) are reused.
+template <typename T, int EPC>
+struct GnBwdCoef {
+    float a[EPC], mu[EPC], rs[EPC], be[EPC];
+};
+template <typename T, int EPC>
+__device__ __forceinline__ void gn_bwd_load(GnBwdCoef<T, EPC>& k, int b, int c, int C, int groups, const float* __restrict__ ad,
+                                            const float* __restrict__ rstd, const T* __restrict__ beta) {
+    const int cpg = C / groups;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        k.a[e] = ad[((long)b * C + c + e) * 2];
+        k.mu[e] = ad[((long)b * C + c + e) * 2 + 1];
+        k.rs[e] = rstd[(long)b * groups + (c + e) / cpg];
+        k.be[e] = beta ? to_f(beta[c + e]) : 0.f;
+    }
+}
+__device__ __forceinline__ float silu_grad_f(float z) {
+    const float sg = 1.f / (1.f + __expf(-z));
+    return sg * (1.f + z * (1.f - sg));
+}
+
+// grid (nslabs, batch, nchb): per-(image, slab, channel) sums S1, S2
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnGeom g, int groups, int silu, int lddy, const T* __restrict__ x1,
+                                                             const T* __restrict__ x2, const T* __restrict__ dy,
+                                                             const float* __restrict__ ad, const float* __restrict__ rstd,
+                                                             const T* __restrict__ beta, float* __restrict__ part /* [B][nslabs][C][2] */) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    __shared__ float sm[256 * 8 * 2];
+    const int tid = threadIdx.x;
+    const int chl = tid % g.cpb, pl = tid / g.cpb;
+    const int ch = blockIdx.z * g.cpb + chl;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * g.slab;
+    const int p1 = min(p0 + g.slab, g.hw);
+    const bool active = pl < g.pl;
+    const int c = ch * EPC;
+    const T* src;
+    int ld;
+    if (c < g.c1) { src = x1 + c; ld = g.ldx1; } else { src = x2 + (c - g.c1); ld = g.ldx2; }
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+    if (active) {
+        GnBwdCoef<T, EPC> k;
+        gn_bwd_load<T, EPC>(k, b, c, g.C, groups, ad, rstd, beta);
+        for (int pix = p0 + pl; pix < p1; pix += g.pl) {
+            const long row = (long)b * g.hw + pix;
+            Vec16<T> v = ld16(src + row * ld), d = ld16(dy + row * lddy + c);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float xc = to_f(v.e[e]) - k.mu[e];
+                float dz = to_f(d.e[e]);
+                if (silu) dz *= silu_grad_f(fmaf(xc, k.a[e], k.be[e]));
+                s1[e] += dz;
+                s2[e] += dz * xc * k.rs[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float* o = sm + ((pl * g.cpb + chl) * EPC + e) * 2;
+            o[0] = s1[e]; o[1] = s2[e];
+        }
+    }
+    __syncthreads();
+    const int cblk = g.cpb * EPC;
+    for (int cc = tid; cc < cblk; cc += 256) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int q = 0; q < g.pl; ++q) { a1 += sm[(q * cblk + cc) * 2]; a2 += sm[(q * cblk + cc) * 2 + 1]; }
+        float* o = part + (((long)b * g.nslabs + blockIdx.x) * g.C + blockIdx.z * cblk + cc) * 2;
+        o[0] = a1; o[1] = a2;
+    }
+}
+
+// grid (groups, batch): slab sums -> sc[b][c] = (S1, S2); mm[b][g] = (m1, m2)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(int C, int groups, int hw, int nslabs, const float* __restrict__ part,
+                                                              const T* __restrict__ gamma, float* __restrict__ sc, float* __restrict__ mm) {
+    __shared__ float red[2][4];
+    const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / groups;
+    float m1 = 0.f, m2 = 0.f;
+    for (int cc = tid; cc < cpg; cc += 256) {
+        const int c = grp * cpg + cc;
+        float a1 = 0.f, a2 = 0.f;
+        for (int sl = 0; sl < nslabs; ++sl) {
+            const float* o = part + (((long)b * nslabs + sl) * C + c) * 2;
+            a1 += o[0]; a2 += o[1];
+        }
+        sc[((long)b * C + c) * 2] = a1;
+        sc[((long)b * C + c) * 2 + 1] = a2;
+        const float ga = gamma ? to_f(gamma[c]) : 1.f;
+        m1 += ga * a1; m2 += ga * a2;
+    }
+    m1 = wave_sum(m1); m2 = wave_sum(m2);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = m1; red[1][tid >> 6] = m2; }
+    __syncthreads();
+    if (tid == 0) {
+        const float n = (float)cpg * (float)hw;
+        mm[((long)b * groups + grp) * 2] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / n;
+        mm[((long)b * groups + grp) * 2 + 1] = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / n;
+    }
+}
+
+// grid (nslabs, batch, nchb)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnGeom g, int groups, int silu, int lddy, int lddx, const T* __restrict__ x1,
+                                                           const T* __restrict__ x2, const T* __restrict__ dy, const float* __restrict__ ad,
+                                                           const float* __restrict__ rstd, const float* __restrict__ mm,
+                                                           const T* __restrict__ gamma, const T* __restrict__ beta, T* __restrict__ dx) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int tid = threadIdx.x;
+    const int chl = tid % g.cpb, pl = tid / g.cpb;
+    if (pl >= g.pl) return;
+    const int ch = blockIdx.z * g.cpb + chl;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * g.slab;
+    const int p1 = min(p0 + g.slab, g.hw);
+    const int c = ch * EPC;
+    const T* src;
+    int ld;
+    if (c < g.c1) { src = x1 + c; ld = g.ldx1; } else { src = x2 + (c - g.c1); ld = g.ldx2; }
+    GnBwdCoef<T, EPC> k;
+    gn_bwd_load<T, EPC>(k, b, c, g.C, groups, ad, rstd, beta);
+    const int cpg = g.C / groups;
+    float k1[EPC], k2[EPC], k3[EPC];   // dx = k1*dz - k2 - (x - mean)*k3
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int grp = (c + e) / cpg;
+        const float ga = gamma ? to_f(gamma[c + e]) : 1.f;
+        k1[e] = k.rs[e] * ga;
+        k2[e] = k.rs[e] * mm[((long)b * groups + grp) * 2];
+        k3[e] = k.rs[e] * k.rs[e] * mm[((long)b * groups + grp) * 2 + 1];
+    }
+    for (int pix = p0 + pl; pix < p1; pix += g.pl) {
+        const long row = (long)b * g.hw + pix;
+        Vec16<T> v = ld16(src + row * ld), d = ld16(dy + row * lddy + c), o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float xc = to_f(v.e[e]) - k.mu[e];
+            float dz = to_f(d.e[e]);
+            if (silu) dz *= silu_grad_f(fmaf(xc, k.a[e], k.be[e]));
+            o.e[e] = from_f<T>(k1[e] * dz - k2[e] - xc * k3[e]);
+        }
+        st16(dx + row * lddx + c, o);
+    }
+}
+
+// dgamma[c] = sum_b S2[b][c], dbeta[c] = sum_b S1[b][c]
+__global__ __launch_bounds__(256) void gn_bwd_params_kernel(int batch, int C, const float* __restrict__ sc, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a1 = 0.f, a2 = 0.f;
+    for (int b = 0; b < batch; ++b) { a1 += sc[((long)b * C + c) * 2]; a2 += sc[((long)b * C + c) * 2 + 1]; }
+    if (dbeta) dbeta[c] = a1;
+    if (dgamma) dgamma[c] = a2;
+}
+
+static size_t gn_bwd_ws_bytes(const E2eftGroupNormDesc* d) {
+    GnGeom g;
+    gn_geom(d, g);
+    const size_t C = d->c1 + d->c2;
+    return ((size_t)d->batch * g.nslabs * C * 2 + (size_t)d->batch * C * 2 + (size_t)d->batch * d->groups * 2) * sizeof(float);
+}
+
+template <typename T>
+static int gn_bwd_run(const E2eftGroupNormDesc* d, const GnGeom& g, const void* x1, const void* x2, const void* gamma, const void* beta,
+                      const void* dy, int lddy, void* dx, int lddx, float* dgamma, float* dbeta, const float* fwd_ws, void* ws,
+                      hipStream_t s) {
+    const float* ad = fwd_ws + (gn_ws_bytes(d) / sizeof(float) - (size_t)d->batch * g.C * 2 - (size_t)d->batch * d->groups);
+    const float* rstd = ad + (size_t)d->batch * g.C * 2;
+    float* part = (float*)ws;
+    float* sc = part + (size_t)d->batch * g.nslabs * g.C * 2;
+    float* mm = sc + (size_t)d->batch * g.C * 2;
+    const dim3 grid(g.nslabs, g.batch, g.nchb);
+    hipLaunchKernelGGL((gn_bwd_partial_kernel<T>), grid, dim3(256), 0, s, g, d->groups, d->silu, lddy, (const T*)x1, (const T*)x2,
+                       (const T*)dy, ad, rstd, (const T*)beta, part);
+    hipLaunchKernelGGL((gn_bwd_finalize_kernel<T>), dim3(d->groups, g.batch), dim3(256), 0, s, g.C, d->groups, d->hw, g.nslabs, part,
+                       (const T*)gamma, sc, mm);
+    if (dx)
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), grid, dim3(256), 0, s, g, d->groups, d->silu, lddy, lddx, (const T*)x1, (const T*)x2,
+                           (const T*)dy, ad, rstd, mm, (const T*)gamma, (const T*)beta, (T*)dx);
+    if (dgamma || dbeta)
+        hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(cdiv(g.C, 256)), dim3(256), 0, s, g.batch, g.C, sc, dgamma, dbeta);
+    return check_launch("groupnorm_bwd");
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -363,6 +559,152 @@ __global__ __launch_bounds__(256) void geglu_kernel(long rows, int c, int ldh, i
     }
 }
 
+
+// LayerNorm backward: one wave per row (row + dy in registers); per-wave register accumulators of dgamma / dbeta over the rows
+// the wave visits, written as one partial row per wave ([2][c] fp32) and reduced by the column-sum kernel afterwards.
+//   dxhat = dy*gamma;  dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat))
+template <typename T, int MAXI>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(long rows, int c, int ldx, int lddy, int lddx, float eps, const T* __restrict__ x,
+                                                            const T* __restrict__ gamma, const T* __restrict__ dy, T* __restrict__ dx,
+                                                            float* __restrict__ part /* [gridDim.x*4][2][c] */) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = c / EPC;
+    float dg[MAXI][EPC], db[MAXI][EPC];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) dg[i][e] = db[i][e] = 0.f;
+    const float invc = 1.f / (float)c;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        float v[MAXI][EPC], d[MAXI][EPC];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nchunks) {
+                Vec16<T> t = ld16(x + row * ldx + ch * EPC), u = ld16(dy + row * lddy + ch * EPC);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { v[i][e] = to_f(t.e[e]); d[i][e] = to_f(u.e[e]); sum += v[i][e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[i][e] = d[i][e] = 0.f;
+            }
+        }
+        const float mean = wave_sum(sum) * invc;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+            if (lane + 64 * i < nchunks) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { const float dd = v[i][e] - mean; sq += dd * dd; }
+            }
+        const float rstd = rsqrtf(wave_sum(sq) * invc + eps);
+        float a = 0.f, bsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nchunks) {
+                Vec16<T> ga = ld16(gamma + ch * EPC);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float xh = (v[i][e] - mean) * rstd;
+                    v[i][e] = xh;
+                    dg[i][e] += d[i][e] * xh;
+                    db[i][e] += d[i][e];
+                    d[i][e] *= to_f(ga.e[e]);   // dxhat
+                    a += d[i][e];
+                    bsum += d[i][e] * xh;
+                }
+            }
+        }
+        a = wave_sum(a) * invc;
+        bsum = wave_sum(bsum) * invc;
+        if (dx) {
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nchunks) {
+                    Vec16<T> o;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(rstd * (d[i][e] - a - v[i][e] * bsum));
+                    st16(dx + row * lddx + ch * EPC, o);
+                }
+            }
+        }
+    }
+    float* o = part + ((long)blockIdx.x * 4 + wave) * 2 * c;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nchunks) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { o[ch * EPC + e] = dg[i][e]; o[c + ch * EPC + e] = db[i][e]; }
+        }
+    }
+}
+
+// out[j] = sum_r part[r][j] (fp32), grid over 256-column blocks
+__global__ __launch_bounds__(256) void rowsum_f32_kernel(int rows, int n, const float* __restrict__ part, float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    float a = 0.f;
+    for (int r = 0; r < rows; ++r) a += part[(long)r * n + j];
+    out[j] = a;
+}
+
+// softmax backward in place on dp: ds = p * (dp - sum_j dp_j p_j) * scale   (rows of n valid columns, pad columns zeroed)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(int n, long lds, float scale, const T* __restrict__ pbuf, T* __restrict__ dpbuf) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    __shared__ float red[4];
+    const T* prow = pbuf + (long)blockIdx.x * lds;
+    T* drow = dpbuf + (long)blockIdx.x * lds;
+    const int tid = threadIdx.x;
+    const int npad = (n + EPC - 1) / EPC * EPC;   // forward zeroes p in the pad columns, so they contribute nothing
+    float dot = 0.f;
+    for (int ch = tid; ch < npad / EPC; ch += 256) {
+        Vec16<T> pv = ld16(prow + ch * EPC), dv = ld16(drow + ch * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) dot += (ch * EPC + e < n) ? to_f(pv.e[e]) * to_f(dv.e[e]) : 0.f;
+    }
+    dot = wave_sum(dot);
+    if ((tid & 63) == 0) red[tid >> 6] = dot;
+    __syncthreads();
+    dot = red[0] + red[1] + red[2] + red[3];
+    for (int ch = tid; ch < npad / EPC; ch += 256) {
+        Vec16<T> pv = ld16(prow + ch * EPC), dv = ld16(drow + ch * EPC), o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+            o.e[e] = from_f<T>((ch * EPC + e < n) ? to_f(pv.e[e]) * (to_f(dv.e[e]) - dot) * scale : 0.f);
+        st16(drow + ch * EPC, o);
+    }
+}
+
+// GEGLU backward: dh[:, :c] = dy * gelu(gate), dh[:, c:] = dy * value * gelu'(gate)
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(long rows, int c, int ldh, int lddy, int lddh, const T* __restrict__ hbuf,
+                                                        const T* __restrict__ dy, T* __restrict__ dh) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int cch = c / EPC;
+    const long total = rows * cch;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const long r = it / cch;
+        const int ch = (int)(it - r * cch);
+        Vec16<T> a = ld16(hbuf + r * ldh + ch * EPC), gt = ld16(hbuf + r * ldh + c + ch * EPC), d = ld16(dy + r * lddy + ch * EPC), oa, og;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float g = to_f(gt.e[e]), dd = to_f(d.e[e]);
+            const float cdf = 0.5f * (1.0f + erff(g * 0.70710678118654752440f));
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * g * g);
+            oa.e[e] = from_f<T>(dd * g * cdf);
+            og.e[e] = from_f<T>(dd * to_f(a.e[e]) * (cdf + g * pdf));
+        }
+        st16(dh + r * lddh + ch * EPC, oa);
+        st16(dh + r * lddh + c + ch * EPC, og);
+    }
+}
+
 }  // namespace e2eft
 
 using namespace e2eft;
@@ -452,4 +794,92 @@ extern "C" int e2eft_geglu_fwd(int32_t dtype, int64_t rows, int32_t c, int32_t l
     hipStream_t s = (hipStream_t)stream;
     E2EFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((geglu_kernel<T>), dim3((unsigned)nb), dim3(256), 0, s, (long)rows, c, ldh, ldy, (const T*)h, (T*)y));
     return check_launch("geglu");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward entry points
+extern "C" size_t e2eft_groupnorm_bwd_workspace_bytes(const E2eftGroupNormDesc* d) {
+    if (gn_validate(d)) return 0;
+    return gn_bwd_ws_bytes(d);
+}
+
+extern "C" int e2eft_groupnorm_bwd(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma, const void* beta,
+                                   const void* dy, int32_t lddy, void* dx, int32_t lddx, float* dgamma, float* dbeta,
+                                   const void* fwd_workspace, void* workspace, size_t ws_bytes, void* stream) {
+    if (int e = gn_validate(d)) return e;
+    E2EFT_REQUIRE(x1 && dy && fwd_workspace && workspace, "groupnorm_bwd: null pointer");
+    E2EFT_REQUIRE(d->c2 == 0 || x2, "groupnorm_bwd: x2 missing");
+    const int epc = 16 / (int)dtype_size(d->dtype);
+    const int C = d->c1 + d->c2;
+    E2EFT_REQUIRE(lddy >= C && lddy % epc == 0 && (!dx || (lddx >= C && lddx % epc == 0)), "groupnorm_bwd: strides");
+    GnGeom g;
+    gn_geom(d, g);
+    const size_t need = gn_bwd_ws_bytes(d);
+    if (ws_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "groupnorm_bwd: workspace %zu < %zu", ws_bytes, need);
+    E2EFT_REQUIRE(g.batch <= 65535 && g.nchb <= 65535, "groupnorm_bwd: grid");
+    E2EFT_DISPATCH_DTYPE(d->dtype, T, return gn_bwd_run<T>(d, g, x1, x2, gamma, beta, dy, lddy, dx, lddx, dgamma, dbeta,
+                                                          (const float*)fwd_workspace, workspace, (hipStream_t)stream));
+    return 0;
+}
+
+static int ln_bwd_blocks(int64_t rows) {
+    long nb = (rows + 3) / 4;
+    return (int)(nb > 512 ? 512 : nb);
+}
+
+extern "C" size_t e2eft_layernorm_bwd_workspace_bytes(int64_t rows, int32_t c) {
+    return rows > 0 && c > 0 ? (size_t)ln_bwd_blocks(rows) * 4 * 2 * (size_t)c * sizeof(float) : 0;
+}
+
+extern "C" int e2eft_layernorm_bwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldx, int32_t lddy, int32_t lddx, float eps,
+                                   const void* x, const void* gamma, const void* dy, void* dx, float* dgamma_dbeta /* [2][c] */,
+                                   void* workspace, size_t ws_bytes, void* stream) {
+    E2EFT_REQUIRE(x && gamma && dy && dgamma_dbeta && workspace, "layernorm_bwd: null pointer");
+    E2EFT_REQUIRE(dtype >= 0 && dtype <= 2, "layernorm_bwd: bad dtype");
+    const int epc = 16 / (int)dtype_size(dtype);
+    E2EFT_REQUIRE(rows > 0 && c > 0 && c % epc == 0 && ldx >= c && lddy >= c && ldx % epc == 0 && lddy % epc == 0 &&
+                      (!dx || (lddx >= c && lddx % epc == 0)), "layernorm_bwd: shape c=%d", c);
+    const int nchunks = c / epc;
+    E2EFT_REQUIRE(nchunks <= 64 * 8, "layernorm_bwd: c=%d too large", c);
+    const size_t need = e2eft_layernorm_bwd_workspace_bytes(rows, c);
+    if (ws_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "layernorm_bwd: workspace %zu < %zu", ws_bytes, need);
+    const int nblk = ln_bwd_blocks(rows);
+    hipStream_t s = (hipStream_t)stream;
+    const int iters = (nchunks + 63) / 64;
+#define LNB_LAUNCH(T, MAXI) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MAXI>), dim3((unsigned)nblk), dim3(256), 0, s, (long)rows, c, ldx, lddy, lddx, eps, (const T*)x, (const T*)gamma, (const T*)dy, (T*)dx, (float*)workspace)
+    E2EFT_DISPATCH_DTYPE(dtype, T, {
+        if (iters <= 1) LNB_LAUNCH(T, 1);
+        else if (iters <= 2) LNB_LAUNCH(T, 2);
+        else if (iters <= 4) LNB_LAUNCH(T, 4);
+        else LNB_LAUNCH(T, 8);
+    });
+#undef LNB_LAUNCH
+    hipLaunchKernelGGL(rowsum_f32_kernel, dim3(cdiv(2 * c, 256)), dim3(256), 0, s, nblk * 4, 2 * c, (const float*)workspace, dgamma_dbeta);
+    return check_launch("layernorm_bwd");
+}
+
+extern "C" int e2eft_softmax_bwd_rows(int32_t dtype, int64_t rows, int32_t n, int64_t lds, float scale, const void* p, void* dp, void* stream) {
+    E2EFT_REQUIRE(p && dp, "softmax_bwd: null pointer");
+    E2EFT_REQUIRE(dtype >= 0 && dtype <= 2, "softmax_bwd: bad dtype");
+    const int epc = 16 / (int)dtype_size(dtype);
+    E2EFT_REQUIRE(rows > 0 && rows < 2147483647L && n > 0 && lds >= (n + epc - 1) / epc * epc && lds % epc == 0, "softmax_bwd: shape n=%d lds=%ld", n, (long)lds);
+    hipStream_t s = (hipStream_t)stream;
+    E2EFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((softmax_bwd_rows_kernel<T>), dim3((unsigned)rows), dim3(256), 0, s, n, (long)lds, scale, (const T*)p, (T*)dp));
+    return check_launch("softmax_bwd_rows");
+}
+
+extern "C" int e2eft_geglu_bwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldh, int32_t lddy, int32_t lddh, const void* h, const void* dy,
+                               void* dh, void* stream) {
+    E2EFT_REQUIRE(h && dy && dh, "geglu_bwd: null pointer");
+    E2EFT_REQUIRE(dtype >= 0 && dtype <= 2, "geglu_bwd: bad dtype");
+    const int epc = 16 / (int)dtype_size(dtype);
+    E2EFT_REQUIRE(rows > 0 && c > 0 && c % epc == 0 && ldh >= 2 * c && ldh % epc == 0 && lddy >= c && lddy % epc == 0 && lddh >= 2 * c && lddh % epc == 0,
+                  "geglu_bwd: shape");
+    const long total = rows * (c / epc);
+    long nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    E2EFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((geglu_bwd_kernel<T>), dim3((unsigned)nb), dim3(256), 0, s, (long)rows, c, ldh, lddy, lddh,
+                                                      (const T*)h, (const T*)dy, (T*)dh));
+    return check_launch("geglu_bwd");
 }

@@ -10,62 +10,26 @@ import torch
 from torch import nn
 
 from . import ops
+from . import autograd as F
 
 
 # ------------------------------------------------------------------------------------------------------------
-# derived-tensor cache (packed conv weights, fused QKV matrices): rebuilt whenever a source parameter changes
-def _key(*params):
-    return tuple((p._version, p.data_ptr(), p.dtype, str(p.device)) for p in params)
-
-
-def _cached(module, name, params, builder):
-    cache = module.__dict__.setdefault("_e2eft_cache", {})
-    k = _key(*params)
-    hit = cache.get(name)
-    if hit is None or hit[0] != k:
-        with torch.no_grad():
-            hit = (k, builder())
-        cache[name] = hit
-    return hit[1]
+# derived tensors (packed conv weights, fused QKV matrices, casts, transposes) are cached per parameter version in autograd.py
+_cached = F.cached
 
 
 def packed_conv_weight(conv):
     """[Co,Ci,kh,kw] -> OHWI rows [Co, kh*kw*Ci_pad] (Ci padded with zeros to a 16-byte multiple)."""
-    w = conv.weight
-
-    def build():
-        Co, Ci, kh, kw = w.shape
-        e = ops.epc(w.dtype)
-        cp = ops.round_up(Ci, e)
-        t = w.detach().permute(0, 2, 3, 1)
-        if cp != Ci:
-            t = torch.nn.functional.pad(t, (0, cp - Ci))
-        return t.reshape(Co, kh * kw * cp).contiguous()
-
-    return _cached(conv, "packed", (w,), build)
+    return F.packed_conv_weight(conv, conv.weight.dtype)
 
 
 def conv_nhwc(conv, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0, pad=None, out=None, gn_stats=True):
     """Run any nn.Conv2d-shaped module (weight/bias/stride/padding) on NHWC input through the implicit-GEMM kernel.
-    Works for plain torch.nn.Conv2d objects too (training/util/unet_prep.py:6-20 swaps conv_in for one)."""
-    _no_grad_guard(conv.weight, x)
-    kh, kw = conv.weight.shape[2:]
-    stride = conv.stride[0] if isinstance(conv.stride, tuple) else conv.stride
-    if pad is None:
-        p = conv.padding[0] if isinstance(conv.padding, tuple) else conv.padding
-        pad = (p, p, p, p)
-    if x2 is None:
-        x = ops.pad_channels(x)
+    Works for plain torch.nn.Conv2d objects too (training/util/unet_prep.py:6-20 swaps conv_in for one).  Differentiable:
+    under autograd the backward runs e2eft_conv2d_dgrad / the wgrad GEMM (autograd.py)."""
+    assert out is None
     # gn_stats: nearly every conv output of the path is consumed by a GroupNorm next; the epilogue then emits its statistics
-    return ops.conv2d(x, packed_conv_weight(conv), conv.bias, conv.weight.shape[0], kh, kw, stride, pad, x2=x2, up_to=up_to,
-                      rowadd=rowadd, residual=residual, alpha=alpha, out=out, gn_stats=gn_stats)
-
-
-def _no_grad_guard(*tensors):
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError(
-            "libe2eft round 1 implements the forward (inference) path only; run under torch.no_grad(). "
-            "The E2E-FT backward kernels are not built yet (DESIGN.md, 'next').")
+    return F.conv(conv, x, x2=x2, up_to=up_to, rowadd=rowadd, residual=residual, alpha=alpha, pad=pad, gn_stats=gn_stats)
 
 
 def to_nhwc(x):
@@ -79,7 +43,7 @@ def to_nhwc(x):
         dense = False
     if dense:
         return v
-    return ops.nchw_to_nhwc(x.contiguous(), cpad=x.shape[1])
+    return F.nchw_to_nhwc(x, cpad=x.shape[1])
 
 
 def to_nchw_view(y):
@@ -94,21 +58,14 @@ class Conv2d(nn.Conv2d):
 
 
 class Linear(nn.Linear):
-    def forward(self, x):
-        _no_grad_guard(self.weight, x)
-        K = self.in_features
-        e = ops.epc(self.weight.dtype)
-        if K % e != 0:  # e.g. GeoWizard's 10-dim class-embedding input: zero-pad K to a 16-byte multiple
-            kp = ops.round_up(K, e)
-            w = _cached(self, "wpad", (self.weight,), lambda: torch.nn.functional.pad(self.weight.detach(), (0, kp - K)).contiguous())
-            return ops.linear(torch.nn.functional.pad(x, (0, kp - K)), w, self.bias)
-        return ops.linear(x, self.weight, self.bias)
+    def forward(self, x, residual=None, gn_rows_per_image=0):
+        # K that is not a 16-byte multiple (GeoWizard's 10-dim class-embedding input) is zero padded inside F.linear
+        return F.linear(x, self.weight, self.bias, residual=residual, owner=self, gn_rows_per_image=gn_rows_per_image)
 
 
 class GroupNorm(nn.GroupNorm):
     def nhwc(self, x, x2=None, silu=False):
-        _no_grad_guard(self.weight, x)
-        return ops.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2)
+        return F.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2)
 
     def forward(self, x):
         return to_nchw_view(self.nhwc(to_nhwc(x)))
@@ -116,8 +73,7 @@ class GroupNorm(nn.GroupNorm):
 
 class LayerNorm(nn.LayerNorm):
     def forward(self, x):
-        _no_grad_guard(self.weight, x)
-        return ops.layernorm(x, self.weight, self.bias, self.eps)
+        return F.layernorm(x, self.weight, self.bias, self.eps)
 
 
 class TimestepEmbedding(nn.Module):
@@ -129,7 +85,7 @@ class TimestepEmbedding(nn.Module):
         self.linear_2 = Linear(dim, dim)
 
     def forward(self, x):
-        return self.linear_2(ops.silu(self.linear_1(x)))
+        return self.linear_2(F.silu(self.linear_1(x)))
 
 
 class ResnetBlock2D(nn.Module):
@@ -161,7 +117,7 @@ class ResnetBlock2D(nn.Module):
         return conv_nhwc(self.conv2, h, residual=sc)
 
     def forward(self, x, temb=None):
-        return to_nchw_view(self.nhwc(to_nhwc(x), None if temb is None else ops.silu(temb)))
+        return to_nchw_view(self.nhwc(to_nhwc(x), None if temb is None else F.silu(temb)))
 
 
 class Downsample2D(nn.Module):
@@ -239,34 +195,48 @@ class Attention(nn.Module):
         self.to_v = Linear(kv, query_dim, bias=bias)
         self.to_out = nn.ModuleList([Linear(query_dim, query_dim), nn.Dropout(0.0)])
 
-    def _qkv(self):
-        ps = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
-        return _cached(self, "wqkv", ps, lambda: torch.cat([p.detach() for p in ps], dim=0).contiguous())
-
-    def _kv(self):
-        ps = (self.to_k.weight, self.to_v.weight)
-        return _cached(self, "wkv", ps, lambda: torch.cat([p.detach() for p in ps], dim=0).contiguous())
-
     def forward(self, x, ctx=None, residual=None):
         """x [B,N,C] (already normalised), ctx [B,L,X] or None; returns to_out(attn) + residual."""
-        _no_grad_guard(self.to_q.weight, x)
         B, N, C = x.shape
         d = C // self.heads
+        out = self.to_out[0]
+        if F.needs_grad(x, ctx, self.to_q.weight, self.to_k.weight, self.to_v.weight, out.weight):
+            return out(self._forward_train(x, ctx), residual=residual)
         fused = x.dtype != torch.float32 and d == 64
+        dt = x.dtype
         if fused:
             if ctx is None:
-                qkv = ops.linear(x, self._qkv())
+                qkv = F.linear(x, (self.to_q.weight, self.to_k.weight, self.to_v.weight), owner=self, name="wqkv")
                 q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
             else:
-                q = ops.linear(x, self.to_q.weight)
-                kv = ops.linear(ctx, self._kv())
+                q = self.to_q(x)
+                kv = F.linear(ctx, (self.to_k.weight, self.to_v.weight), owner=self, name="wkv")
                 k, v = kv[..., :C], kv[..., C:]
             a = ops.attention(q, k, v, self.heads, self.scale, kv_nseg=2 if self.joint else 1, kv_bmod=B // 2 if self.joint else B)
         else:
             src = x if ctx is None else ctx
-            a = attention_unfused(x, src, self.to_q.weight, self.to_q.bias, self.to_k.weight, self.to_k.bias, self.to_v.weight,
-                                  self.to_v.bias, self.heads, self.scale, joint=self.joint)
-        return ops.linear(a, self.to_out[0].weight, self.to_out[0].bias, residual=residual)
+            cw = lambda lin: F._cat_weight(lin, "w", (lin.weight,), dt, lin.weight.shape[1])
+            a = attention_unfused(x, src, cw(self.to_q), F._vec(self.to_q.bias, dt), cw(self.to_k), F._vec(self.to_k.bias, dt), cw(self.to_v),
+                                  F._vec(self.to_v.bias, dt), self.heads, self.scale, joint=self.joint)
+        return out(a, residual=residual)
+
+    def _forward_train(self, x, ctx):
+        """differentiable path: fused projections -> attention core (autograd.py _AttentionFn)"""
+        B, N, C = x.shape
+        if ctx is None:
+            bias = None if self.to_q.bias is None else torch.cat([self.to_q.bias, self.to_k.bias, self.to_v.bias])
+            qkv = F.linear(x, (self.to_q.weight, self.to_k.weight, self.to_v.weight), bias, owner=self, name="wqkv")
+            if self.joint:
+                # GeoWizard cross-domain self-attention (attention.py:482-491): keys / values of both domains side by side
+                Bv = B // 2
+                q, kv = qkv[..., :C], qkv[..., C:]
+                kv = torch.cat([kv[:Bv], kv[Bv:]], dim=1).repeat(2, 1, 1)
+                return F.attention(q.contiguous(), kv, self.heads, self.scale)
+            return F.attention(qkv, None, self.heads, self.scale)
+        q = self.to_q(x)
+        bias = None if self.to_k.bias is None else torch.cat([self.to_k.bias, self.to_v.bias])
+        kv = F.linear(ctx, (self.to_k.weight, self.to_v.weight), bias, owner=self, name="wkv")
+        return F.attention(q, kv, self.heads, self.scale)
 
 
 class GEGLU(nn.Module):
@@ -277,7 +247,7 @@ class GEGLU(nn.Module):
         self.proj = Linear(dim, 2 * inner)
 
     def forward(self, x):
-        return ops.geglu(self.proj(x))
+        return F.geglu(self.proj(x))
 
 
 class FeedForward(nn.Module):
@@ -288,8 +258,7 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, 4 * dim), nn.Dropout(0.0), Linear(4 * dim, dim)])
 
     def forward(self, x, residual=None):
-        h = self.net[0](x)
-        return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=residual)
+        return self.net[2](self.net[0](x), residual=residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -328,7 +297,7 @@ class Transformer2DModel(nn.Module):
         h = self.proj_in(h)
         for blk in self.transformer_blocks:
             h = blk(h, ctx)
-        out = ops.linear(h, self.proj_out.weight, self.proj_out.bias, residual=x, gn_rows_per_image=H * W)
+        out = self.proj_out(h, residual=x.reshape(B, H * W, C), gn_rows_per_image=H * W)
         res = out.view(B, H, W, C)
         st = getattr(out, "_e2eft_gn", None)
         if st is not None:
@@ -349,14 +318,20 @@ class VaeAttention(nn.Module):
         self.to_out = nn.ModuleList([Linear(channels, channels), nn.Dropout(0.0)])
 
     def nhwc(self, x):
-        _no_grad_guard(self.to_q.weight, x)
         B, H, W, C = x.shape
         n = self.group_norm.nhwc(x).view(B, H * W, C)
-        a = attention_unfused(n, n, self.to_q.weight, self.to_q.bias, self.to_k.weight, self.to_k.bias, self.to_v.weight,
-                              self.to_v.bias, 1, C ** -0.5)
-        out = ops.linear(a, self.to_out[0].weight, self.to_out[0].bias, residual=x, gn_rows_per_image=H * W)
-        res = out.view(B, H, W, C)
-        st = getattr(out, "_e2eft_gn", None)
+        out = self.to_out[0]
+        if F.needs_grad(x, self.to_q.weight):
+            bias = torch.cat([self.to_q.bias, self.to_k.bias, self.to_v.bias])
+            qkv = F.linear(n, (self.to_q.weight, self.to_k.weight, self.to_v.weight), bias, owner=self, name="wqkv")
+            a = F.attention(qkv, None, 1, C ** -0.5)
+            return out(a, residual=x.reshape(B, H * W, C)).view(B, H, W, C)
+        dt = x.dtype
+        a = attention_unfused(n, n, self.to_q.weight, F._vec(self.to_q.bias, dt), self.to_k.weight, F._vec(self.to_k.bias, dt), self.to_v.weight,
+                              F._vec(self.to_v.bias, dt), 1, C ** -0.5)
+        o = out(a, residual=x.reshape(B, H * W, C), gn_rows_per_image=H * W)
+        res = o.view(B, H, W, C)
+        st = getattr(o, "_e2eft_gn", None)
         if st is not None:
             res._e2eft_gn = st
         return res

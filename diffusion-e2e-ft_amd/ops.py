@@ -497,3 +497,281 @@ def angular_loss(pred, target, mask):
     out = torch.empty(1, dtype=torch.float32, device=p.device)
     check(lib.e2eft_angular_loss_fwd(B, p.shape[2], _ptr(p), _ptr(t), _ptr(m), _ptr(out), _ptr(ws), nbytes, _stream()))
     return out[0]
+
+
+# =========================================================================================================
+# backward-pass kernels (include/e2eft.h "Backward pass of the E2E-FT training step"); used by autograd.py
+def _conv_desc(x, x2, cout, kh, kw, stride, pad, up_to, alpha, ldo=0):
+    B, H, W, c1 = x.shape
+    hl, wl = (H, W) if up_to is None else up_to
+    pt, pb, pl, pr = pad
+    d = ConvDesc()
+    d.dtype = dtype_id(x.dtype)
+    d.batch, d.hin, d.win, d.hl, d.wl = B, H, W, hl, wl
+    d.c1, d.ldx1 = c1, _nhwc_ld(x)
+    d.c2, d.ldx2 = (x2.shape[3], _nhwc_ld(x2)) if x2 is not None else (0, 0)
+    d.kh, d.kw, d.stride, d.pad_t, d.pad_l = kh, kw, stride, pt, pl
+    d.hout = (hl + pt + pb - kh) // stride + 1
+    d.wout = (wl + pl + pr - kw) // stride + 1
+    d.cout, d.ldo, d.ldr, d.ldw = cout, ldo, 0, 0
+    d.alpha = alpha
+    return d
+
+
+def transpose(x, rows_pad=None, out=None):
+    """x: [Z, R, C] (or [R, C]) row-strided view -> [Z, C, rows_pad] with zeros in [R, rows_pad) (rows_pad multiple of 64 by default
+    so that the result is a FAST-path K operand of e2eft_gemm)."""
+    _check_cuda(x, out)
+    squeeze = x.dim() == 2
+    if squeeze:
+        x = x[None]
+    Z, R, Cc = x.shape
+    if Cc > 1 and x.stride(2) != 1:
+        raise ValueError("transpose: unit inner stride required")
+    ld = x.stride(1) if R > 1 else max(Cc, x.stride(1))
+    bs = x.stride(0) if Z > 1 else R * ld
+    rp = round_up(R, 64) if rows_pad is None else rows_pad
+    if out is None:
+        out = torch.empty((Z, Cc, rp), dtype=x.dtype, device=x.device)
+    assert out.shape == (Z, Cc, rp) and out.is_contiguous()
+    with _timed("transpose", 0.0, 2.0 * Z * R * Cc * x.element_size(), label="transpose z%d %dx%d" % (Z, R, Cc)):
+        check(_lib.load().e2eft_transpose(dtype_id(x.dtype), Z, R, Cc, ld, bs, rp, rp, Cc * rp, _ptr(x), _ptr(out), _stream()))
+    return out[0] if squeeze else out
+
+
+def im2col_t(x, x2, kh, kw, stride, pad, up_to=None):
+    """-> ([kh*kw*(c1+c2), Ppad] K-contiguous im2col of the conv input over the OUTPUT pixels, P, Ppad)"""
+    _check_cuda(x, x2)
+    d = _conv_desc(x, x2, 1, kh, kw, stride, pad, up_to, 1.0)
+    P = d.batch * d.hout * d.wout
+    Pp = round_up(P, 64)
+    cin = d.c1 + d.c2
+    col = torch.empty((kh * kw * cin, Pp), dtype=x.dtype, device=x.device)
+    with _timed("im2col_t", 0.0, 2.0 * kh * kw * cin * Pp * x.element_size(), label="im2col_t %dx%d %d P%d" % (kh, kw, cin, P)):
+        check(_lib.load().e2eft_conv2d_im2col_t(C.byref(d), _ptr(x), _ptr(x2), _ptr(col), Pp, _stream()))
+    return col, P, Pp
+
+
+def conv2d_dgrad(dy, w_dgrad, x_shape, c2, kh, kw, stride, pad, up_to, alpha):
+    """dy [B,hout,wout,cout_pad] (zero / finite pad channels), w_dgrad [cin, kh*kw*cout_pad]; x_shape = forward x [B,H,W,c1].
+    Returns the gradient w.r.t. the logical (upsampled) concatenated input [B, hl, wl, c1+c2]."""
+    _check_cuda(dy, w_dgrad)
+    B, H, W, c1 = x_shape
+    hl, wl = (H, W) if up_to is None else up_to
+    pt, pb, pl, pr = pad
+    d = ConvDesc()
+    d.dtype = dtype_id(dy.dtype)
+    d.batch, d.hin, d.win, d.hl, d.wl = B, H, W, hl, wl
+    d.c1, d.ldx1, d.c2, d.ldx2 = c1, c1, c2, c2
+    d.kh, d.kw, d.stride, d.pad_t, d.pad_l = kh, kw, stride, pt, pl
+    d.hout, d.wout = dy.shape[1], dy.shape[2]
+    assert d.hout == (hl + pt + pb - kh) // stride + 1 and d.wout == (wl + pl + pr - kw) // stride + 1
+    cop = dy.shape[3]
+    d.cout, d.alpha = cop, alpha
+    cin = c1 + c2
+    assert w_dgrad.shape == (cin, kh * kw * cop) and w_dgrad.is_contiguous() and w_dgrad.dtype == dy.dtype
+    dx = new_nhwc(B, hl, wl, cin, dy.dtype, dy.device)
+    with _timed("igemm", 2.0 * B * hl * wl * cin * kh * kw * cop, label="dgrad%dx%ds%d B%d %dx%d %d->%d" % (kh, kw, stride, B, hl, wl, cop, cin)):
+        check(_lib.load().e2eft_conv2d_dgrad(C.byref(d), _ptr(dy), _nhwc_ld(dy), cop, _ptr(w_dgrad), w_dgrad.shape[1], _ptr(dx), _nhwc_ld(dx),
+                                             _stream()))
+    return dx
+
+
+def colsum(x2d, groups=1, alpha=1.0):
+    """x2d [rows, cols] row-strided -> fp32 [groups, cols] sums over each group of rows/groups consecutive rows"""
+    _check_cuda(x2d)
+    R, Cc = x2d.shape
+    assert R % groups == 0
+    lib = _lib.load()
+    nbytes = lib.e2eft_colsum_workspace_bytes(groups, R // groups, Cc)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2d.device)
+    out = torch.empty((groups, Cc), dtype=torch.float32, device=x2d.device)
+    check(lib.e2eft_colsum(dtype_id(x2d.dtype), groups, R // groups, Cc, _rows_ld(x2d), alpha, _ptr(x2d), _ptr(out), _ptr(ws), nbytes, _stream()))
+    return out
+
+
+def upsample_nearest_bwd(dy, H, W):
+    """dy [B,hl,wl,C] -> [B,H,W,C]"""
+    _check_cuda(dy)
+    B, hl, wl, Cc = dy.shape
+    dx = torch.empty((B, H, W, Cc), dtype=dy.dtype, device=dy.device)
+    check(_lib.load().e2eft_upsample_nearest_bwd(dtype_id(dy.dtype), B, H, W, hl, wl, Cc, _nhwc_ld(dy), Cc, _ptr(dy), _ptr(dx), _stream()))
+    return dx
+
+
+def groupnorm_fwd_ws(x, gamma, beta, groups, eps, silu=False, x2=None):
+    """GroupNorm forward that also returns its workspace (mean / rstd live there) for groupnorm_bwd."""
+    _check_cuda(x, gamma, beta, x2)
+    B, H, W, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[3]
+    out = torch.empty((B, H, W, c1 + c2), dtype=x.dtype, device=x.device)
+    d = _gn_desc(x, x2, groups, eps, silu, _nhwc_ld(out))
+    lib = _lib.load()
+    nbytes = lib.e2eft_groupnorm_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError("groupnorm: %s" % lib.e2eft_last_error().decode())
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    with _timed("groupnorm", 0.0, 3.0 * B * H * W * (c1 + c2) * x.element_size(), label="gn B%d %dx%d C%d" % (B, H, W, c1 + c2)):
+        check(lib.e2eft_groupnorm_fwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), nbytes, _stream()))
+    return out, ws
+
+
+def _gn_desc(x, x2, groups, eps, silu, ldy):
+    B, H, W, c1 = x.shape
+    d = GroupNormDesc()
+    d.dtype = dtype_id(x.dtype)
+    d.batch, d.hw = B, H * W
+    d.c1, d.ldx1 = c1, _nhwc_ld(x)
+    d.c2, d.ldx2 = (x2.shape[3], _nhwc_ld(x2)) if x2 is not None else (0, 0)
+    d.groups, d.ldy, d.silu, d.eps = groups, ldy, 1 if silu else 0, eps
+    return d
+
+
+def groupnorm_bwd(x, x2, gamma, beta, groups, eps, silu, dy, fwd_ws, need_dx=True, need_dparams=True):
+    """-> (dx [B,H,W,C] or None, dgamma fp32 [C] or None, dbeta fp32 [C] or None)"""
+    _check_cuda(x, x2, gamma, beta, dy, fwd_ws)
+    B, H, W, c1 = x.shape
+    Cc = c1 + (0 if x2 is None else x2.shape[3])
+    d = _gn_desc(x, x2, groups, eps, silu, Cc)
+    lib = _lib.load()
+    nbytes = lib.e2eft_groupnorm_bwd_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError("groupnorm_bwd: %s" % lib.e2eft_last_error().decode())
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    dx = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device) if need_dx else None
+    dg = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_dparams else None
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_dparams else None
+    with _timed("groupnorm_bwd", 0.0, 5.0 * B * H * W * Cc * x.element_size(), label="gn_bwd B%d %dx%d C%d" % (B, H, W, Cc)):
+        check(lib.e2eft_groupnorm_bwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(dy), _nhwc_ld(dy), _ptr(dx), Cc, _ptr(dg), _ptr(db),
+                                      _ptr(fwd_ws), _ptr(ws), nbytes, _stream()))
+    return dx, dg, db
+
+
+def layernorm_bwd(x, gamma, eps, dy, need_dx=True):
+    """-> (dx like x or None, dgamma fp32 [C], dbeta fp32 [C])"""
+    _check_cuda(x, gamma, dy)
+    Cc = x.shape[-1]
+    a = x.reshape(-1, Cc) if x.is_contiguous() else _as_rows(x)
+    g = dy.reshape(-1, Cc) if dy.is_contiguous() else _as_rows(dy)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device) if need_dx else None
+    lib = _lib.load()
+    nbytes = lib.e2eft_layernorm_bwd_workspace_bytes(a.shape[0], Cc)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    gb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    check(lib.e2eft_layernorm_bwd(dtype_id(x.dtype), a.shape[0], Cc, _rows_ld(a), _rows_ld(g), Cc, eps, _ptr(a), _ptr(gamma), _ptr(g), _ptr(dx), _ptr(gb),
+                                  _ptr(ws), nbytes, _stream()))
+    return dx, gb[0], gb[1]
+
+
+def geglu_bwd(h, dy):
+    _check_cuda(h, dy)
+    c2 = h.shape[-1]
+    c = c2 // 2
+    a = h.reshape(-1, c2) if h.is_contiguous() else _as_rows(h)
+    g = dy.reshape(-1, c) if dy.is_contiguous() else _as_rows(dy)
+    dh = torch.empty(h.shape, dtype=h.dtype, device=h.device)
+    check(_lib.load().e2eft_geglu_bwd(dtype_id(h.dtype), a.shape[0], c, _rows_ld(a), _rows_ld(g), c2, _ptr(a), _ptr(g), _ptr(dh), _stream()))
+    return dh
+
+
+def softmax_bwd_rows_(p, dp, n, scale):
+    """in place on dp [rows, lds]: dp <- p * (dp - rowsum(dp*p)) * scale"""
+    _check_cuda(p, dp)
+    assert p.dim() == 2 and p.is_contiguous() and dp.shape == p.shape and dp.is_contiguous() and p.dtype == dp.dtype
+    check(_lib.load().e2eft_softmax_bwd_rows(dtype_id(p.dtype), p.shape[0], n, p.shape[1], scale, _ptr(p), _ptr(dp), _stream()))
+    return dp
+
+
+def silu_bwd(x, dy):
+    _check_cuda(x, dy)
+    x, dy = x.contiguous(), dy.contiguous()
+    dx = torch.empty_like(x)
+    check(_lib.load().e2eft_silu_bwd(dtype_id(x.dtype), x.numel(), _ptr(x), _ptr(dy), _ptr(dx), _stream()))
+    return dx
+
+
+def depth_head_bwd(x, dy, to_unit):
+    """x NHWC [B,H,W,>=3] (forward input), dy [B,1,H,W] -> dx [B,H,W,3] (view of a zero-padded buffer)"""
+    _check_cuda(x, dy)
+    B, H, W, _ = x.shape
+    dy = dy.contiguous()
+    cp = round_up(3, epc(x.dtype))
+    dx = torch.empty((B, H, W, cp), dtype=x.dtype, device=x.device)
+    check(_lib.load().e2eft_depth_head_bwd(dtype_id(x.dtype), dtype_id(dy.dtype), B * H * W, _nhwc_ld(x), cp, cp, 1 if to_unit else 0, _ptr(x), _ptr(dy),
+                                           _ptr(dx), _stream()))
+    return dx[..., :x.shape[3]] if x.shape[3] <= cp else dx
+
+
+def normal_head_bwd(x, dy, clamp, sign):
+    _check_cuda(x, dy)
+    B, H, W, _ = x.shape
+    dy = dy.contiguous()
+    cp = round_up(3, epc(x.dtype))
+    dx = torch.empty((B, H, W, cp), dtype=x.dtype, device=x.device)
+    check(_lib.load().e2eft_normal_head_bwd(dtype_id(x.dtype), dtype_id(dy.dtype), B, H * W, _nhwc_ld(x), cp, cp, 1 if clamp else 0, sign, _ptr(x), _ptr(dy),
+                                            _ptr(dx), _stream()))
+    return dx[..., :x.shape[3]] if x.shape[3] <= cp else dx
+
+
+def ssi_loss_fwd_saved(p, t, m):
+    """p, t fp32 [B, hw] contiguous, m uint8 [B, hw] -> (loss[1], scale_shift [B,2], workspace) for ssi_loss_bwd"""
+    lib = _lib.load()
+    B = p.shape[0]
+    nbytes = lib.e2eft_ssi_loss_workspace_bytes(B)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=p.device)
+    out = torch.empty(1, dtype=torch.float32, device=p.device)
+    ss = torch.empty((B, 2), dtype=torch.float32, device=p.device)
+    check(lib.e2eft_ssi_loss_fwd(B, p.shape[1], _ptr(p), _ptr(t), _ptr(m), _ptr(out), _ptr(ss), _ptr(ws), nbytes, _stream()))
+    return out, ss, ws
+
+
+def ssi_loss_bwd(p, t, m, ss, fwd_ws, gout):
+    B = p.shape[0]
+    dp = torch.empty_like(p)
+    ws = torch.empty(2 * B, dtype=torch.float64, device=p.device)
+    g = gout.reshape(1).float().contiguous()
+    check(_lib.load().e2eft_ssi_loss_bwd(B, p.shape[1], _ptr(p), _ptr(t), _ptr(m), _ptr(ss), _ptr(fwd_ws), _ptr(g), _ptr(dp), _ptr(ws), 16 * B, _stream()))
+    return dp
+
+
+def angular_loss_fwd_saved(p, t, m):
+    """p, t fp32 [B,3,hw], m uint8 [B,hw]"""
+    lib = _lib.load()
+    ws = torch.empty(2, dtype=torch.float64, device=p.device)
+    out = torch.empty(1, dtype=torch.float32, device=p.device)
+    check(lib.e2eft_angular_loss_fwd(p.shape[0], p.shape[2], _ptr(p), _ptr(t), _ptr(m), _ptr(out), _ptr(ws), 16, _stream()))
+    return out, ws
+
+
+def angular_loss_bwd(p, t, m, fwd_ws, gout):
+    dp = torch.empty_like(p)
+    g = gout.reshape(1).float().contiguous()
+    check(_lib.load().e2eft_angular_loss_bwd(p.shape[0], p.shape[2], _ptr(p), _ptr(t), _ptr(m), _ptr(fwd_ws), _ptr(g), _ptr(dp), _stream()))
+    return dp
+
+
+def sumsq(g, out=None):
+    """fp64 [1] device scalar = sum g^2 over a flat fp32 buffer"""
+    _check_cuda(g)
+    assert g.dtype == torch.float32 and g.is_contiguous()
+    if out is None:
+        out = torch.empty(1, dtype=torch.float64, device=g.device)
+    check(_lib.load().e2eft_sumsq(g.numel(), _ptr(g), _ptr(out), _stream()))
+    return out
+
+
+def adamw_step_(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_sumsq=None, grad_scale=1.0, max_norm=0.0):
+    _check_cuda(param, grad, exp_avg, exp_avg_sq, grad_sumsq)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
+    check(_lib.load().e2eft_adamw_step(param.numel(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), lr, beta1, beta2, eps, weight_decay, step,
+                                       _ptr(grad_sumsq), grad_scale, max_norm, _stream()))
+    return param
+
+
+def cast_(x, y, mul=1.0, accumulate=False):
+    """y <- (y if accumulate else 0) + x*mul with dtype conversion; flat contiguous buffers"""
+    _check_cuda(x, y)
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(_lib.load().e2eft_cast(dtype_id(x.dtype), dtype_id(y.dtype), x.numel(), mul, 1 if accumulate else 0, _ptr(x), _ptr(y), _stream()))
+    return y

@@ -1,0 +1,214 @@
+"""Host side of the E2E-FT training step (training/train.py:470-568), built on the libe2eft forward/backward kernels.
+
+  e2e_ft_loss        — the step's forward half: frozen VAE encode -> zeros latent -> UNet @ t=999 -> x0 -> frozen VAE decode ->
+                       depth / normal head -> ScaleAndShiftInvariantLoss / AngularLoss   (train.py:472-556)
+  FlatAdamW          — clip_grad_norm_ + torch.optim.AdamW semantics (train.py:346-353,561-566) on ONE flat fp32 parameter
+                       buffer: parameters and their .grad are views of two big allocations, so the data-parallel gradient
+                       exchange is a handful of large RCCL all-reduces over contiguous slices (no bucket copies), launched
+                       from autograd hooks while the rest of the backward is still running, and the update is one launch.
+  IterExponential    — training/util/lr_scheduler.py:10-36
+  replace_unet_conv_in — training/util/unet_prep.py:6-20
+
+The reference wraps the UNet in DDP via accelerate; here one process per GPU (torchrun) calls FlatAdamW.step(), which waits for
+the outstanding all-reduces.  xGMI is point-to-point, so few large collectives (default 4 slices of the 3.46 GB gradient)
+keep all seven links busy; the first slice to finish its backward (the up blocks) starts its exchange while the down blocks
+are still computing.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import autograd as F
+from . import ops
+from .modules import to_nhwc, to_nchw_view
+
+
+class IterExponential:
+    """lr multiplier: linear warm-up, then exp decay to final_ratio at total_iter_length (lr_scheduler.py:10-36)"""
+
+    def __init__(self, total_iter_length, final_ratio, warmup_steps=0):
+        self.total_length = total_iter_length
+        self.effective_length = total_iter_length - warmup_steps
+        self.final_ratio = final_ratio
+        self.warmup_steps = warmup_steps
+
+    def __call__(self, n_iter):
+        if n_iter < self.warmup_steps:
+            return 1.0 * n_iter / self.warmup_steps
+        if n_iter >= self.total_length:
+            return self.final_ratio
+        return math.exp((n_iter - self.warmup_steps) / self.effective_length * math.log(self.final_ratio))
+
+
+def replace_unet_conv_in(unet, repeat=2):
+    """4 -> 8 input channels: repeat the weight on Cin, halve weight and bias (unet_prep.py:6-20)"""
+    w = unet.conv_in.weight.detach().clone().repeat(1, repeat, 1, 1) / repeat
+    b = unet.conv_in.bias.detach().clone() / repeat
+    old = unet.conv_in
+    new = type(old)(old.in_channels * repeat, old.out_channels, kernel_size=old.kernel_size, stride=old.stride, padding=old.padding)
+    new = new.to(device=w.device, dtype=w.dtype)
+    with torch.no_grad():
+        new.weight.copy_(w)
+        new.bias.copy_(b)
+    unet.conv_in = new
+    unet.config["in_channels"] = old.in_channels * repeat
+
+
+# ------------------------------------------------------------------------------------------------------------
+def encode_image(vae, image):
+    """train.py:233-237"""
+    h = vae.encoder(image)
+    moments = vae.quant_conv(h)
+    latent, _ = torch.chunk(moments, 2, dim=1)
+    return latent
+
+
+def e2e_ft_loss(unet, vae, batch, empty_encoding, modality="depth", alpha_prod_999=None, return_estimate=False):
+    """Forward half of one micro-step (train.py:472-556) with the zeros latent at t = 999 (the E2E-FT recipe).
+    batch: rgb [b,3,H,W] in [-1,1], val_mask [b,1,H,W] bool, metric [b,1,H,W] / normals [b,3,H,W].  Returns the scalar loss
+    (device tensor with a grad_fn through the decoder and the UNet)."""
+    dev = unet.device
+    dt = unet.dtype
+    with torch.no_grad():
+        rgb_latents = encode_image(vae, batch["rgb"].to(device=dev, dtype=dt)) * vae.config.scaling_factor
+    val_mask = batch["val_mask"].bool().to(dev)
+    b = rgb_latents.shape[0]
+    timesteps = torch.full((b,), 999, device=dev, dtype=torch.long)
+    noisy = torch.zeros_like(rgb_latents)
+    ctx = empty_encoding.to(device=dev, dtype=dt).repeat(b, 1, 1)
+    unet_input = torch.cat((rgb_latents, noisy), dim=1).contiguous(memory_format=torch.channels_last)
+    model_pred = unet(unet_input, timesteps, ctx, return_dict=False)[0]
+    if alpha_prod_999 is None:
+        from .scheduler import DDIMScheduler
+        alpha_prod_999 = float(DDIMScheduler().alphas_cumprod[999])
+    # v-prediction with x_t = 0: x0 = -sqrt(1 - alpha_prod) * v   (train.py:509-512), then / scaling_factor (:528)
+    x0 = model_pred * (-math.sqrt(1.0 - alpha_prod_999) / vae.config.scaling_factor)
+    est = vae.decoder(vae.post_quant_conv(x0))                     # [b,3,H,W] logical NCHW, NHWC memory
+    est_nhwc = est.permute(0, 2, 3, 1)
+    if modality == "depth":
+        cur = F.depth_head(est_nhwc, to_unit=False)                # mean over channels, clamp(-1, 1)  (:531-533)
+        loss = F.ssi_loss(cur, batch["metric"].to(device=dev), val_mask)
+    elif modality == "normals":
+        cur = F.normal_head(est_nhwc, clamp=True)                  # x / (|x| + 1e-5), clamp  (:535-538)
+        loss = F.angular_loss(cur, batch["normals"].to(device=dev), val_mask)
+    else:
+        raise ValueError("Unknown modality %s" % modality)
+    return (loss, cur) if return_estimate else loss
+
+
+# ------------------------------------------------------------------------------------------------------------
+class FlatAdamW:
+    """AdamW + gradient clipping over one flat fp32 buffer, gradient all-reduce overlapped with the backward.
+
+    params: iterable of trainable Parameters (fp32, same device).  Their storage is moved into `self.flat_param`
+    (diffusers-layout views, state_dict() keeps working) and `.grad` is pre-bound to views of `self.flat_grad`, so autograd
+    accumulates straight into the exchange buffer."""
+
+    def __init__(self, params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0, n_slices=4,
+                 process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev = self.params[0].device
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("FlatAdamW keeps fp32 master parameters; got %s" % p.dtype)
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4                     # keep every view 16-byte aligned
+        self.numel = n
+        self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat_param[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        F.bump_param_epoch()
+        self.step_count = 0
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        # slices of the flat buffer in BACKWARD order: the last parameters (up blocks, conv_out) get their gradients first
+        n_slices = max(1, min(n_slices, len(self.params)))
+        per = (len(self.params) + n_slices - 1) // n_slices
+        self.slices = []
+        for s in range(n_slices):
+            lo, hi = s * per, min(len(self.params), (s + 1) * per)
+            if lo >= hi:
+                continue
+            start = self.offsets[lo]
+            end = self.offsets[hi] if hi < len(self.params) else n
+            self.slices.append(dict(lo=lo, hi=hi, start=start, end=end, ready=0, work=None))
+        self._slice_of = {}
+        for si, sl in enumerate(self.slices):
+            for i in range(sl["lo"], sl["hi"]):
+                self._slice_of[id(self.params[i])] = si
+        self.sync_grads = True          # set False on non-final gradient-accumulation micro-steps
+        self._hooks = []
+        if self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # autograd hook: a parameter's gradient is final for this backward
+    def _on_grad(self, p):
+        if not self.sync_grads:
+            return
+        sl = self.slices[self._slice_of[id(p)]]
+        sl["ready"] += 1
+        if sl["ready"] == sl["hi"] - sl["lo"]:
+            sl["work"] = dist.all_reduce(self.flat_grad[sl["start"]:sl["end"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _finish_exchange(self):
+        if self.world == 1:
+            return
+        for sl in self.slices:
+            if sl["work"] is None:     # parameters that received no gradient this step: exchange the slice now
+                sl["work"] = dist.all_reduce(self.flat_grad[sl["start"]:sl["end"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for sl in self.slices:
+            sl["work"].wait()
+            sl["work"], sl["ready"] = None, 0
+
+    @torch.no_grad()
+    def step(self, lr_scale=1.0, grad_scale=1.0):
+        """all-reduce(mean) -> clip_grad_norm_(max_grad_norm) -> AdamW; returns nothing (no host synchronisation)."""
+        self._finish_exchange()
+        self.step_count += 1
+        gs = grad_scale / self.world
+        sumsq = None
+        if self.max_grad_norm and self.max_grad_norm > 0:
+            sumsq = ops.sumsq(self.flat_grad, out=self._sumsq)
+        ops.adamw_step_(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr * lr_scale, self.betas[0], self.betas[1], self.eps,
+                        self.weight_decay, self.step_count, grad_sumsq=sumsq, grad_scale=gs, max_norm=self.max_grad_norm or 0.0)
+        F.bump_param_epoch()
+
+    def grad_norm(self):
+        """global L2 norm of the (averaged) gradient — host value, synchronises"""
+        return math.sqrt(float(ops.sumsq(self.flat_grad, out=self._sumsq).item())) / self.world
+
+    @torch.no_grad()
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p, o in zip(self.params, self.offsets):      # autograd may have re-bound .grad (e.g. set_to_none by a caller)
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+
+def train_step(unet, vae, optimizer, batches, empty_encoding, modality="depth", lr_scale=1.0):
+    """One optimizer step over `batches` (a list of micro-batches = gradient accumulation, train.py:470,559-566): returns the
+    mean micro-loss as a device tensor."""
+    n = len(batches)
+    total = None
+    for i, batch in enumerate(batches):
+        optimizer.sync_grads = i == n - 1
+        loss = e2e_ft_loss(unet, vae, batch, empty_encoding, modality)
+        (loss / n).backward()
+        total = loss.detach() if total is None else total + loss.detach()
+    optimizer.step(lr_scale=lr_scale)
+    optimizer.zero_grad()
+    return total / n

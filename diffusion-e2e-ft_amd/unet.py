@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from . import ops
+from . import autograd as F
 from .modules import (Conv2d, GroupNorm, ResnetBlock2D, Transformer2DModel, Downsample2D, Upsample2D, TimestepEmbedding,
                       conv_nhwc, to_nhwc, to_nchw_view)
 
@@ -216,8 +217,8 @@ class UNet2DConditionModel(nn.Module):
         if self.class_embedding is not None:
             if class_labels is None:
                 raise ValueError("class_labels should be provided for class_embed_type='projection'")
-            emb = ops.add(emb, self.class_embedding(class_labels.to(dt).contiguous()))
-        temb_act = ops.silu(emb)  # every ResnetBlock2D applies SiLU before its time_emb_proj
+            emb = F.add(emb, self.class_embedding(class_labels.to(dt).contiguous()))
+        temb_act = F.silu(emb)  # every ResnetBlock2D applies SiLU before its time_emb_proj
         ctx = encoder_hidden_states.to(dt).contiguous()
         n_up = len(cfg.block_out_channels) - 1
         forward_upsample_size = any(s % (2 ** n_up) != 0 for s in sample.shape[-2:])

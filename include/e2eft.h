@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define E2EFT_VERSION 100 /* 0.1.0 */
+#define E2EFT_VERSION 110 /* 0.1.1: backward entry points */
 
 enum {
     E2EFT_OK = 0,
@@ -215,6 +215,79 @@ size_t e2eft_angular_loss_workspace_bytes(int32_t batch);
 int e2eft_angular_loss_fwd(int32_t batch, int32_t hw, const float* pred /* [B,3,hw] */,
                            const float* target /* [B,3,hw] */, const uint8_t* mask /* [B,hw] */, float* out_loss,
                            void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Backward pass of the E2E-FT training step (training/train.py:470-568: loss.backward() through the loss hooks, the
+ * frozen VAE decoder, the x0 conversion and the UNet; accelerator.clip_grad_norm_ + AdamW at :561-566).  In the reference
+ * these gradients come from torch autograd over diffusers modules; here every autograd.Function.backward of the host layer
+ * (diffusion-e2e-ft_amd/autograd.py) calls one of these.
+ *
+ * Convolution (replaces the cudnn/miopen dgrad + wgrad autograd dispatches for nn.Conv2d in diffusers ResnetBlock2D /
+ * Downsample2D / Upsample2D / conv_in / conv_out):
+ *   dgrad — the forward implicit-GEMM kernel run on dy with flipped, channel-transposed weights
+ *           w_dgrad[ci][(kh-1-ky, kw-1-kx, co)] (co padded to cout_pad with zeros, dy pad channels must be finite);
+ *           strided convolutions read dy through a zero-insertion grid; dx is w.r.t. the LOGICAL (upsampled) input
+ *           [B, hl, wl, c1+c2] and covers both concat sources.
+ *   wgrad — e2eft_transpose(dy) [cout, P] x e2eft_conv2d_im2col_t(x) [kh*kw*cin, P] through e2eft_gemm; the result
+ *           [cout, kh*kw*cin] is the OHWI weight layout.  P = batch*hout*wout; im2col_t writes zeros in [P, ldcol).
+ * ---------------------------------------------------------------------------------------------------- */
+int e2eft_conv2d_dgrad(const E2eftConvDesc* fwd, const void* dy, int32_t lddy, int32_t cout_pad, const void* w_dgrad,
+                       int32_t ldwd, void* dx, int32_t lddx, void* stream);
+int e2eft_conv2d_im2col_t(const E2eftConvDesc* fwd, const void* x1, const void* x2, void* col /* [kh*kw*cin][ldcol] */,
+                          int64_t ldcol, void* stream);
+/* out[z][c][r] = in[z][r][c] for r < rows, 0 for rows <= r < rows_pad (batched 2-D transpose, 16-byte vectors both ways) */
+int e2eft_transpose(int32_t dtype, int32_t batch, int64_t rows, int32_t cols, int64_t ld_in, int64_t batch_stride_in,
+                    int64_t rows_pad, int64_t ld_out, int64_t batch_stride_out, const void* in, void* out, void* stream);
+/* out[g][c] = alpha * sum over the g-th group of rows_per_group consecutive rows of x[:, c] (fp32 out): bias gradients
+ * (groups = 1) and the per-image time-embedding gradient of ResnetBlock2D (groups = batch).  Deterministic (no atomics). */
+size_t e2eft_colsum_workspace_bytes(int32_t groups, int64_t rows_per_group, int32_t cols);
+int e2eft_colsum(int32_t dtype, int32_t groups, int64_t rows_per_group, int32_t cols, int64_t ld, float alpha,
+                 const void* x, float* out, void* workspace, size_t ws_bytes, void* stream);
+/* nearest-upsample backward: dx[B,hin,win,c] = sum of dy[B,hl,wl,c] over the forward gather's preimage */
+int e2eft_upsample_nearest_bwd(int32_t dtype, int32_t batch, int32_t hin, int32_t win, int32_t hl, int32_t wl, int32_t c,
+                               int32_t lddy, int32_t lddx, const void* dy, void* dx, void* stream);
+/* GroupNorm(+SiLU) backward (F.group_norm / F.silu autograd in diffusers ResnetBlock2D, Transformer2DModel.norm, VAE):
+ * fwd_workspace is the workspace e2eft_groupnorm_fwd[_pre] filled for the same desc (it holds mean / rstd);
+ * dx [B*hw, lddx] covers both concat sources; dgamma / dbeta fp32 [C] or NULL (frozen VAE); dx may be NULL. */
+size_t e2eft_groupnorm_bwd_workspace_bytes(const E2eftGroupNormDesc* d);
+int e2eft_groupnorm_bwd(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma, const void* beta,
+                        const void* dy, int32_t lddy, void* dx, int32_t lddx, float* dgamma, float* dbeta,
+                        const void* fwd_workspace, void* workspace, size_t ws_bytes, void* stream);
+/* LayerNorm backward: dx (may be NULL) and dgamma_dbeta fp32 [2][c] */
+size_t e2eft_layernorm_bwd_workspace_bytes(int64_t rows, int32_t c);
+int e2eft_layernorm_bwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldx, int32_t lddy, int32_t lddx, float eps,
+                        const void* x, const void* gamma, const void* dy, void* dx, float* dgamma_dbeta, void* workspace,
+                        size_t ws_bytes, void* stream);
+/* GEGLU backward: h [rows, 2c] (value | gate), dy [rows, c] -> dh [rows, 2c] */
+int e2eft_geglu_bwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldh, int32_t lddy, int32_t lddh, const void* h,
+                    const void* dy, void* dh, void* stream);
+/* softmax backward in place on dp: ds = p * (dp - rowsum(dp * p)) * scale (attention backward, p = softmax(scale * s)) */
+int e2eft_softmax_bwd_rows(int32_t dtype, int64_t rows, int32_t n, int64_t lds, float scale, const void* p, void* dp,
+                           void* stream);
+int e2eft_silu_bwd(int32_t dtype, int64_t n, const void* x, const void* dy, void* dx, void* stream);
+/* head gradients (train.py:531-538): dx NHWC [pixels, lddx] with cpad >= 3 channels written (zeros beyond 3) */
+int e2eft_depth_head_bwd(int32_t dt_x, int32_t dt_y, int64_t pixels, int32_t ldx, int32_t lddx, int32_t cpad,
+                         int32_t to_unit, const void* x, const void* dy, void* dx, void* stream);
+int e2eft_normal_head_bwd(int32_t dt_x, int32_t dt_y, int32_t batch, int32_t hw, int32_t ldx, int32_t lddx, int32_t cpad,
+                          int32_t clamp, float sign, const void* x, const void* dy, void* dx, void* stream);
+/* loss gradients w.r.t. pred (training/util/loss.py autograd, including the chain through the closed-form scale/shift):
+ * fwd_workspace = the workspace the matching *_fwd call filled; grad_out = 1 float on the device; workspace: 2 doubles/image */
+int e2eft_ssi_loss_bwd(int32_t batch, int32_t hw, const float* pred, const float* target, const uint8_t* mask,
+                       const float* scale_shift, const void* fwd_workspace, const float* grad_out, float* dpred,
+                       void* workspace, size_t ws_bytes, void* stream);
+int e2eft_angular_loss_bwd(int32_t batch, int32_t hw, const float* pred, const float* target, const uint8_t* mask,
+                           const void* fwd_workspace, const float* grad_out, float* dpred, void* stream);
+/* Flat-buffer optimizer step (torch.optim.AdamW + accelerator.clip_grad_norm_, train.py:561-566): all trainable
+ * parameters / gradients / moments are single fp32 buffers.  e2eft_sumsq: out[0] = sum g^2 (fp64).  e2eft_adamw_step
+ * scales the gradient by grad_scale * min(1, max_norm / (sqrt(grad_sumsq) * grad_scale + 1e-6)) when grad_sumsq != NULL
+ * and max_norm > 0 (no host synchronisation), then applies decoupled-decay Adam with bias correction for `step` (>= 1). */
+int e2eft_sumsq(int64_t n, const float* g, double* out, void* stream);
+int e2eft_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int32_t step, const double* grad_sumsq, float grad_scale,
+                     float max_norm, void* stream);
+/* y = (accumulate ? y : 0) + x * mul with dtype conversion (fp32 master weights -> 16-bit compute copies, 16-bit gradients
+ * accumulated into the fp32 flat gradient buffer) */
+int e2eft_cast(int32_t dt_in, int32_t dt_out, int64_t n, float mul, int32_t accumulate, const void* x, void* y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,8 @@
   model_golden.pt  — outputs of the CPU oracle (oracle/) on seeded synthetic weights/inputs for the tiny configs.
                      PARITY UNPINNED at the diffusers boundary: these freeze the oracle, they do not
                      come from the reference implementation (diffusers is not installable here, no checkpoints exist).
+  train_golden.pt  — loss, estimate and UNet gradients of one E2E-FT micro-step (depth / normals) through torch autograd over
+                     the CPU oracle (same pinning caveat as model_golden.pt).
   hooks_golden.pt  — outputs of the REFERENCE'S OWN modules imported from /root/reference/training/util
                      (loss.py, lr_scheduler.py, unet_prep.py) on seeded inputs: these pin oracle/losses_ref.py and the
                      HIP loss kernels to the reference.
@@ -37,6 +39,9 @@ def main():
             out[name] = fn()
             print(name, {k: tuple(v.shape) for k, v in out[name].items()})
     torch.save(out, os.path.join(HERE, "model_golden.pt"))
+    train = {m: gc.train_grads(m) for m in ("depth", "normals")}
+    torch.save(train, os.path.join(HERE, "train_golden.pt"))
+    print("train:", {m: (float(v["loss"]), len(v["grads"]), len(v["grad_norms"])) for m, v in train.items()})
 
     ref_dir = "/root/reference/training/util"
     if os.path.isdir(ref_dir):
@@ -46,10 +51,16 @@ def main():
         hooks = {}
         pred, tgt, mask = gc.ssi_inputs()
         hooks["ssi_loss"] = loss.ScaleAndShiftInvariantLoss()(pred, tgt, mask)
+        pg = pred.clone().requires_grad_(True)
+        loss.ScaleAndShiftInvariantLoss()(pg, tgt, mask).backward()
+        hooks["ssi_dpred"] = pg.grad.clone()
         s, t = loss.compute_scale_and_shift_masked(pred.squeeze(1), tgt.squeeze(1), mask.squeeze(1))
         hooks["ssi_scale"], hooks["ssi_shift"] = s, t
         n, nt, m3 = gc.angular_inputs()
         hooks["angular_loss"] = loss.AngularLoss()(n, nt, m3)
+        ng = n.clone().requires_grad_(True)
+        loss.AngularLoss()(ng, nt, m3).backward()
+        hooks["angular_dpred"] = ng.grad.clone()
         sched = lr.IterExponential(total_iter_length=20000, final_ratio=0.01, warmup_steps=100)
         hooks["lr_iters"] = torch.tensor(gc.LR_ITERS)
         hooks["lr_values"] = torch.tensor([float(sched(i)) for i in gc.LR_ITERS], dtype=torch.float64)

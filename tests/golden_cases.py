@@ -109,3 +109,46 @@ MODEL_CASES = {
     "pipe": _pipe,
     "geo_pipe": _geo_pipe,
 }
+
+
+def train_batch(seed=21, B=2, H=64, W=64):
+    """synthetic micro-batch of the E2E-FT step: rgb in [-1,1], metric depth target in [-1,1], unit normals, 5 % invalid"""
+    rgb, ctx = synth.synth_inputs(B, H, W, 2, 128, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    metric = torch.stack([(0.6 * xx * (b + 1) / B + 0.3 * yy).clamp(-1, 1) for b in range(B)])[:, None] + 0.05 * torch.randn(B, 1, H, W, generator=g)
+    normals = torch.nn.functional.normalize(torch.randn(B, 3, H, W, generator=g) + torch.tensor([0.0, 0.0, 2.0]).view(1, 3, 1, 1), dim=1)
+    mask = torch.rand(B, 1, H, W, generator=g) > 0.05
+    return {"rgb": rgb, "metric": metric.clamp(-1, 1), "normals": normals, "val_mask": mask}, ctx[:1]
+
+
+TRAIN_FULL_GRADS = ["conv_in.weight", "conv_in.bias", "time_embedding.linear_1.weight", "down_blocks.0.resnets.0.time_emb_proj.weight",
+                    "down_blocks.0.resnets.0.norm1.weight", "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight",
+                    "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight", "down_blocks.0.attentions.0.transformer_blocks.0.norm2.bias",
+                    "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.weight", "down_blocks.0.downsamplers.0.conv.weight",
+                    "mid_block.resnets.0.conv1.weight", "up_blocks.0.resnets.0.conv1.weight", "up_blocks.0.resnets.0.conv_shortcut.weight",
+                    "up_blocks.0.upsamplers.0.conv.weight", "conv_norm_out.bias", "conv_out.weight", "conv_out.bias"]
+
+
+def train_grads(modality):
+    """loss and UNet parameter gradients of one micro-step through the CPU oracle (torch autograd over oracle/*_ref.py)"""
+    batch, text = train_batch()
+    usd = {k: v.clone().requires_grad_(True) for k, v in tiny_unet_sd().items()}
+    loss, est = pipeline_ref.train_forward_ref(usd, config.TINY_UNET, tiny_vae_sd(), config.TINY_VAE, batch, text, modality)
+    loss.backward()
+    out = {"loss": loss.detach(), "estimate": est.detach(),
+           "grad_norms": {k: float(v.grad.norm()) for k, v in usd.items()}}
+    keys = [k for k in TRAIN_FULL_GRADS if k in usd]
+    assert len(keys) >= 12, [k for k in TRAIN_FULL_GRADS if k not in usd]
+    # large tensors are stored as a strided sample of the flattened gradient (GRAD_STRIDE) to keep the fixture small
+    out["grads"] = {k: sample_grad(usd[k].grad) for k in keys}
+    out["estimate"] = out["estimate"][:, :, ::4, ::4].clone()
+    return out
+
+
+GRAD_STRIDE = 61
+
+
+def sample_grad(g):
+    f = g.detach().reshape(-1)
+    return f.clone() if f.numel() <= 4096 else f[::GRAD_STRIDE].clone()

@@ -43,6 +43,34 @@ def _worker(rank, world, port, q):
     assert nb >= 3
     for i, p in enumerate(params):
         assert torch.allclose(p.grad.float(), torch.full_like(p, (1 + 2) / 2 * (i + 1)).float())
+    # FlatAdamW's overlapped exchange (training.py): gradients are views of one flat buffer, slices are all-reduced from autograd
+    # hooks; only the exchange is exercised here (the update itself is a HIP kernel, tests/test_train_gpu.py)
+    from diffusion_e2e_ft_amd import training
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 1))
+    opt = training.FlatAdamW(net.parameters(), n_slices=3)
+    assert opt.world == 2 and len(opt.slices) == 3
+    xs = [torch.full((4, 6), 0.1 * (k + 1)) for k in range(2)]
+    # reference: mean over ranks of the per-rank gradients
+    refs = []
+    for k in range(2):
+        ref_net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 1))
+        ref_net.load_state_dict(net.state_dict())
+        ref_net(xs[k]).sum().backward()
+        refs.append([p.grad.clone() for p in ref_net.parameters()])
+    # two accumulation micro-steps: only the last one exchanges
+    opt.sync_grads = False
+    (net(xs[rank]).sum() * 0.5).backward()
+    assert all(sl["work"] is None for sl in opt.slices)
+    opt.sync_grads = True
+    (net(xs[rank]).sum() * 0.5).backward()
+    assert all(sl["work"] is not None for sl in opt.slices)
+    opt._finish_exchange()
+    for p, a, b in zip(net.parameters(), refs[0], refs[1]):
+        assert p.grad.data_ptr() >= opt.flat_grad.data_ptr()
+        assert torch.allclose(p.grad / world, (a + b) / 2, atol=1e-6)
+    opt.zero_grad()
+    assert opt.flat_grad.abs().max().item() == 0
     dist.destroy_process_group()
     q.put(rank)
 
