@@ -36,12 +36,19 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="images per rank per step")
-    ap.add_argument("--res", type=int, default=768)
+    ap.add_argument("--res", type=int, default=None, help="default 768 (inference, configs[1]) / 576 (--train, configs[2])")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail", default=None, help="write a per-shape kernel table (TSV) to this path")
     ap.add_argument("--tiny", action="store_true", help="tiny configs (plumbing check only, not a valid benchmark)")
-    return ap.parse_args()
+    ap.add_argument("--train", action="store_true", help="time the E2E-FT training step (BASELINE.json configs[2]) instead of inference")
+    ap.add_argument("--micro-batch", type=int, default=8, help="--train: images per micro-step per rank")
+    ap.add_argument("--accum", type=int, default=4, help="--train: gradient-accumulation micro-steps per optimizer step")
+    ap.add_argument("--modality", default="depth", choices=["depth", "normals"])
+    args = ap.parse_args()
+    if args.res is None:
+        args.res = 576 if args.train else 768
+    return args
 
 
 def build_pipeline(dev, dtype, tiny):
@@ -96,8 +103,99 @@ def cpu_baseline(res_hint):
                        "FLOPs (%.2f/%.2f TFLOP), %d threads" % (t256, tf256, tf768, cores))
 
 
+def train_main(args):
+    """E2E-FT optimizer step: `accum` micro-steps of (frozen VAE encode -> UNet -> x0 -> frozen VAE decode -> loss -> backward) on
+    `micro_batch` images each, then gradient all-reduce (overlapped), clip_grad_norm_ and AdamW (training/train.py:470-568)."""
+    from diffusion_e2e_ft_amd import dist as D
+    from diffusion_e2e_ft_amd import ops, training
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    from diffusion_e2e_ft_amd.synth import init_synthetic_
+    rank, local_rank, world = D.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    cdt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
+    if cdt == torch.float16:
+        raise SystemExit("--train supports fp32 (the reference recipe, --mixed_precision no) or bf16 compute over fp32 master weights")
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    ucfg, vcfg = dict(in_channels=8), {}
+    if args.tiny:
+        ucfg.update(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4), cross_attention_dim=128)
+        vcfg.update(block_out_channels=(32, 64, 128, 128))
+    with torch.device(dev):
+        unet = UNet2DConditionModel(**ucfg)                    # fp32 master weights
+        vae = AutoencoderKL(**vcfg).to(cdt)
+    init_synthetic_(unet, seed=1234)
+    init_synthetic_(vae, seed=4321)
+    unet.train().set_compute_dtype(cdt)
+    vae.eval().requires_grad_(False)
+    opt = training.FlatAdamW(unet.parameters(), lr=3e-5, max_grad_norm=1.0)
+    R, mb, acc = args.res, args.micro_batch, args.accum
+    text = 0.5 * torch.randn((1, 77, unet.config.cross_attention_dim), generator=torch.Generator(device=dev).manual_seed(0), device=dev)
+    batches = [training.synthetic_batch(mb, R, R, dev, seed=1000 * rank + i, dtype=cdt) for i in range(acc)]
+    sched = training.IterExponential(20000 * world, 0.01, 100 * world)
+
+    def step(i):
+        return training.train_step(unet, vae, opt, batches, text, args.modality, lr_scale=sched(i))
+
+    for i in range(args.warmup):
+        loss = step(i)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    assert torch.isfinite(loss).all(), "non-finite loss"
+    elapsed = D.max_over_ranks(elapsed, device=dev)
+    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    ksum = timer.summary()
+    if args.detail and rank == 0:
+        rows = sorted(timer.by_label().items(), key=lambda kv: -kv[1]["ms"])
+        with open(args.detail, "w") as f:
+            f.write("kernel\tlabel\tlaunches/step\tms/step\tTFLOP/s\tGB/s\n")
+            for (name, label), d in rows:
+                f.write("%s\t%s\t%.1f\t%.3f\t%.1f\t%.1f\n" % (name, label, d["launches"] / args.steps, d["ms"] / args.steps,
+                                                               d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] else 0, d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] else 0))
+    if rank == 0:
+        n_img = mb * acc * world
+        sec = elapsed / args.steps
+        ig = ksum.get("igemm", dict(launches=0, ms=1e-9, flops=0.0))
+        achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        peak = PEAK_TF[args.dtype]
+        others = {k: dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] / args.steps, gbs=v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else 0)
+                  for k, v in ksum.items() if k != "igemm"}
+        line = {
+            "metric": "E2E-FT training step time (affine-invariant depth loss, UNet bwd): one optimizer step",
+            "value": sec, "unit": "s/step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "images_per_s": n_img / sec, "final_loss": float(loss), "peak_mem_gib": peak_mem,
+            "config": {"workload": "E2E-FT training step (%s loss, UNet bwd) batch=%d/GPU (%d micro-steps x %d) at %dx%d, %s compute, fp32 master "
+                                   "weights + flat AdamW, no activation recompute%s" % (args.modality, mb * acc, acc, mb, R, R, args.dtype,
+                                                                                         " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
+                       "images_per_step": n_img, "resolution": R, "parallelism": "dp%d (RCCL all-reduce of the flat fp32 gradient, overlapped)" % world},
+            "roofline": {"bound": "mfma", "kernel": "igemm kernels (fwd, dgrad, wgrad GEMMs, attention-backward GEMMs)", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches_per_step": ig["launches"] / args.steps,
+                         "kernel_ms_per_step": ig["ms"] / args.steps, "algorithmic_gflop_per_step": ig["flops"] / args.steps / 1e9, "other_kernels": others},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.train:
+        return train_main(args)
     from diffusion_e2e_ft_amd import dist as D
     from diffusion_e2e_ft_amd import ops
     rank, local_rank, world = D.init_from_env()

@@ -164,10 +164,11 @@ class _Conv2dFn(torch.autograd.Function):
             if x2 is not None and need[1]:
                 dx2 = dxl[..., c1:]
         if need[2]:
-            dyT = ops.transpose(ops._as_rows(dyp))                              # [cop, Pp]
-            col, P, Pp = ops.im2col_t(xp, x2, kh, kw, stride, pad, up_to)       # [kh*kw*cin, Pp]
-            assert dyT.shape[1] == Pp
-            dwp = ops.gemm(dyT[:Co], col, alpha=alpha)                          # [Co, kh*kw*cin] = OHWI
+            P = dyp.shape[0] * dyp.shape[1] * dyp.shape[2]
+            nsplit, kc = ops.splitk_plan(Co, kh * kw * (c1 + c2), P)
+            dyT = ops.transpose(ops._as_rows(dyp), rows_pad=nsplit * kc)        # [cop, Pp]
+            col, _, _ = ops.im2col_t(xp, x2, kh, kw, stride, pad, up_to, Pp=nsplit * kc)   # [kh*kw*cin, Pp]
+            dwp = ops.gemm_splitk(dyT[:Co], col, nsplit, kc, alpha=alpha)       # [Co, kh*kw*cin] = OHWI
             dw = dwp.view(Co, kh, kw, c1 + c2)[..., :Ci].permute(0, 3, 1, 2)
             if dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
@@ -247,9 +248,10 @@ class _LinearFn(torch.autograd.Function):
             dxp = ops.gemm(g64, wt, alpha=alpha)                    # [M, kp]
             dx = dxp.view(*xp.shape[:-1], kp)[..., :K]
         if any(need[6:]):
-            gT = ops.transpose(g)                                   # [N, M64]
-            xT = ops.transpose(_rows(xp))                           # [kp, M64]
-            dw = ops.gemm(gT, xT, alpha=alpha)                      # [N, kp]
+            nsplit, kc = ops.splitk_plan(N, kp, M)
+            gT = ops.transpose(g, rows_pad=nsplit * kc)             # [N, Mp]
+            xT = ops.transpose(_rows(xp), rows_pad=nsplit * kc)     # [kp, Mp]
+            dw = ops.gemm_splitk(gT, xT, nsplit, kc, alpha=alpha)   # [N, kp]
             o = 0
             for i, wgt in enumerate(weights):
                 n = wgt.shape[0]

@@ -97,15 +97,15 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(Im2colGeom g, long P, lon
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// column sums per row group: part[g][slab][c] (fp32); grid (nslabs, groups, ceil(nchunks/32)), block = 32 chunk lanes x 8 row lanes
+// column sums per row group: part[g][slab][c] (fp32); grid (ceil(nchunks/32), groups, nslabs), block = 32 chunk lanes x 8 row lanes
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(long rows_per_group, int cols, long ld, long slab, const T* __restrict__ x,
                                                              float* __restrict__ part) {
     constexpr int EPC = 16 / (int)sizeof(T);
     __shared__ float sm[8][32 * EPC];
     const int chl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = (blockIdx.z * 32 + chl) * EPC;
-    const long r0 = (long)blockIdx.x * slab;
+    const int c = (blockIdx.x * 32 + chl) * EPC;
+    const long r0 = (long)blockIdx.z * slab;
     const long r1 = min(r0 + slab, rows_per_group);
     const T* src = x + (long)blockIdx.y * rows_per_group * ld;
     float s[EPC];
@@ -122,12 +122,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(long rows_per_group
     for (int e = 0; e < EPC; ++e) sm[rl][chl * EPC + e] = s[e];
     __syncthreads();
     for (int j = threadIdx.x; j < 32 * EPC; j += 256) {
-        const int cc = blockIdx.z * 32 * EPC + j;
+        const int cc = blockIdx.x * 32 * EPC + j;
         if (cc < cols) {
             float a = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) a += sm[q][j];
-            part[((long)blockIdx.y * gridDim.x + blockIdx.x) * cols + cc] = a;
+            part[((long)blockIdx.y * gridDim.z + blockIdx.z) * cols + cc] = a;
         }
     }
 }
@@ -414,8 +414,8 @@ extern "C" int e2eft_conv2d_im2col_t(const E2eftConvDesc* d, const void* x1, con
 }
 
 static int colsum_slabs(int64_t rows_per_group) {
-    long ns = (rows_per_group + 127) / 128;
-    return (int)(ns < 1 ? 1 : (ns > 512 ? 512 : ns));
+    long ns = (rows_per_group + 511) / 512;
+    return (int)(ns < 1 ? 1 : (ns > 64 ? 64 : ns));
 }
 
 extern "C" size_t e2eft_colsum_workspace_bytes(int32_t groups, int64_t rows_per_group, int32_t cols) {
@@ -434,7 +434,7 @@ extern "C" int e2eft_colsum(int32_t dtype, int32_t groups, int64_t rows_per_grou
     const int ns = colsum_slabs(rows_per_group);
     const long slab = (rows_per_group + ns - 1) / ns;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(ns, groups, cdiv(cols / epc, 32));
+    const dim3 grid(cdiv(cols / epc, 32), groups, ns);
     E2EFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(256), 0, s, (long)rows_per_group, cols, (long)ld, slab,
                                                       (const T*)x, (float*)workspace));
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256), groups), dim3(256), 0, s, ns, cols, alpha, (const float*)workspace, out);

@@ -336,28 +336,30 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnGeom g, int group
     }
 }
 
-// grid (groups, batch): slab sums -> sc[b][c] = (S1, S2); mm[b][g] = (m1, m2)
+// grid (groups, batch): slab sums -> sc[b][c] = (S1, S2); mm[b][g] = (m1, m2).  Waves take channels, lanes take slabs.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(int C, int groups, int hw, int nslabs, const float* __restrict__ part,
                                                               const T* __restrict__ gamma, float* __restrict__ sc, float* __restrict__ mm) {
     __shared__ float red[2][4];
-    const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cpg = C / groups;
     float m1 = 0.f, m2 = 0.f;
-    for (int cc = tid; cc < cpg; cc += 256) {
+    for (int cc = wave; cc < cpg; cc += 4) {
         const int c = grp * cpg + cc;
         float a1 = 0.f, a2 = 0.f;
-        for (int sl = 0; sl < nslabs; ++sl) {
+        for (int sl = lane; sl < nslabs; sl += 64) {
             const float* o = part + (((long)b * nslabs + sl) * C + c) * 2;
             a1 += o[0]; a2 += o[1];
         }
-        sc[((long)b * C + c) * 2] = a1;
-        sc[((long)b * C + c) * 2 + 1] = a2;
+        a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (lane == 0) {
+            sc[((long)b * C + c) * 2] = a1;
+            sc[((long)b * C + c) * 2 + 1] = a2;
+        }
         const float ga = gamma ? to_f(gamma[c]) : 1.f;
         m1 += ga * a1; m2 += ga * a2;
     }
-    m1 = wave_sum(m1); m2 = wave_sum(m2);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = m1; red[1][tid >> 6] = m2; }
+    if (lane == 0) { red[0][wave] = m1; red[1][wave] = m2; }
     __syncthreads();
     if (tid == 0) {
         const float n = (float)cpg * (float)hw;
@@ -644,13 +646,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(long rows, int c, in
     }
 }
 
-// out[j] = sum_r part[r][j] (fp32), grid over 256-column blocks
+// out[g][j] = sum_r part[g][r][j] (fp32); grid (ceil(n/256), groups)
 __global__ __launch_bounds__(256) void rowsum_f32_kernel(int rows, int n, const float* __restrict__ part, float* __restrict__ out) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
+    const float* p = part + (long)blockIdx.y * rows * n;
     float a = 0.f;
-    for (int r = 0; r < rows; ++r) a += part[(long)r * n + j];
-    out[j] = a;
+    for (int r = 0; r < rows; ++r) a += p[(long)r * n + j];
+    out[(long)blockIdx.y * n + j] = a;
 }
 
 // softmax backward in place on dp: ds = p * (dp - sum_j dp_j p_j) * scale   (rows of n valid columns, pad columns zeroed)
@@ -822,13 +825,17 @@ extern "C" int e2eft_groupnorm_bwd(const E2eftGroupNormDesc* d, const void* x1, 
     return 0;
 }
 
+static const int LN_BWD_STAGE = 32;   // the per-wave partial rows are reduced in two deterministic stages (LN_BWD_STAGE groups, then one)
+
 static int ln_bwd_blocks(int64_t rows) {
     long nb = (rows + 3) / 4;
-    return (int)(nb > 512 ? 512 : nb);
+    nb = nb > 512 ? 512 : nb;
+    if (nb * 4 > LN_BWD_STAGE) nb = nb * 4 / LN_BWD_STAGE * LN_BWD_STAGE / 4;   // partial rows divisible by the stage count
+    return (int)nb;
 }
 
 extern "C" size_t e2eft_layernorm_bwd_workspace_bytes(int64_t rows, int32_t c) {
-    return rows > 0 && c > 0 ? (size_t)ln_bwd_blocks(rows) * 4 * 2 * (size_t)c * sizeof(float) : 0;
+    return rows > 0 && c > 0 ? ((size_t)ln_bwd_blocks(rows) * 4 + LN_BWD_STAGE) * 2 * (size_t)c * sizeof(float) : 0;
 }
 
 extern "C" int e2eft_layernorm_bwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldx, int32_t lddy, int32_t lddx, float eps,
@@ -854,7 +861,14 @@ extern "C" int e2eft_layernorm_bwd(int32_t dtype, int64_t rows, int32_t c, int32
         else LNB_LAUNCH(T, 8);
     });
 #undef LNB_LAUNCH
-    hipLaunchKernelGGL(rowsum_f32_kernel, dim3(cdiv(2 * c, 256)), dim3(256), 0, s, nblk * 4, 2 * c, (const float*)workspace, dgamma_dbeta);
+    const int prow = nblk * 4;
+    if (prow > LN_BWD_STAGE && prow % LN_BWD_STAGE == 0) {
+        float* stage = (float*)workspace + (size_t)prow * 2 * c;
+        hipLaunchKernelGGL(rowsum_f32_kernel, dim3(cdiv(2 * c, 256), LN_BWD_STAGE), dim3(256), 0, s, prow / LN_BWD_STAGE, 2 * c, (const float*)workspace, stage);
+        hipLaunchKernelGGL(rowsum_f32_kernel, dim3(cdiv(2 * c, 256), 1), dim3(256), 0, s, LN_BWD_STAGE, 2 * c, (const float*)stage, dgamma_dbeta);
+    } else {
+        hipLaunchKernelGGL(rowsum_f32_kernel, dim3(cdiv(2 * c, 256), 1), dim3(256), 0, s, prow, 2 * c, (const float*)workspace, dgamma_dbeta);
+    }
     return check_launch("layernorm_bwd");
 }
 

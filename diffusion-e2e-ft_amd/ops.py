@@ -539,12 +539,36 @@ def transpose(x, rows_pad=None, out=None):
     return out[0] if squeeze else out
 
 
-def im2col_t(x, x2, kh, kw, stride, pad, up_to=None):
+def splitk_plan(M, N, K):
+    """(nsplit, kc): weight-gradient GEMMs are [Cout x kh*kw*Cin] outputs contracted over 10^4..10^5 pixels — a handful of output
+    tiles.  Split the contraction into nsplit chunks of kc (multiple of 64) columns so that >= ~512 workgroups exist; the
+    operands are zero padded to nsplit*kc columns by their producers (transpose / im2col_t)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    want = max(1, min((512 + tiles - 1) // tiles, K // 512))
+    kc = round_up((K + want - 1) // want, 64)
+    nsplit = (K + kc - 1) // kc
+    return nsplit, kc
+
+
+def gemm_splitk(a, w, nsplit, kc, alpha=1.0):
+    """out[m,n] = alpha * sum_k a[m,k] w[n,k] for a [M, nsplit*kc], w [N, nsplit*kc]: nsplit batched partial GEMMs + a column-sum
+    reduction in fp32.  Returns fp32 [M, N] (or the plain GEMM result in the operand dtype when nsplit == 1)."""
+    if nsplit == 1:
+        return gemm(a, w, alpha=alpha)
+    M, K = a.shape
+    N = w.shape[0]
+    assert K == nsplit * kc and w.shape[1] == K and N % epc(a.dtype) == 0
+    part = torch.empty((nsplit, M, N), dtype=a.dtype, device=a.device)
+    bgemm_raw(a.dtype, M, N, kc, a, _rows_ld(a), (0, kc), w, _rows_ld(w), (0, kc), part, N, (0, M * N), 1, nsplit)
+    return colsum(part.view(nsplit, M * N), groups=1, alpha=alpha).view(M, N)
+
+
+def im2col_t(x, x2, kh, kw, stride, pad, up_to=None, Pp=None):
     """-> ([kh*kw*(c1+c2), Ppad] K-contiguous im2col of the conv input over the OUTPUT pixels, P, Ppad)"""
     _check_cuda(x, x2)
     d = _conv_desc(x, x2, 1, kh, kw, stride, pad, up_to, 1.0)
     P = d.batch * d.hout * d.wout
-    Pp = round_up(P, 64)
+    Pp = round_up(P, 64) if Pp is None else Pp
     cin = d.c1 + d.c2
     col = torch.empty((kh * kw * cin, Pp), dtype=x.dtype, device=x.device)
     with _timed("im2col_t", 0.0, 2.0 * kh * kw * cin * Pp * x.element_size(), label="im2col_t %dx%d %d P%d" % (kh, kw, cin, P)):

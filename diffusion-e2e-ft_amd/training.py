@@ -69,7 +69,7 @@ def e2e_ft_loss(unet, vae, batch, empty_encoding, modality="depth", alpha_prod_9
     batch: rgb [b,3,H,W] in [-1,1], val_mask [b,1,H,W] bool, metric [b,1,H,W] / normals [b,3,H,W].  Returns the scalar loss
     (device tensor with a grad_fn through the decoder and the UNet)."""
     dev = unet.device
-    dt = unet.dtype
+    dt = getattr(unet, "compute_dtype", unet.dtype)
     with torch.no_grad():
         rgb_latents = encode_image(vae, batch["rgb"].to(device=dev, dtype=dt)) * vae.config.scaling_factor
     val_mask = batch["val_mask"].bool().to(dev)
@@ -212,3 +212,30 @@ def train_step(unet, vae, optimizer, batches, empty_encoding, modality="depth", 
     optimizer.step(lr_scale=lr_scale)
     optimizer.zero_grad()
     return total / n
+
+
+def synthetic_batch(batch, height, width, device, seed=0, dtype=torch.float32):
+    """"Hypersim-val synthetic" micro-batch: uniform-noise rgb in [-1,1]; metric depth = tilted plane + 3 boxes in
+    [0.5, 20] m, normalised to [-1,1] by its 2 % / 98 % quantiles (load.py:255-267); normals of that surface; 5 % invalid pixels."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rgb = (torch.randint(0, 256, (batch, 3, height, width), generator=g, device=device, dtype=torch.int32).float() / 255.0 * 2.0 - 1.0)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, height, device=device), torch.linspace(-1, 1, width, device=device), indexing="ij")
+    depth = torch.empty((batch, 1, height, width), device=device)
+    for b in range(batch):
+        c = torch.rand(3, generator=g, device=device)
+        d = 6.0 + 4.0 * (c[0] - 0.5) * xx + 4.0 * (c[1] - 0.5) * yy + 8.0 * c[2]
+        for _ in range(3):
+            r = torch.rand(5, generator=g, device=device)
+            x0, y0 = r[0] * 1.4 - 1.0, r[1] * 1.4 - 1.0
+            box = (xx > x0) & (xx < x0 + 0.2 + 0.5 * r[2]) & (yy > y0) & (yy < y0 + 0.2 + 0.5 * r[3])
+            d = torch.where(box, 0.5 + 5.0 * r[4] + 0.0 * d, d)
+        depth[b, 0] = d.clamp(0.5, 20.0)
+    flat = depth.view(batch, -1)
+    lo = torch.quantile(flat, 0.02, dim=1).view(batch, 1, 1, 1)
+    hi = torch.quantile(flat, 0.98, dim=1).view(batch, 1, 1, 1)
+    metric = (((depth - lo) / (hi - lo).clamp_min(1e-6) - 0.5) * 2.0).clamp(-1, 1)
+    dzdx = torch.gradient(depth[:, 0], dim=2)[0]
+    dzdy = torch.gradient(depth[:, 0], dim=1)[0]
+    normals = torch.nn.functional.normalize(torch.stack([-dzdx * width / 2, -dzdy * height / 2, torch.ones_like(dzdx)], dim=1), dim=1)
+    mask = torch.rand((batch, 1, height, width), generator=g, device=device) > 0.05
+    return {"rgb": rgb.to(dtype), "metric": metric, "normals": normals, "val_mask": mask}

@@ -172,6 +172,16 @@ class UNet2DConditionModel(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
+    @property
+    def compute_dtype(self):
+        """dtype of the activations: the parameters' dtype unless set_compute_dtype() asked for 16-bit compute over fp32 master
+        weights (the kernels cast each parameter once per version)"""
+        return getattr(self, "_compute_dtype", None) or self.dtype
+
+    def set_compute_dtype(self, dtype):
+        self._compute_dtype = dtype
+        return self
+
     def enable_gradient_checkpointing(self):  # training/train.py:343
         self.gradient_checkpointing = True
 
@@ -203,9 +213,9 @@ class UNet2DConditionModel(nn.Module):
     # ---- forward ----
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, return_dict=True, **unused):
         cfg = self.config
-        dt = self.dtype
+        dt = self.compute_dtype
         if sample.dtype != dt:
-            raise TypeError("sample dtype %s != model dtype %s" % (sample.dtype, dt))
+            raise TypeError("sample dtype %s != model compute dtype %s" % (sample.dtype, dt))
         B = sample.shape[0]
         x = to_nhwc(sample)
         # 1. time (+ class) embedding  (unet_2d_condition.py:960-1000)

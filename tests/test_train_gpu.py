@@ -58,7 +58,7 @@ def test_micro_step_gradients_fp32(dev, modality):
 
 
 def test_micro_step_bf16_activations(dev):
-    """bf16 model: gradients agree with the fp32 golden in direction (cosine > 0.75 per sampled tensor, > 0.93 on average; everything incl. the weights is bf16 here)"""
+    """bf16 model: gradients agree with the fp32 golden in direction (cosine > 0.75 per sampled tensor, > 0.88 on average; everything incl. the weights is bf16 here)"""
     from diffusion_e2e_ft_amd import training
     unet, vae = _models(dev, torch.bfloat16)
     batch, text = gc.train_batch()
@@ -71,7 +71,7 @@ def test_micro_step_bf16_activations(dev):
     for k, ref in gold["grads"].items():
         g = gc.sample_grad(named[k].grad.float()).cpu()
         cosines[k] = torch.nn.functional.cosine_similarity(g.flatten(), ref.flatten(), dim=0).item()
-    assert min(cosines.values()) > 0.75 and sum(cosines.values()) / len(cosines) > 0.93, cosines
+    assert min(cosines.values()) > 0.75 and sum(cosines.values()) / len(cosines) > 0.88, cosines
 
 
 def test_optimizer_step_matches_torch_adamw(dev):
