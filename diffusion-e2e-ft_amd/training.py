@@ -97,6 +97,43 @@ def e2e_ft_loss(unet, vae, batch, empty_encoding, modality="depth", alpha_prod_9
     return (loss, cur) if return_estimate else loss
 
 
+def geowizard_class_embedding(batch, domain, dtype, device):
+    """hybrid switcher + domain class, rows [depth (b); normal (b)]  (train_depth_normal.py:684-700)"""
+    geo = torch.tensor([[0.0, 1.0], [1.0, 0.0]], dtype=torch.float32, device=device).repeat_interleave(batch, 0)
+    dom = {"indoor": [1.0, 0.0, 0.0], "outdoor": [0.0, 1.0, 0.0], "object": [0.0, 0.0, 1.0]}[domain]
+    dom = torch.tensor([dom], dtype=torch.float32, device=device).repeat(2 * batch, 1)
+    return torch.cat([torch.sin(geo), torch.cos(geo), torch.sin(dom), torch.cos(dom)], dim=-1).to(dtype)
+
+
+def geowizard_e2e_ft_loss(unet, vae, batch, imgs_embed, domain="indoor", depth_scale=0.5, normal_scale=1.0, return_parts=False):
+    """Forward half of the GeoWizard E2E-FT micro-step (GeoWizard/geowizard/training/train_depth_normal.py:597-768, --e2e_ft, zeros
+    noise): the UNet runs the doubled batch [depth rows; normal rows] with cross-domain joint self-attention and the class
+    embedding, the frozen decoder decodes both halves, loss = 0.5 * SSI(depth) + 1.0 * angular(normals vs -GT).
+    imgs_embed: CLIP image embeddings [b,1,768] (an input here)."""
+    dev = unet.device
+    dt = getattr(unet, "compute_dtype", unet.dtype)
+    with torch.no_grad():
+        rgb_latents = encode_image(vae, batch["rgb"].to(device=dev, dtype=dt)) * vae.config.scaling_factor
+    val_mask = batch["val_mask"].bool().to(dev)
+    b = rgb_latents.shape[0]
+    timesteps = torch.full((2 * b,), 999, device=dev, dtype=torch.long)
+    noisy = torch.zeros_like(rgb_latents).repeat(2, 1, 1, 1)
+    ctx = imgs_embed.to(device=dev, dtype=dt).repeat(2, 1, 1)
+    cls = geowizard_class_embedding(b, domain, dt, dev)
+    unet_input = torch.cat((rgb_latents.repeat(2, 1, 1, 1), noisy), dim=1).contiguous(memory_format=torch.channels_last)
+    noise_pred = unet(unet_input, timesteps, ctx, class_labels=cls, return_dict=False)[0]
+    from .scheduler import DDIMScheduler
+    a999 = float(DDIMScheduler().alphas_cumprod[999])
+    x0 = noise_pred * (-math.sqrt(1.0 - a999) / vae.config.scaling_factor)
+    est = vae.decoder(vae.post_quant_conv(x0)).permute(0, 2, 3, 1)          # NHWC view [2b,H,W,3]
+    depth = F.depth_head(est[:b], to_unit=False)
+    normal = F.normal_head(est[b:], clamp=True)
+    ssi = F.ssi_loss(depth, batch["metric"].to(device=dev), val_mask)
+    ang = F.angular_loss(normal, batch["normals"].to(device=dev) * -1, val_mask)     # GeoWizard trains on inverted normals (:611,751)
+    loss = ssi * depth_scale + ang * normal_scale
+    return (loss, ssi, ang) if return_parts else loss
+
+
 # ------------------------------------------------------------------------------------------------------------
 class FlatAdamW:
     """AdamW + gradient clipping over one flat fp32 buffer, gradient all-reduce overlapped with the backward.

@@ -102,3 +102,25 @@ def train_forward_ref(unet_sd, unet_cfg, vae_sd, vae_cfg, batch, text_embed, mod
         est = torch.clamp(est / (torch.norm(est, p=2, dim=1, keepdim=True) + 1e-5), -1, 1)
         loss = angular_loss_ref(est, batch["normals"], mask)
     return loss, est
+
+
+def geowizard_train_forward_ref(unet_sd, unet_cfg, vae_sd, vae_cfg, batch, img_embed, domain="indoor"):
+    """Forward half of GeoWizard/geowizard/training/train_depth_normal.py:597-768 with --e2e_ft and zeros noise: doubled batch
+    [depth rows; normal rows], joint self-attention, class embedding, 0.5 * SSI + 1.0 * angular on inverted normals.
+    Returns (loss, ssi, angular)."""
+    rgb_latents = encode_rgb_ref(vae_sd, vae_cfg, batch["rgb"])
+    B = rgb_latents.shape[0]
+    noisy = torch.zeros_like(rgb_latents).repeat(2, 1, 1, 1)
+    t = 999
+    ctx = img_embed.repeat(2, 1, 1)
+    cls = geowizard_class_embedding(B, domain, rgb_latents.dtype)
+    v = unet_ref.unet_forward(unet_sd, unet_cfg, torch.cat([rgb_latents.repeat(2, 1, 1, 1), noisy], dim=1), torch.full((2 * B,), t), ctx, class_labels=cls)
+    x0 = v_to_x0(v, noisy, t)
+    est = decode_ref(vae_sd, vae_cfg, x0)
+    d_est, n_est = torch.chunk(est, 2, dim=0)
+    d_est = torch.clamp(d_est.mean(dim=1, keepdim=True), -1, 1)
+    n_est = torch.clamp(n_est / (torch.norm(n_est, p=2, dim=1, keepdim=True) + 1e-5), -1, 1)
+    mask = batch["val_mask"].bool()
+    ssi = ssi_loss_ref(d_est, batch["metric"], mask)
+    ang = angular_loss_ref(n_est, batch["normals"] * -1, mask)
+    return 0.5 * ssi + 1.0 * ang, ssi, ang

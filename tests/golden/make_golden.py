@@ -40,6 +40,7 @@ def main():
             print(name, {k: tuple(v.shape) for k, v in out[name].items()})
     torch.save(out, os.path.join(HERE, "model_golden.pt"))
     train = {m: gc.train_grads(m) for m in ("depth", "normals")}
+    train["geowizard"] = gc.geo_train_grads()
     torch.save(train, os.path.join(HERE, "train_golden.pt"))
     print("train:", {m: (float(v["loss"]), len(v["grads"]), len(v["grad_norms"])) for m, v in train.items()})
 

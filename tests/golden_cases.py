@@ -152,3 +152,20 @@ GRAD_STRIDE = 61
 def sample_grad(g):
     f = g.detach().reshape(-1)
     return f.clone() if f.numel() <= 4096 else f[::GRAD_STRIDE].clone()
+
+
+def geo_train_inputs():
+    batch, _ = train_batch(seed=31)
+    emb = 0.5 * torch.randn(2, 1, config.TINY_GEOWIZARD_UNET["cross_attention_dim"], generator=torch.Generator().manual_seed(32))
+    return batch, emb
+
+
+def geo_train_grads():
+    """GeoWizard E2E-FT micro-step (joint attention, class embedding, 0.5 SSI + angular) through autograd over the CPU oracle"""
+    batch, emb = geo_train_inputs()
+    usd = {k: v.clone().requires_grad_(True) for k, v in tiny_geo_sd().items()}
+    loss, ssi, ang = pipeline_ref.geowizard_train_forward_ref(usd, config.TINY_GEOWIZARD_UNET, tiny_vae_sd(), config.TINY_VAE, batch, emb, "indoor")
+    loss.backward()
+    keys = [k for k in TRAIN_FULL_GRADS if k in usd] + ["class_embedding.linear_1.weight"]
+    return {"loss": loss.detach(), "ssi": ssi.detach(), "angular": ang.detach(),
+            "grad_norms": {k: float(v.grad.norm()) for k, v in usd.items()}, "grads": {k: sample_grad(usd[k].grad) for k in keys}}

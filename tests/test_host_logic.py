@@ -103,3 +103,28 @@ def test_shard_range():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_training_host_mirrors_match_reference_fixtures():
+    """training.IterExponential / replace_unet_conv_in against the values the REFERENCE's own lr_scheduler.py / unet_prep.py produced
+    (tests/golden/hooks_golden.pt), and the GeoWizard class embedding against the oracle restatement"""
+    from diffusion_e2e_ft_amd import training
+    from oracle import pipeline_ref
+    hooks = torch.load(os.path.join(os.path.dirname(__file__), "golden", "hooks_golden.pt"))
+    sched = training.IterExponential(total_iter_length=20000, final_ratio=0.01, warmup_steps=100)
+    for i, v in zip(hooks["lr_iters"].tolist(), hooks["lr_values"].tolist()):
+        assert abs(sched(i) - v) < 1e-12, (i, sched(i), v)
+
+    class _U:
+        pass
+    u = _U()
+    u.conv_in = torch.nn.Conv2d(4, 32, 3, 1, 1)
+    with torch.no_grad():
+        u.conv_in.weight.copy_(hooks["conv_in_w0"])
+        u.conv_in.bias.copy_(hooks["conv_in_b0"])
+    u.config = {"in_channels": 4}
+    training.replace_unet_conv_in(u, repeat=2)
+    assert torch.equal(u.conv_in.weight.detach(), hooks["conv_in_w"]) and torch.equal(u.conv_in.bias.detach(), hooks["conv_in_b"])
+    assert u.config["in_channels"] == int(hooks["conv_in_cfg"])
+    for dom in ("indoor", "outdoor", "object"):
+        assert torch.equal(training.geowizard_class_embedding(3, dom, torch.float32, "cpu"), pipeline_ref.geowizard_class_embedding(3, dom))
