@@ -42,16 +42,42 @@ template <> struct MmaA<bf16> {
     }
 };
 
-template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    union { T t[2]; uint32_t u; } x;
-    x.t[0] = from_f<T>(lo);
-    x.t[1] = from_f<T>(hi);
-    return x.u;
-}
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bhalf2v __attribute__((ext_vector_type(2)));
 
-// grid (ceil(nq/128), heads, batch)
-template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+// pack two fp32 into one dword of T (v_cvt_pk_{f16,bf16}_f32) and add both halves of a packed dword to an fp32 accumulator
+// (v_dot2c_f32_{f16,bf16} with a packed (1, 1)): the softmax row sum then costs one instruction per key PAIR and is taken over
+// the rounded probabilities the second MFMA actually multiplies with.
+template <typename T> struct Pk;
+template <> struct Pk<f16> {
+    __device__ static __forceinline__ uint32_t pack(float lo, float hi) {
+        const float2v f = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2v));
+    }
+    __device__ static __forceinline__ float add2(uint32_t w, float acc) {
+        const half2v one = {(f16)1.f, (f16)1.f};
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w), one, acc, false);
+    }
+};
+template <> struct Pk<bf16> {
+    __device__ static __forceinline__ uint32_t pack(float lo, float hi) {
+        const float2v f = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bhalf2v));
+    }
+    __device__ static __forceinline__ float add2(uint32_t w, float acc) {
+        const bhalf2v one = {(bf16)1.f, (bf16)1.f};
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bhalf2v, w), one, acc, false);
+    }
+};
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return Pk<T>::pack(lo, hi); }
+
+// grid (ceil(nq/128), heads, batch).  JOINT: keys come from kv_nseg = 2 batch-strided segments (GeoWizard), which costs an
+// integer division per loaded row; the plain case indexes keys linearly.
+// launch_bounds(256, 2): two workgroups per CU caps the wave at 256 registers, which makes the compiler keep the MFMA
+// accumulators in VGPRs — with the 512-register budget it parks O^T / S^T in AGPRs and pays a v_accvgpr_read + write per
+// element per tile for the online-softmax rescale (measured: 255 of ~600 VALU instructions per tile).
+template <typename T, bool JOINT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KVBUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -82,23 +108,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const int kvb0 = b % p.kv_bmod;
 
     auto key_row = [&](int j) -> long {  // global row index (in rows of the [kv_batch*nk_seg] matrix) of key j
+        if (!JOINT) return (long)kvb0 * p.nk_seg + j;
         const int seg = j / p.nk_seg;
         return (long)(kvb0 + seg * p.kv_bmod) * p.nk_seg + (j - seg * p.nk_seg);
     };
 
     u32x4 rk[2], rv[2];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
     auto load_tile = [&](int t) {
         const int base = t * 64;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int j = base + k_r0 + 32 * i;
-            rk[i] = j < p.nk_total ? *reinterpret_cast<const u32x4*>(K + key_row(j) * p.ldk + head * 64 + k_kc * 8) : zero4;
+            const int j = min(base + k_r0 + 32 * i, p.nk_total - 1);   // rows past the end: scores are masked below, p = 0
+            rk[i] = *reinterpret_cast<const u32x4*>(K + key_row(j) * p.ldk + head * 64 + k_kc * 8);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int j = base + 2 * v_kp + i;
-            rv[i] = j < p.nk_total ? *reinterpret_cast<const u32x4*>(V + key_row(j) * p.ldv + head * 64 + v_vc * 8) : zero4;
+            const int j = min(base + 2 * v_kp + i, p.nk_total - 1);
+            rv[i] = *reinterpret_cast<const u32x4*>(V + key_row(j) * p.ldv + head * 64 + v_vc * 8);
         }
     };
     auto store_tile = [&](int buf) {
@@ -109,9 +135,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         // transpose: V^T[8 vc + e][2 kp, 2 kp + 1]
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const uint32_t lo = (rv[0][e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-            const uint32_t hi = (rv[1][e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-            *reinterpret_cast<uint32_t*>(sv + (8 * v_vc + e) * VROW + v_kp * 4) = lo | (hi << 16);
+            // one v_perm_b32 per pair: {low halves} or {high halves} of the two keys' dwords
+            const uint32_t w = __builtin_amdgcn_perm(rv[1][e >> 1], rv[0][e >> 1], (e & 1) ? 0x07060302u : 0x05040100u);
+            *reinterpret_cast<uint32_t*>(sv + (8 * v_vc + e) * VROW + v_kp * 4) = w;
         }
     };
 
@@ -169,29 +195,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
         const float mc = m_new * p.c;
         m_run = m_new;
+        // probabilities, packed straight into the B operand of the second MFMA; row sums from the packed words
+        uint32_t pw[2][8];
         float psum = 0.f;
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt2][r], p.c, -mc));
-                s[kt2][r] = e;
-                psum += e;
+            for (int w = 0; w < 8; ++w) {
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(s[kt2][2 * w], p.c, -mc));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(s[kt2][2 * w + 1], p.c, -mc));
+                pw[kt2][w] = Pk<T>::pack(e0, e1);
+                psum = Pk<T>::add2(pw[kt2][w], psum);
             }
         l_run = l_run * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // the running max settles after a few tiles: skip the rescale then
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
 
         // ---- O^T += V^T P^T ----
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                u32x4 pf;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) pf[w] = pack2<T>(s[kt2][8 * s2 + 2 * w], s[kt2][8 * s2 + 2 * w + 1]);
+                const u32x4 pf = {pw[kt2][4 * s2], pw[kt2][4 * s2 + 1], pw[kt2][4 * s2 + 2], pw[kt2][4 * s2 + 3]};
                 const int kb = (kt2 * 32 + 16 * s2 + 4 * hh) * 2;  // byte offset of the first 4-key run
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -250,7 +279,13 @@ extern "C" int e2eft_attn_fwd(const E2eftAttnDesc* d, const void* q, const void*
     p.c = d->scale * 1.4426950408889634f;
     dim3 grid(cdiv(d->nq, 128), d->heads, d->batch);
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == E2EFT_F16) hipLaunchKernelGGL((attn_fwd_kernel<f16>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<bf16>), grid, dim3(256), 0, s, p);
+    const bool joint = d->kv_nseg > 1;
+    if (d->dtype == E2EFT_F16) {
+        if (joint) hipLaunchKernelGGL((attn_fwd_kernel<f16, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<f16, false>), grid, dim3(256), 0, s, p);
+    } else {
+        if (joint) hipLaunchKernelGGL((attn_fwd_kernel<bf16, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<bf16, false>), grid, dim3(256), 0, s, p);
+    }
     return check_launch("attn_fwd");
 }
