@@ -45,18 +45,12 @@ template <> struct MmaA<bf16> {
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bhalf2v __attribute__((ext_vector_type(2)));
 
-// pack two fp32 into one dword of T (v_cvt_pk_{f16,bf16}_f32) and add both halves of a packed dword to an fp32 accumulator
-// (v_dot2c_f32_{f16,bf16} with a packed (1, 1)): the softmax row sum then costs one instruction per key PAIR and is taken over
-// the rounded probabilities the second MFMA actually multiplies with.
+// pack two fp32 into one dword of T with a single v_cvt_pk_{f16,bf16}_f32
 template <typename T> struct Pk;
 template <> struct Pk<f16> {
     __device__ static __forceinline__ uint32_t pack(float lo, float hi) {
         const float2v f = {lo, hi};
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2v));
-    }
-    __device__ static __forceinline__ float add2(uint32_t w, float acc) {
-        const half2v one = {(f16)1.f, (f16)1.f};
-        return __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w), one, acc, false);
     }
 };
 template <> struct Pk<bf16> {
@@ -64,15 +58,12 @@ template <> struct Pk<bf16> {
         const float2v f = {lo, hi};
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bhalf2v));
     }
-    __device__ static __forceinline__ float add2(uint32_t w, float acc) {
-        const bhalf2v one = {(bf16)1.f, (bf16)1.f};
-        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bhalf2v, w), one, acc, false);
-    }
 };
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return Pk<T>::pack(lo, hi); }
 
 // grid (ceil(nq/128), heads, batch).  JOINT: keys come from kv_nseg = 2 batch-strided segments (GeoWizard), which costs an
 // integer division per loaded row; the plain case indexes keys linearly.
+// Measured dead ends: s_setprio(1) around the MFMA phases (771 -> 697 TF/s), v_dot2c row sums on the packed probabilities (717).
 // launch_bounds(256, 2): two workgroups per CU caps the wave at 256 registers, which makes the compiler keep the MFMA
 // accumulators in VGPRs — with the 512-register budget it parks O^T / S^T in AGPRs and pays a v_accvgpr_read + write per
 // element per tile for the online-softmax rescale (measured: 255 of ~600 VALU instructions per tile).
@@ -195,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
         const float mc = m_new * p.c;
         m_run = m_new;
-        // probabilities, packed straight into the B operand of the second MFMA; row sums from the packed words
+        // probabilities, packed straight into the B operand of the second MFMA
         uint32_t pw[2][8];
         float psum = 0.f;
 #pragma unroll
@@ -205,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 const float e0 = __builtin_amdgcn_exp2f(fmaf(s[kt2][2 * w], p.c, -mc));
                 const float e1 = __builtin_amdgcn_exp2f(fmaf(s[kt2][2 * w + 1], p.c, -mc));
                 pw[kt2][w] = Pk<T>::pack(e0, e1);
-                psum = Pk<T>::add2(pw[kt2][w], psum);
+                psum += e0 + e1;   // (v_dot2c on the packed word is one instruction per pair but measured slower beside the MFMAs: 717 vs 771 TF/s)
             }
         l_run = l_run * alpha + psum;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // the running max settles after a few tiles: skip the rescale then
