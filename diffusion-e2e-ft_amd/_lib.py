@@ -63,6 +63,9 @@ SIGNATURES = {
     "e2eft_geglu_fwd": (_I, [_I, _L, _I, _I, _I, _P, _P, _P]),
     "e2eft_softmax_rows": (_I, [_I, _L, _I, _L, _F, _P, _P]),
     "e2eft_attn_fwd": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
+    "e2eft_attn_fwd_lse": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P]),
+    "e2eft_attn_bwd_workspace_bytes": (_Z, [C.POINTER(AttnDesc)]),
+    "e2eft_attn_bwd": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
     "e2eft_nchw_to_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "e2eft_nhwc_to_nchw": (_I, [_I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "e2eft_copy_scale": (_I, [_I, _L, _I, _I, _I, _F, _F, _P, _P, _P]),

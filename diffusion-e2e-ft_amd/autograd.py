@@ -406,9 +406,13 @@ def _attn_core_unfused(q, k, v, heads, scale):
     return o
 
 
+FLASH_BACKWARD = True   # tests flip this to cross-check the fused backward against the GEMM + softmax form
+
+
 class _AttentionFn(torch.autograd.Function):
     """Attention core on packed projections: self-attention takes qkv [B,N,3C]; cross-attention q [B,N,C] + kv [B,L,2C].
-    Forward: the flash kernel (16-bit, d = 64) or the GEMM + softmax form.  Backward recomputes P = softmax(q k^T) and runs
+    Forward: the flash kernel (16-bit, d = 64) or the GEMM + softmax form.  Backward: the fused kernels of csrc/attn_bwd.hip for
+    the flash case; otherwise (fp32, VAE's 512-dim head) it recomputes P = softmax(q k^T) and runs
         dP = dO V^T,  dS = P o (dP - rowsum(dP o P)) * scale,  dQ = dS K,  dK = dS^T Q,  dV = P^T dO
     as batched MFMA GEMMs; the pixel-major operands (K^T, Q^T, dO^T, P^T, dS^T) come from e2eft_transpose."""
 
@@ -417,16 +421,17 @@ class _AttentionFn(torch.autograd.Function):
         C = qkv.shape[-1] // 3 if kv is None else qkv.shape[-1]
         q, k, v = _attn_views(qkv, kv, C)
         if qkv.dtype != torch.float32 and C // heads == 64:
-            o = ops.attention(q, k, v, heads, scale)
+            o, lse = ops.attention(q, k, v, heads, scale, return_lse=True)
+            ctx.save_for_backward(qkv, kv, o, lse)
         else:
             o = _attn_core_unfused(q, k, v, heads, scale)
-        ctx.save_for_backward(qkv, kv)
+            ctx.save_for_backward(qkv, kv)
         ctx.meta = (heads, scale, C)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, kv = ctx.saved_tensors
+        qkv, kv = ctx.saved_tensors[:2]
         heads, scale, C = ctx.meta
         q, k, v = _attn_views(qkv, kv, C)
         B, N, _ = q.shape
@@ -434,6 +439,18 @@ class _AttentionFn(torch.autograd.Function):
         d = C // heads
         dt = q.dtype
         do = do.contiguous()
+        if len(ctx.saved_tensors) == 4 and FLASH_BACKWARD:      # fused backward (e2eft_attn_bwd): no N x Nk matrix in HBM
+            o, lse = ctx.saved_tensors[2:]
+            if kv is None:
+                dqkv = torch.empty(qkv.shape, dtype=dt, device=qkv.device)
+                dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+                dkv = None
+            else:
+                dqkv = torch.empty(q.shape, dtype=dt, device=q.device)
+                dkv = torch.empty(kv.shape, dtype=dt, device=q.device)
+                dq, dk, dv = dqkv, dkv[..., :C], dkv[..., C:]
+            ops.attention_bwd(q, k, v, o, do, lse, heads, scale, dq, dk, dv)
+            return dqkv, dkv, None, None
         z = B * heads
         # P = softmax(scale * q k^T)
         p, nkp = _scores(q, k, heads, dt)

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libe2eft.so")
-SOURCES = ["api.hip", "igemm.hip", "igemm2.hip", "norm.hip", "attn.hip", "elementwise.hip", "loss.hip", "bwd.hip"]
+SOURCES = ["api.hip", "igemm.hip", "igemm2.hip", "norm.hip", "attn.hip", "attn_bwd.hip", "elementwise.hip", "loss.hip", "bwd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

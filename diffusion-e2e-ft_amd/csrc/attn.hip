@@ -28,6 +28,7 @@ struct AttnParams {
     int batch, heads, nq, nk_seg, kv_nseg, kv_bmod, nk_total;
     int ldq, ldk, ldv, ldo;
     float c;  // scale * log2(e)
+    float* lse;  // optional [batch][heads][nq]: log2-sum-exp of the scaled scores (saved for e2eft_attn_bwd)
 };
 
 template <typename T> struct MmaA;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
     const int qr = q0 + l31;
+    if (p.lse && hh == 0 && qr < p.nq) p.lse[((long)b * p.heads + head) * p.nq + qr] = m_run * p.c + __builtin_amdgcn_logf(l_tot);
     if (qr < p.nq) {
         T* dst = (T*)p.out + ((long)b * p.nq + qr) * p.ldo + head * 64;
 #pragma unroll
@@ -251,6 +253,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 using namespace e2eft;
 
 extern "C" int e2eft_attn_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, void* stream) {
+    return e2eft_attn_fwd_lse(d, q, k, v, out, nullptr, stream);
+}
+
+extern "C" int e2eft_attn_fwd_lse(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, float* lse, void* stream) {
     E2EFT_REQUIRE(d && q && k && v && out, "attn: null pointer");
     E2EFT_REQUIRE(d->dtype == E2EFT_F16 || d->dtype == E2EFT_BF16, "attn: dtype %d unsupported (fp16/bf16 only; fp32 uses the unfused path)", d->dtype);
     E2EFT_REQUIRE(d->batch > 0 && d->heads > 0 && d->nq > 0 && d->nk_seg > 0, "attn: geometry");
@@ -268,6 +274,7 @@ extern "C" int e2eft_attn_fwd(const E2eftAttnDesc* d, const void* q, const void*
     p.kv_nseg = d->kv_nseg; p.kv_bmod = d->kv_bmod; p.nk_total = d->nk_seg * d->kv_nseg;
     p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo;
     p.c = d->scale * 1.4426950408889634f;
+    p.lse = lse;
     dim3 grid(cdiv(d->nq, 128), d->heads, d->batch);
     hipStream_t s = (hipStream_t)stream;
     const bool joint = d->kv_nseg > 1;

@@ -356,34 +356,59 @@ def softmax_rows_(s, n, scale):
     return s
 
 
-def attention(q, k, v, heads, scale, kv_nseg=1, kv_bmod=None, out=None):
-    """Fused attention, head dim 64. q: [B,Nq,heads*64] view, k/v: [Bkv,Nk,heads*64] views (row-strided)."""
-    _check_cuda(q, k, v, out)
+def _ld3(t):
+    if t.shape[2] > 1 and t.stride(2) != 1:
+        raise ValueError("attention operands need unit inner stride")
+    ld = t.stride(1) if t.shape[1] > 1 else max(t.shape[2], t.stride(1))
+    if t.shape[0] > 1 and t.stride(0) != t.shape[1] * ld:
+        raise ValueError("attention operands must be batch-dense: %s %s" % (tuple(t.shape), t.stride()))
+    return ld
+
+
+def _attn_desc(q, k, v, out, heads, scale, kv_nseg, kv_bmod):
     B, Nq, Wd = q.shape
     Bkv, Nk, _ = k.shape
     assert Wd == heads * 64 and k.shape[2] == Wd and v.shape == k.shape
-    if out is None:
-        out = torch.empty((B, Nq, Wd), dtype=q.dtype, device=q.device)
     d = AttnDesc()
     d.dtype = dtype_id(q.dtype)
     d.batch, d.heads, d.nq, d.nk_seg = B, heads, Nq, Nk
     d.kv_nseg = kv_nseg
     d.kv_bmod = B if kv_bmod is None else kv_bmod
     assert Bkv >= d.kv_bmod * kv_nseg
-
-    def ld3(t):
-        if t.shape[2] > 1 and t.stride(2) != 1:
-            raise ValueError("attention operands need unit inner stride")
-        ld = t.stride(1) if t.shape[1] > 1 else max(t.shape[2], t.stride(1))
-        if t.shape[0] > 1 and t.stride(0) != t.shape[1] * ld:
-            raise ValueError("attention operands must be batch-dense: %s %s" % (tuple(t.shape), t.stride()))
-        return ld
-
-    d.ldq, d.ldk, d.ldv, d.ldo = ld3(q), ld3(k), ld3(v), ld3(out)
+    d.ldq, d.ldk, d.ldv, d.ldo = _ld3(q), _ld3(k), _ld3(v), _ld3(out)
     d.scale = scale
+    return d
+
+
+def attention(q, k, v, heads, scale, kv_nseg=1, kv_bmod=None, out=None, return_lse=False):
+    """Fused attention, head dim 64. q: [B,Nq,heads*64] view, k/v: [Bkv,Nk,heads*64] views (row-strided).
+    return_lse: also return the [B, heads, Nq] fp32 log-sum-exp the fused backward needs."""
+    _check_cuda(q, k, v, out)
+    B, Nq, Wd = q.shape
+    Nk = k.shape[1]
+    if out is None:
+        out = torch.empty((B, Nq, Wd), dtype=q.dtype, device=q.device)
+    d = _attn_desc(q, k, v, out, heads, scale, kv_nseg, kv_bmod)
+    lse = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device) if return_lse else None
     with _timed("attn", 4.0 * B * heads * Nq * Nk * kv_nseg * 64, label="attn B%d h%d Nq%d Nk%d" % (B, heads, Nq, Nk * kv_nseg)):
-        check(_lib.load().e2eft_attn_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _stream()))
-    return out
+        check(_lib.load().e2eft_attn_fwd_lse(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _stream()))
+    return (out, lse) if return_lse else out
+
+
+def attention_bwd(q, k, v, out, dout, lse, heads, scale, dq, dk, dv):
+    """Fused attention backward (head dim 64, 16-bit): writes dq / dk / dv (row-strided views shaped like q / k / v)."""
+    _check_cuda(q, k, v, out, dout, lse, dq, dk, dv)
+    B, Nq, Wd = q.shape
+    Nk = k.shape[1]
+    d = _attn_desc(q, k, v, out, heads, scale, 1, None)
+    assert dout.shape == out.shape and dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
+    assert lse.shape == (B, heads, Nq) and lse.dtype == torch.float32 and lse.is_contiguous()
+    lib = _lib.load()
+    nbytes = lib.e2eft_attn_bwd_workspace_bytes(C.byref(d))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+    with _timed("attn_bwd", 14.0 * B * heads * Nq * Nk * 64, label="attn_bwd B%d h%d Nq%d Nk%d" % (B, heads, Nq, Nk)):
+        check(lib.e2eft_attn_bwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ld3(dout), _ptr(lse), _ptr(dq), _ld3(dq), _ptr(dk), _ld3(dk),
+                                 _ptr(dv), _ld3(dv), _ptr(ws), nbytes, _stream()))
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -168,6 +168,17 @@ typedef struct E2eftAttnDesc {
 } E2eftAttnDesc;
 
 int e2eft_attn_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, void* stream);
+/* same, also storing lse[batch][heads][nq] (fp32): the base-2 log-sum-exp of the scaled scores of every query row, which
+ * e2eft_attn_bwd needs to recompute the probabilities (lse may be NULL) */
+int e2eft_attn_fwd_lse(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, float* lse, void* stream);
+/* Fused attention backward (head dim 64, fp16 / bf16, kv_nseg == 1; autograd of F.scaled_dot_product_attention /
+ * xformers.memory_efficient_attention in diffusers Attention processors, attention.py:338-343,375-380): dq [B,Nq,heads*64],
+ * dk / dv [B,Nk,heads*64] (row strides lddq / lddk / lddv), from q, k, v, the forward output `out` (desc ldo), its gradient
+ * dout and the forward's lse.  No Nq x Nk matrix is materialised.  workspace: batch*heads*nq floats. */
+size_t e2eft_attn_bwd_workspace_bytes(const E2eftAttnDesc* d);
+int e2eft_attn_bwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, const void* out, const void* dout,
+                   int32_t lddo, const float* lse, void* dq, int32_t lddq, void* dk, int32_t lddk, void* dv, int32_t lddv,
+                   void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Elementwise / layout glue on the path.
