@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--micro-batch", type=int, default=8, help="--train: images per micro-step per rank")
     ap.add_argument("--accum", type=int, default=4, help="--train: gradient-accumulation micro-steps per optimizer step")
     ap.add_argument("--modality", default="depth", choices=["depth", "normals"])
+    ap.add_argument("--no-train-leg", action="store_true", help="inference mode at N=1: skip the short E2E-FT training-step measurement "
+                    "that is appended to the JSON line as `train_step`")
     args = ap.parse_args()
     if args.res is None:
         args.res = 576 if args.train else 768
@@ -104,17 +106,27 @@ def cpu_baseline(res_hint):
 
 
 def train_main(args):
+    from diffusion_e2e_ft_amd import dist as D
+    rank, local_rank, world = D.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    line = run_train(args, rank, world, torch.device("cuda", local_rank))
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def run_train(args, rank, world, dev):
     """E2E-FT optimizer step: `accum` micro-steps of (frozen VAE encode -> UNet -> x0 -> frozen VAE decode -> loss -> backward) on
-    `micro_batch` images each, then gradient all-reduce (overlapped), clip_grad_norm_ and AdamW (training/train.py:470-568)."""
+    `micro_batch` images each, then gradient all-reduce (overlapped), clip_grad_norm_ and AdamW (training/train.py:470-568).
+    Returns the JSON line (rank 0) or None."""
     from diffusion_e2e_ft_amd import dist as D
     from diffusion_e2e_ft_amd import ops, training
     from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
     from diffusion_e2e_ft_amd.vae import AutoencoderKL
     from diffusion_e2e_ft_amd.synth import init_synthetic_
-    rank, local_rank, world = D.init_from_env()
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     cdt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
     if cdt == torch.float16:
         raise SystemExit("--train supports fp32 (the reference recipe, --mixed_precision no) or bf16 compute over fp32 master weights")
@@ -186,10 +198,8 @@ def train_main(args):
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches_per_step": ig["launches"] / args.steps,
                          "kernel_ms_per_step": ig["ms"] / args.steps, "algorithmic_gflop_per_step": ig["flops"] / args.steps / 1e9, "other_kernels": others},
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        return line
+    return None
 
 
 def main():
@@ -276,6 +286,19 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(R)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        if world == 1 and not args.no_train_leg and not args.tiny:
+            # second part of BASELINE.json's metric ("...; E2E-FT step time"): configs[2], batch 32 at 576x576, one GPU
+            try:
+                del pipe, out, rgb, img
+                torch.cuda.empty_cache()
+                targs = argparse.Namespace(**vars(args))
+                targs.dtype, targs.res, targs.steps, targs.warmup, targs.detail = "bf16", 576, 2, 1, None
+                t = run_train(targs, 0, 1, dev)
+                line["train_step"] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "images_per_s", "dtype", "steps", "warmup", "peak_mem_gib")}
+                line["train_step"]["workload"] = t["config"]["workload"]
+                line["train_step"]["roofline"] = {k: t["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac")}
+            except Exception as e:
+                line["train_step"] = {"value": None, "error": repr(e)}
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
