@@ -127,3 +127,30 @@ def test_oracle_reproduces_model_golden():
             now = gc.MODEL_CASES[name]()
             for k, v in now.items():
                 assert torch.allclose(v, gold[name][k], rtol=1e-4, atol=1e-5), (name, k)
+
+
+def test_absrel_metric_restatement_matches_reference():
+    """oracle/metric_ref.py vs the reference's alignment.py / metric.py on seeded data"""
+    import importlib.util
+    import numpy as np
+    from oracle import metric_ref
+    base = "/root/reference/Marigold/src/util"
+    if not os.path.isdir(base):
+        pytest.skip("reference tree not present")
+
+    def imp(name):
+        spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(base, name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    al, me = imp("alignment"), imp("metric")
+    g = torch.Generator().manual_seed(5)
+    gt = torch.rand(48, 64, generator=g) * 9 + 1
+    pred = (gt - 2.0) / 7.0 + 0.03 * torch.randn(48, 64, generator=g)
+    mask = torch.rand(48, 64, generator=g) > 0.1
+    a_ref, s_ref, t_ref = al.align_depth_least_square(gt.numpy(), pred.numpy(), mask.numpy())
+    a, s_, t_ = metric_ref.align_depth_least_square_ref(gt.numpy(), pred.numpy(), mask.numpy())
+    assert abs(s_ - float(s_ref)) < 1e-5 * abs(float(s_ref)) and abs(t_ - float(t_ref)) < 1e-5 and np.allclose(a, a_ref, rtol=1e-5, atol=1e-5)
+    x = torch.from_numpy(a_ref).float()
+    assert torch.allclose(metric_ref.abs_relative_difference_ref(x, gt, mask), me.abs_relative_difference(x.clone(), gt, mask), rtol=1e-6)
+    assert torch.allclose(metric_ref.abs_relative_difference_ref(x, gt), me.abs_relative_difference(x.clone(), gt), rtol=1e-6)
