@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="images per rank per step")
     ap.add_argument("--res", type=int, default=None, help="default 768 (inference, configs[1]) / 576 (--train, configs[2])")
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--dtype", default=None, choices=["fp16", "bf16", "fp32"], help="default fp16 (inference, configs[1]) / bf16 (--train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail", default=None, help="write a per-shape kernel table (TSV) to this path")
     ap.add_argument("--tiny", action="store_true", help="tiny configs (plumbing check only, not a valid benchmark)")
@@ -51,6 +51,8 @@ def parse():
     args = ap.parse_args()
     if args.res is None:
         args.res = 576 if args.train else 768
+    if args.dtype is None:
+        args.dtype = "bf16" if args.train else "fp16"
     return args
 
 

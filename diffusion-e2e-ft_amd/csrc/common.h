@@ -58,7 +58,7 @@ template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>&
     *reinterpret_cast<u32x4*>(p) = v.raw;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // v_rcp_f32: 1 ulp, no division sequence
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

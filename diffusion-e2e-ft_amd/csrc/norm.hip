@@ -173,9 +173,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnGeom g, int silu, int l
         mu[e] = ad[((long)b * g.C + c + e) * 2 + 1];
         be[e] = beta ? to_f(beta[c + e]) : 0.f;
     }
-    for (int pix = p0 + pl; pix < p1; pix += g.pl) {
-        const long row = (long)b * g.hw + pix;
-        Vec16<T> v = ld16(src + row * ld);
+    auto one = [&](long row, const Vec16<T>& v) {
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -184,6 +182,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnGeom g, int silu, int l
             o.e[e] = from_f<T>(t);
         }
         st16(y + row * ldy + c, o);
+    };
+    int pix = p0 + pl;
+    for (; pix + 3 * g.pl < p1; pix += 4 * g.pl) {   // four independent 16-byte loads in flight per thread
+        const long row = (long)b * g.hw + pix;
+        Vec16<T> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld16(src + (row + (long)u * g.pl) * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(row + (long)u * g.pl, v[u]);
+    }
+    for (; pix < p1; pix += g.pl) {
+        const long row = (long)b * g.hw + pix;
+        one(row, ld16(src + row * ld));
     }
 }
 
@@ -279,7 +290,7 @@ __device__ __forceinline__ void gn_bwd_load(GnBwdCoef<T, EPC>& k, int b, int c, 
     }
 }
 __device__ __forceinline__ float silu_grad_f(float z) {
-    const float sg = 1.f / (1.f + __expf(-z));
+    const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-z));
     return sg * (1.f + z * (1.f - sg));
 }
 
@@ -308,9 +319,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnGeom g, int group
     if (active) {
         GnBwdCoef<T, EPC> k;
         gn_bwd_load<T, EPC>(k, b, c, g.C, groups, ad, rstd, beta);
-        for (int pix = p0 + pl; pix < p1; pix += g.pl) {
-            const long row = (long)b * g.hw + pix;
-            Vec16<T> v = ld16(src + row * ld), d = ld16(dy + row * lddy + c);
+        auto one = [&](const Vec16<T>& v, const Vec16<T>& d) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const float xc = to_f(v.e[e]) - k.mu[e];
@@ -319,6 +328,18 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnGeom g, int group
                 s1[e] += dz;
                 s2[e] += dz * xc * k.rs[e];
             }
+        };
+        int pix = p0 + pl;
+        for (; pix + g.pl < p1; pix += 2 * g.pl) {
+            const long row = (long)b * g.hw + pix;
+            const Vec16<T> v0 = ld16(src + row * ld), d0 = ld16(dy + row * lddy + c);
+            const Vec16<T> v1 = ld16(src + (row + g.pl) * ld), d1 = ld16(dy + (row + g.pl) * lddy + c);
+            one(v0, d0);
+            one(v1, d1);
+        }
+        for (; pix < p1; pix += g.pl) {
+            const long row = (long)b * g.hw + pix;
+            one(ld16(src + row * ld), ld16(dy + row * lddy + c));
         }
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -398,9 +419,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnGeom g, int groups,
         k2[e] = k.rs[e] * mm[((long)b * groups + grp) * 2];
         k3[e] = k.rs[e] * k.rs[e] * mm[((long)b * groups + grp) * 2 + 1];
     }
-    for (int pix = p0 + pl; pix < p1; pix += g.pl) {
-        const long row = (long)b * g.hw + pix;
-        Vec16<T> v = ld16(src + row * ld), d = ld16(dy + row * lddy + c), o;
+    auto one = [&](long row, const Vec16<T>& v, const Vec16<T>& d) {
+        Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const float xc = to_f(v.e[e]) - k.mu[e];
@@ -409,6 +429,18 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnGeom g, int groups,
             o.e[e] = from_f<T>(k1[e] * dz - k2[e] - xc * k3[e]);
         }
         st16(dx + row * lddx + c, o);
+    };
+    int pix = p0 + pl;
+    for (; pix + g.pl < p1; pix += 2 * g.pl) {   // two pixel rows (four 16-byte loads) in flight per thread
+        const long row = (long)b * g.hw + pix;
+        const Vec16<T> v0 = ld16(src + row * ld), d0 = ld16(dy + row * lddy + c);
+        const Vec16<T> v1 = ld16(src + (row + g.pl) * ld), d1 = ld16(dy + (row + g.pl) * lddy + c);
+        one(row, v0, d0);
+        one(row + g.pl, v1, d1);
+    }
+    for (; pix < p1; pix += g.pl) {
+        const long row = (long)b * g.hw + pix;
+        one(row, ld16(src + row * ld), ld16(dy + row * lddy + c));
     }
 }
 
