@@ -115,19 +115,36 @@ def _rows(t):
     return t.contiguous().reshape(-1, Cc)
 
 
+# GroupNorm statistics emitted by a producer's epilogue ride on the output tensor as a Python attribute (ops.GnStats).  An
+# autograd Function returns a fresh tensor object, so forward() parks the statistics here and the wrapper re-attaches them.
+_LAST_STATS = [None]
+
+
+def _stash_stats(out):
+    _LAST_STATS[0] = getattr(out, "_e2eft_gn", None)
+
+
+def _attach_stats(y):
+    st, _LAST_STATS[0] = _LAST_STATS[0], None
+    if st is not None:
+        y._e2eft_gn = st
+    return y
+
+
 # ------------------------------------------------------------------------------------------------------------
 class _Conv2dFn(torch.autograd.Function):
     """out = alpha * (conv(cat(x, x2)) + bias + rowadd[b]) + residual — forward e2eft_conv2d_fwd, backward e2eft_conv2d_dgrad
     (+ e2eft_upsample_nearest_bwd), e2eft_transpose + e2eft_conv2d_im2col_t + e2eft_gemm (wgrad), e2eft_colsum (bias / rowadd)."""
 
     @staticmethod
-    def forward(ctx, x, x2, weight, bias, rowadd, residual, conv, stride, pad, up_to, alpha):
+    def forward(ctx, x, x2, weight, bias, rowadd, residual, conv, stride, pad, up_to, alpha, gn_stats):
         dt = x.dtype
         kh, kw = weight.shape[2:]
         cout = weight.shape[0]
         xp = ops.pad_channels(x) if x2 is None else x     # 3/4-channel inputs: zero padded copy (weights are packed to match)
         out = ops.conv2d(xp, packed_conv_weight(conv, dt), _vec(bias, dt), cout, kh, kw, stride, pad, x2=x2, up_to=up_to,
-                         rowadd=rowadd, residual=residual, alpha=alpha, gn_stats=False)
+                         rowadd=rowadd, residual=residual, alpha=alpha, gn_stats=gn_stats)
+        _stash_stats(out)
         ctx.save_for_backward(xp, x2, weight, bias)
         ctx.conv, ctx.geom = conv, (stride, pad, up_to, alpha, x.shape[3])
         ctx.has = (rowadd is not None, residual is not None)
@@ -172,7 +189,7 @@ class _Conv2dFn(torch.autograd.Function):
             dw = dwp.view(Co, kh, kw, c1 + c2)[..., :Ci].permute(0, 3, 1, 2)
             if dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
-        return dx, dx2, dw, dbias, drow, dres, None, None, None, None, None
+        return dx, dx2, dw, dbias, drow, dres, None, None, None, None, None, None
 
 
 def conv(conv_mod, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0, pad=None, gn_stats=True):
@@ -183,7 +200,7 @@ def conv(conv_mod, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0
         p = conv_mod.padding[0] if isinstance(conv_mod.padding, tuple) else conv_mod.padding
         pad = (p, p, p, p)
     if needs_grad(x, x2, conv_mod.weight, conv_mod.bias, rowadd, residual):
-        return _Conv2dFn.apply(x, x2, conv_mod.weight, conv_mod.bias, rowadd, residual, conv_mod, stride, tuple(pad), up_to, alpha)
+        return _attach_stats(_Conv2dFn.apply(x, x2, conv_mod.weight, conv_mod.bias, rowadd, residual, conv_mod, stride, tuple(pad), up_to, alpha, gn_stats))
     dt = x.dtype
     if x2 is None:
         x = ops.pad_channels(x)
@@ -213,13 +230,14 @@ class _LinearFn(torch.autograd.Function):
     """y = alpha * (x W^T + b) + residual with W = cat(weights) along the output dim (fused q/k/v projections)."""
 
     @staticmethod
-    def forward(ctx, x, bias, residual, owner, name, alpha, *weights):
+    def forward(ctx, x, bias, residual, owner, name, alpha, gn_rows, *weights):
         dt = x.dtype
         K = x.shape[-1]
         kp = ops.round_up(K, ops.epc(dt))
         xp = torch.nn.functional.pad(x, (0, kp - K)) if kp != K else x
         w = _cat_weight(owner, name, weights, dt, kp)
-        y = ops.linear(xp, w, _vec(bias, dt), residual=residual, alpha=alpha)
+        y = ops.linear(xp, w, _vec(bias, dt), residual=residual, alpha=alpha, gn_rows_per_image=gn_rows)
+        _stash_stats(y)
         ctx.save_for_backward(xp, bias, *weights)
         ctx.meta = (owner, name, alpha, K, residual is not None)
         return y
@@ -247,7 +265,7 @@ class _LinearFn(torch.autograd.Function):
                 g64 = g
             dxp = ops.gemm(g64, wt, alpha=alpha)                    # [M, kp]
             dx = dxp.view(*xp.shape[:-1], kp)[..., :K]
-        if any(need[6:]):
+        if any(need[7:]):
             nsplit, kc = ops.splitk_plan(N, kp, M)
             gT = ops.transpose(g, rows_pad=nsplit * kc)             # [N, Mp]
             xT = ops.transpose(_rows(xp), rows_pad=nsplit * kc)     # [kp, Mp]
@@ -255,13 +273,13 @@ class _LinearFn(torch.autograd.Function):
             o = 0
             for i, wgt in enumerate(weights):
                 n = wgt.shape[0]
-                if need[6 + i]:
+                if need[7 + i]:
                     t = dw[o:o + n, :K]
                     dws[i] = t if t.dtype == wgt.dtype else t.to(wgt.dtype)
                 o += n
         if bias is not None and need[1]:
             dbias = ops.colsum(g, groups=1, alpha=alpha)[0].to(bias.dtype)
-        return (dx, dbias, dres, None, None, None, *dws)
+        return (dx, dbias, dres, None, None, None, None, *dws)
 
 
 def linear(x, weights, bias=None, residual=None, alpha=1.0, owner=None, name="w", gn_rows_per_image=0):
@@ -270,7 +288,7 @@ def linear(x, weights, bias=None, residual=None, alpha=1.0, owner=None, name="w"
     if not isinstance(weights, (tuple, list)):
         weights = (weights,)
     if needs_grad(x, bias, residual, *weights):
-        return _LinearFn.apply(x, bias, residual, owner, name, alpha, *weights)
+        return _attach_stats(_LinearFn.apply(x, bias, residual, owner, name, alpha, gn_rows_per_image, *weights))
     dt = x.dtype
     K = x.shape[-1]
     kp = ops.round_up(K, ops.epc(dt))
@@ -282,9 +300,9 @@ def linear(x, weights, bias=None, residual=None, alpha=1.0, owner=None, name="w"
 # ------------------------------------------------------------------------------------------------------------
 class _GroupNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x2, gamma, beta, groups, eps, silu):
+    def forward(ctx, x, x2, gamma, beta, groups, eps, silu, s1, s2):
         dt = x.dtype
-        y, ws = ops.groupnorm_fwd_ws(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, x2=x2)
+        y, ws = ops.groupnorm_fwd_ws(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, x2=x2, s1=s1, s2=s2)
         ctx.save_for_backward(x, x2, gamma, beta, ws)
         ctx.meta = (groups, eps, silu)
         return y
@@ -303,12 +321,13 @@ class _GroupNormFn(torch.autograd.Function):
         dx, dg, db = ops.groupnorm_bwd(x, x2, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu, g, ws, need_dx=want_dx, need_dparams=want_p)
         d1 = dx[..., :c1] if (need[0] and dx is not None) else None
         d2 = dx[..., c1:] if (x2 is not None and need[1]) else None
-        return d1, d2, (dg.to(gamma.dtype) if need[2] else None), (db.to(beta.dtype) if need[3] else None), None, None, None
+        return d1, d2, (dg.to(gamma.dtype) if need[2] else None), (db.to(beta.dtype) if need[3] else None), None, None, None, None, None
 
 
 def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None):
     if needs_grad(x, x2, gamma, beta):
-        return _GroupNormFn.apply(x, x2, gamma, beta, groups, eps, silu)
+        return _GroupNormFn.apply(x, x2, gamma, beta, groups, eps, silu, getattr(x, "_e2eft_gn", None),
+                                  getattr(x2, "_e2eft_gn", None) if x2 is not None else None)
     dt = x.dtype
     return ops.groupnorm(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, x2=x2)
 

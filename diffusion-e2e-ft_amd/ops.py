@@ -648,8 +648,9 @@ def upsample_nearest_bwd(dy, H, W):
     return dx
 
 
-def groupnorm_fwd_ws(x, gamma, beta, groups, eps, silu=False, x2=None):
-    """GroupNorm forward that also returns its workspace (mean / rstd live there) for groupnorm_bwd."""
+def groupnorm_fwd_ws(x, gamma, beta, groups, eps, silu=False, x2=None, s1=None, s2=None):
+    """GroupNorm forward that also returns its workspace (mean / rstd live there) for groupnorm_bwd.  s1 / s2: GnStats of x / x2
+    emitted by their producers (statistics pass skipped for that source)."""
     _check_cuda(x, gamma, beta, x2)
     B, H, W, c1 = x.shape
     c2 = 0 if x2 is None else x2.shape[3]
@@ -660,8 +661,13 @@ def groupnorm_fwd_ws(x, gamma, beta, groups, eps, silu=False, x2=None):
     if nbytes == 0:
         raise RuntimeError("groupnorm: %s" % lib.e2eft_last_error().decode())
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
-    with _timed("groupnorm", 0.0, 3.0 * B * H * W * (c1 + c2) * x.element_size(), label="gn B%d %dx%d C%d" % (B, H, W, c1 + c2)):
-        check(lib.e2eft_groupnorm_fwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), nbytes, _stream()))
+    if not GN_STATS_ENABLED:
+        s1 = s2 = None
+    with _timed("groupnorm", 0.0, 2.0 * B * H * W * (c1 + c2) * x.element_size(), label="gn B%d %dx%d C%d" % (B, H, W, c1 + c2)):
+        check(lib.e2eft_groupnorm_fwd_pre(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out),
+                                          _ptr(s1.partial) if s1 else C.c_void_p(0), s1.nslabs if s1 else 0,
+                                          _ptr(s2.partial) if (s2 and x2 is not None) else C.c_void_p(0), s2.nslabs if (s2 and x2 is not None) else 0,
+                                          _ptr(ws), nbytes, _stream()))
     return out, ws
 
 
