@@ -190,7 +190,7 @@ def run_train(args, rank, world, dev):
     if rank == 0:
         n_img = mb * acc * world
         sec = elapsed / args.steps
-        ig = ksum.get("igemm", dict(launches=0, ms=1e-9, flops=0.0))
+        ig = ksum.get("igemm", dict(launches=0, ms=1e-9, flops=0.0, bytes=0.0))
         achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         peak = PEAK_TF[args.dtype]
         others = {k: dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] / args.steps, gbs=v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else 0)
@@ -265,7 +265,7 @@ def main():
     if rank == 0:
         n_img = B * world * args.steps
         value = n_img / elapsed
-        ig = ksum.get("igemm", dict(launches=0, ms=1e-9, flops=0.0))
+        ig = ksum.get("igemm", dict(launches=0, ms=1e-9, flops=0.0, bytes=0.0))
         achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         peak = PEAK_TF[args.dtype]
         extra = {}
@@ -274,6 +274,16 @@ def main():
                 kk = ksum[k]
                 extra[k] = dict(launches_per_step=kk["launches"] / args.steps, ms_per_step=kk["ms"] / args.steps,
                                 tflops=kk["flops"] / (kk["ms"] * 1e-3) / 1e12, gbs=kk["bytes"] / (kk["ms"] * 1e-3) / 1e9)
+        # HBM bytes per igemm launch from the PMC counters: collected offline (rocprofv3 --pmc cannot wrap its own process) on exactly
+        # this workload and committed with its provenance; null for any other workload
+        traffic, traffic_note = None, "no PMC profile for this workload"
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(pmc) and (B, R, args.dtype, args.tiny) == (8, 768, "fp16", False):
+            with open(pmc) as f:
+                pj = json.load(f)
+            traffic = pj["kernels"]["igemm2"]["hbm_bytes_per_launch"]
+            traffic_note = "bytes per launch (average over the %d igemm launches of a step), profiles/r01_pmc_hbm_traffic.json: %s" % (
+                ig["launches"] / args.steps, pj["source"])
         line = {
             "metric": "images/sec (768x768, 1-step UNet fwd) full path: VAE encode + SD-v2 UNet @t=999 + VAE decode",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -282,8 +292,9 @@ def main():
             "config": {"workload": "marigold-e2e-ft-depth 1-step inference, batch=%d/GPU at %dx%d %s, random-init SD-v2 UNet (866M) + SD VAE (84M)%s"
                                    % (B, R, R, args.dtype, " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
                        "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world},
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, all launches of the timed region)",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": "igemm2_kernel (implicit-GEMM conv/linear, all launches of the timed region)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_note": traffic_note, "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
                          "launches_per_step": ig["launches"] / args.steps, "kernel_ms_per_step": ig["ms"] / args.steps,
                          "algorithmic_gflop_per_step": ig["flops"] / args.steps / 1e9, "other_kernels": extra},
         }

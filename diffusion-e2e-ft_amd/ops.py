@@ -73,6 +73,10 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def dtype_size(dtype):
+    return 4 if dtype == torch.float32 else 2
+
+
 def epc(dtype):
     """elements per 16-byte chunk"""
     return 4 if dtype == torch.float32 else 8
@@ -188,7 +192,9 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
     if rowadd is not None:
         assert rowadd.dtype == x.dtype and tuple(rowadd.shape) == (B, cout) and rowadd.is_contiguous()
     want = gn_stats and GN_STATS_ENABLED and cout % 8 == 0
-    with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2),
+    es = x.element_size()
+    nb = (B * H * W * (d.c1 + d.c2) + B * hout * wout * cout * (2 if residual is not None else 1) + cout * kh * kw * (d.c1 + d.c2)) * es
+    with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2), nb,
                 label="conv%dx%ds%d%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", B, hout, wout, d.c1 + d.c2, cout)):
         if want:
             buf, nbytes = _gn_buffer(B, hout * wout, cout, x.device)
@@ -225,7 +231,7 @@ def gemm(a, w, bias=None, residual=None, out=None, alpha=1.0, bias_along_m=False
     if residual is not None:
         assert tuple(residual.shape) == (M, N) and residual.dtype == a.dtype
     want = gn_rows_per_image > 0 and GN_STATS_ENABLED and N % 8 == 0 and M % gn_rows_per_image == 0 and not bias_along_m
-    with _timed("igemm", 2.0 * M * N * K, label="gemm M%d N%d K%d" % (M, N, K)):
+    with _timed("igemm", 2.0 * M * N * K, (M * K + N * K + M * N * (2 if residual is not None else 1)) * a.element_size(), label="gemm M%d N%d K%d" % (M, N, K)):
         if want:
             buf, nbytes = _gn_buffer(M // gn_rows_per_image, gn_rows_per_image, N, a.device)
             slab = C.c_int32(0)
@@ -252,7 +258,7 @@ def bgemm_raw(dtype, m, n, k, a, lda, sa, w, ldw, sw, out, ldo, so, nzo, nzi, bi
     d.sr_o = d.sr_i = 0
     d.bias_along_m = 1 if bias_along_m else 0
     d.alpha = alpha
-    with _timed("igemm", 2.0 * m * n * k * nzo * nzi, label="bgemm z%d M%d N%d K%d" % (nzo * nzi, m, n, k)):
+    with _timed("igemm", 2.0 * m * n * k * nzo * nzi, float(nzo * nzi) * (m * k + n * k + m * n) * dtype_size(dtype), label="bgemm z%d M%d N%d K%d" % (nzo * nzi, m, n, k)):
         check(_lib.load().e2eft_gemm(C.byref(d), _ptr(a), _ptr(w), _ptr(bias), _ptr(None), _ptr(out), _stream()))
     return out
 
