@@ -46,6 +46,8 @@ def parse():
                     "configs[2] batch in one pass, 122 GB of the 288 GB HBM; 16 in fp32)")
     ap.add_argument("--accum", type=int, default=None, help="--train: gradient-accumulation micro-steps per optimizer step (default 32 / micro-batch)")
     ap.add_argument("--modality", default="depth", choices=["depth", "normals"])
+    ap.add_argument("--geowizard", action="store_true", help="time GeoWizard joint depth+normals 1-step inference (BASELINE.json configs[4]: "
+                    "dual-latent UNet with cross-domain attention, 2 images per GPU by default) instead of Marigold depth")
     ap.add_argument("--no-train-leg", action="store_true", help="inference mode at N=1: skip the short E2E-FT training-step measurement "
                     "that is appended to the JSON line as `train_step`")
     args = ap.parse_args()
@@ -212,10 +214,77 @@ def run_train(args, rank, world, dev):
     return None
 
 
+def geowizard_main(args):
+    """GeoWizard joint depth + normals, one step: VAE encode -> UNet on the doubled batch (cross-domain joint self-attention, class
+    embedding, CLIP image embedding as an input tensor) -> two VAE decodes (geowizard_pipeline.py:252-344)."""
+    from diffusion_e2e_ft_amd import dist as D
+    from diffusion_e2e_ft_amd import ops
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    from diffusion_e2e_ft_amd.pipeline import DepthNormalEstimationPipeline
+    from diffusion_e2e_ft_amd.synth import init_synthetic_
+    rank, local_rank, world = D.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    with torch.device(dev):
+        unet = UNet2DConditionModel(in_channels=8, cross_attention_dim=768, class_embed_type="projection", projection_class_embeddings_input_dim=10,
+                                    joint_attention=True).to(dtype)
+        vae = AutoencoderKL().to(dtype)
+    init_synthetic_(unet, seed=1234)
+    init_synthetic_(vae, seed=4321)
+    pipe = DepthNormalEstimationPipeline(unet.eval(), vae.eval(), DDIMScheduler())
+    B, R = (args.batch if args.batch != 8 else 2), args.res
+    g = torch.Generator(device=dev).manual_seed(rank)
+    rgb = (torch.randint(0, 256, (B, 3, R, R), generator=g, device=dev, dtype=torch.int32).float() / 255.0 * 2.0 - 1.0).to(dtype)
+    emb = (0.5 * torch.randn((B, 1, 768), generator=g, device=dev)).to(dtype)
+    for _ in range(args.warmup):
+        out = pipe.single_infer(rgb, emb, "indoor")
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipe.single_infer(rgb, emb, "indoor")
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+    ops.TIMER = None
+    assert torch.isfinite(out[0].float()).all() and torch.isfinite(out[1].float()).all()
+    ksum = timer.summary()
+    if rank == 0:
+        ig = ksum.get("igemm", dict(launches=0, ms=1e-9, flops=0.0, bytes=0.0))
+        achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        at = ksum.get("attn", dict(launches=0, ms=0.0, flops=0.0))
+        line = {"metric": "images/sec (768x768, GeoWizard joint depth+normals, 1-step dual-latent UNet fwd) full path",
+                "value": B * world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f16" if args.dtype == "fp16" else args.dtype, "data": "synthetic",
+                "config": {"workload": "GeoWizard joint depth+normals 1-step (dual-latent UNet, cross-domain joint attention, class embedding), batch=%d/GPU at "
+                                       "%dx%d %s, random-init weights, CLIP image embedding as input" % (B, R, R, args.dtype),
+                           "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world},
+                "roofline": {"bound": "mfma", "kernel": "igemm2_kernel", "achieved": achieved, "peak": PEAK_TF[args.dtype], "unit": "TFLOP/s",
+                             "frac": achieved / PEAK_TF[args.dtype], "traffic": None, "launches_per_step": ig["launches"] / args.steps,
+                             "kernel_ms_per_step": ig["ms"] / args.steps,
+                             "other_kernels": {"attn": {"ms_per_step": at["ms"] / args.steps, "tflops": at["flops"] / (at["ms"] * 1e-3) / 1e12 if at["ms"] else 0.0}}}}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.train:
         return train_main(args)
+    if args.geowizard:
+        return geowizard_main(args)
     from diffusion_e2e_ft_amd import dist as D
     from diffusion_e2e_ft_amd import ops
     rank, local_rank, world = D.init_from_env()
