@@ -103,7 +103,7 @@ SIGNATURES = {
 
 
 def lib_path():
-    return _build.LIB
+    return os.environ.get("E2EFT_LIB", _build.LIB)   # E2EFT_LIB: load an instrumented build of the same sources (debugging only)
 
 
 def load():

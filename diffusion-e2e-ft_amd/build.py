@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libe2eft.so")
-SOURCES = ["api.hip", "igemm.hip", "igemm2.hip", "norm.hip", "attn.hip", "attn_bwd.hip", "elementwise.hip", "loss.hip", "bwd.hip"]
+SOURCES = ["api.hip", "igemm.hip", "igemm2.hip", "igemm3.hip", "norm.hip", "attn.hip", "attn_bwd.hip", "elementwise.hip", "loss.hip", "bwd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -67,5 +67,34 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_stamps(verbose=True):
+    """Instrumented twin of the library (lib/libe2eft_stamps.so, -DE2EFT_STAMPS): igemm2 records per-workgroup phase clocks that
+    scripts/stamp_bench.py reads back.  Load it with E2EFT_LIB=<path>.  Never used by the product path or the tests."""
+    hipcc = _hipcc()
+    out = os.path.join(LIBDIR, "libe2eft_stamps.so")
+    objdir = os.path.join(OBJDIR, "stamps")
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        r = subprocess.run([hipcc] + FLAGS + ["-DE2EFT_STAMPS", "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", out)
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--stamps" in sys.argv:
+        build_stamps()
+    else:
+        build(force="--force" in sys.argv)

@@ -4,6 +4,15 @@
 
 namespace e2eft {
 
+// -DE2EFT_STAMPS (build.py build_stamps(): lib/libe2eft_stamps.so, scripts/stamp_bench.py): thread 0 of every workgroup records the
+// shader clock at the phase boundaries of igemm2_kernel — start, k-loop entry, k-loop exit, accumulators staged, end.
+#ifdef E2EFT_STAMPS
+static __device__ long long g_stamps[65536 * 8];
+#define E2EFT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define E2EFT_STAMP(i) do { } while (0)
+#endif
+
 struct IgemmParams {
     const void* x1;
     const void* x2;
@@ -58,6 +67,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
             for (int r = 0; r < 16; ++r)
                 tile[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDT + wn * 64 + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
+    E2EFT_STAMP(3);
 
     const T* __restrict__ bias = (const T*)p.bias;
     const T* __restrict__ rowadd = (const T*)p.rowadd;
@@ -179,5 +189,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
 
 // v2: 256x128 tile, 8 waves, LDS-DMA (global_load_lds) 3-stage ring — igemm2.hip
 int launch_igemm_v2(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
+// v3: same tile, 32-wide k-tiles, two workgroups per CU (16-bit FAST-path problems; returns -1 when not applicable) — igemm3.hip
+int launch_igemm_v3(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 
 }  // namespace e2eft

@@ -228,7 +228,11 @@ static int run_igemm(int dtype, int mode, IgemmParams& p, int nz, void* stream) 
         // this kernel on every shape of the path, including the 12^2 / 24^2 layers); this register-staged kernel stays as an
         // independent second implementation of the same contract: E2EFT_IGEMM=1 selects it (A/B runs, cross-checks).
         static const int forced = [] { const char* e = getenv("E2EFT_IGEMM"); return e ? atoi(e) : 0; }();
-        if (forced != 1) return launch_igemm_v2(dtype, mode, p, nz, s);
+        if (forced != 1) {
+            const int rc3 = launch_igemm_v3(dtype, mode, p, nz, s);
+            if (rc3 >= 0) return rc3;
+            return launch_igemm_v2(dtype, mode, p, nz, s);
+        }
     }
     p.gn_partial = nullptr;   // this variant does not emit GroupNorm statistics
     if (dtype == E2EFT_F32) return mode ? launch_igemm<float, 1>(p, nz, s) : launch_igemm<float, 0>(p, nz, s);

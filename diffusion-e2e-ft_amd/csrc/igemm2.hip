@@ -63,6 +63,7 @@ template <int V> using IC = std::integral_constant<int, V>;
 // half (no change), NW = 4 with two workgroups per CU (840).  See DESIGN.md §3 for the cycle-stamp breakdown.
 template <typename T, int MODE, bool FAST, int NW>
 __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
+    E2EFT_STAMP(0);
     using G = Geo<NW>;
     static constexpr int BM2 = G::BM, A_STAGE = G::A_STAGE, STAGE2 = G::STAGE, NSTAGE = G::NSTAGE, BPIECES = G::BPIECES, NPIECES = G::NPIECES;
     static constexpr int RSTEP = 8 * NW;   // row distance between a wave's consecutive pieces
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
         if constexpr (D == 2) {
             if (nk > 1) { advance(); fire_all(IC<1>{}); }
         }
+        E2EFT_STAMP(1);
         int kt = 0;
         if constexpr (NSTAGE == 3) {
             for (; kt + 3 + D <= nk; kt += 3) {   // steady state: every prefetch exists, every stage index is static
@@ -406,7 +408,9 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
     }
 
     // ---- epilogue: LDS-staged, vectorised (igemm.h) ----
+    E2EFT_STAMP(2);
     igemm_epilogue<T, BM2, BN2, NW * 64>(p, smem, acc, wm, wn, l31, h, m0, n0, zo, zi);
+    E2EFT_STAMP(4);
 }
 
 template <typename T, int MODE, int NW> static int launch2(IgemmParams& p, int nz, hipStream_t s) {
@@ -452,3 +456,9 @@ int launch_igemm_v2(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s) 
 }
 
 }  // namespace e2eft
+
+#ifdef E2EFT_STAMPS
+extern "C" int e2eft_debug_read_stamps(long long* host, int nworkgroups) {   // debug builds only; not part of include/e2eft.h
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(e2eft::g_stamps), (size_t)nworkgroups * 8 * sizeof(long long));
+}
+#endif

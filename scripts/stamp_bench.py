@@ -1,0 +1,36 @@
+"""Per-workgroup phase clocks of igemm2 (instrumented build, -DE2EFT_STAMPS; DESIGN.md §3 'fixed cost per workgroup').
+usage: python -m diffusion_e2e_ft_amd.build --stamps
+       E2EFT_LIB=diffusion-e2e-ft_amd/lib/libe2eft_stamps.so [NOSTATS=1] python scripts/stamp_bench.py B H W Cin Cout [k=3]"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from diffusion_e2e_ft_amd import ops, _lib
+
+a = sys.argv[1:]
+B, H, W, Ci, Co = (int(v) for v in a[:5])
+k = int(a[5]) if len(a) > 5 else 3
+dev = torch.device("cuda")
+x = torch.randn((B, H, W, Ci), device=dev).half()
+w = (torch.randn((Co, k * k * Ci), device=dev) / (k * k * Ci) ** 0.5).half()
+b = torch.randn((Co,), device=dev).half()
+p = k // 2
+for _ in range(3):
+    out = ops.conv2d(x, w, b, Co, k, k, 1, (p, p, p, p), gn_stats=os.environ.get("NOSTATS") is None)
+torch.cuda.synchronize()
+nwg = min(65536, ((B * H * W + 255) // 256) * ((Co + 127) // 128))
+buf = (ctypes.c_longlong * (nwg * 8))()
+lib = _lib.load()
+lib.e2eft_debug_read_stamps.restype = ctypes.c_int
+rc = lib.e2eft_debug_read_stamps(buf, nwg)
+assert rc == 0, rc
+s = np.frombuffer(buf, dtype=np.int64).reshape(nwg, 8)
+names = ["prologue (start -> loop entry)", "main loop", "accumulators -> LDS + barrier", "epilogue stores (+GN stats)"]
+for i, n in enumerate(names):
+    d = s[:, i + 1] - s[:, i]
+    print("%-34s mean %8.0f  median %8.0f cycles" % (n, d.mean(), np.median(d)))
+tot = s[:, 4] - s[:, 0]
+print("%-34s mean %8.0f cycles; k-tiles %d -> %.0f cycles / k-tile in the loop" % ("workgroup total", tot.mean(), k * k * Ci // 64, (s[:, 2] - s[:, 1]).mean() / (k * k * Ci // 64)))
