@@ -1,6 +1,7 @@
 // igemm.h — parameter block shared by the implicit-GEMM kernel variants.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace e2eft {
 
@@ -86,6 +87,76 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
     float s_mean[8], s_m2[8];   // Welford state over this thread's NPASS rows (per column)
 #pragma unroll
     for (int e = 0; e < 8; ++e) s_mean[e] = s_m2[e] = 0.f;
+
+    // ---- fast path: vector epilogue on a tile that lies completely inside the problem; every condition is workgroup-uniform and
+    // hoisted, so the pass loop is straight-line code: x = fma(acc, alpha, bias*alpha) [+ rowadd*alpha] [+ residual], one
+    // v_cvt_pk per column pair, one 16-byte store per row chunk.  (The generic loop below costs ~9k cycles per 256x128 tile in
+    // exec-mask branches and scalar fallbacks even when none is taken — scripts/stamp_bench.py.)
+    const bool full = vec && m0 + BM_ <= p.M && n0 + BN_ <= p.N && !(bias && p.bias_along_m);
+    if (full) {
+        const float al = p.alpha;
+        float bva[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bva[e] = bv[e] * al;
+        const bool one_img = p.rows_per_img % BM_ == 0 || p.rows_per_img >= p.M;
+        const int img0 = rowadd ? m0 / p.rows_per_img : 0;
+        T* __restrict__ orow = out + (long)(m0 + rbase) * p.ldo + n;
+        const T* __restrict__ rrow = res ? res + (long)(m0 + rbase) * p.ldr + n : nullptr;
+        const long ostep = (long)RPP * p.ldo, rstep = (long)RPP * p.ldr;
+        auto run = [&](auto has_res, auto has_ra) {
+            constexpr bool HAS_RES = decltype(has_res)::value, HAS_RA = decltype(has_ra)::value;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int row = rbase + pass * RPP;
+                const floatx4 t0 = *reinterpret_cast<const floatx4*>(tile + row * LDT + chunk * 8);
+                const floatx4 t1 = *reinterpret_cast<const floatx4*>(tile + row * LDT + chunk * 8 + 4);
+                float x[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], al, bva[e]);
+                if constexpr (HAS_RA) {
+                    const int img = one_img ? img0 : (m0 + row) / p.rows_per_img;
+                    const T* ra = rowadd + (long)img * p.N + n;
+#pragma unroll
+                    for (int q = 0; q < 8 / EPC; ++q) {
+                        const Vec16<T> t = ld16(ra + q * EPC);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) x[q * EPC + e] = fmaf(to_f(t.e[e]), al, x[q * EPC + e]);
+                    }
+                }
+                if constexpr (HAS_RES) {
+#pragma unroll
+                    for (int q = 0; q < 8 / EPC; ++q) {
+                        const Vec16<T> t = ld16(rrow + pass * rstep + q * EPC);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) x[q * EPC + e] += to_f(t.e[e]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8 / EPC; ++q) {
+                    Vec16<T> o;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(x[q * EPC + e]);
+                    st16(orow + pass * ostep + q * EPC, o);
+                    if (stats) {   // uniform
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {   // statistics of what GroupNorm will read back: the rounded value
+                            const float xr = to_f(o.e[e]);
+                            const float d = xr - s_mean[q * EPC + e];
+                            s_mean[q * EPC + e] += d * (1.0f / (float)(pass + 1));
+                            s_m2[q * EPC + e] += d * (xr - s_mean[q * EPC + e]);
+                        }
+                    }
+                }
+            }
+        };
+        if (res) {
+            if (rowadd) run(std::true_type{}, std::true_type{});
+            else run(std::true_type{}, std::false_type{});
+        } else {
+            if (rowadd) run(std::false_type{}, std::true_type{});
+            else run(std::false_type{}, std::false_type{});
+        }
+    } else {
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         const int row = rbase + pass * RPP;
@@ -142,6 +213,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
                 }
             }
         }
+    }
     }
     if (stats) {   // uniform branch
         // lanes l, l^16, l^32, l^48 own the same 8 columns (rbase differs): butterfly-merge equal-count triples
