@@ -103,6 +103,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
         T* __restrict__ orow = out + (long)(m0 + rbase) * p.ldo + n;
         const T* __restrict__ rrow = res ? res + (long)(m0 + rbase) * p.ldr + n : nullptr;
         const long ostep = (long)RPP * p.ldo, rstep = (long)RPP * p.ldr;
+        // GroupNorm statistics: every thread of a column accumulates sum(x - pv), sum((x - pv)^2) about the same pivot pv (the tile's
+        // first row before rowadd / residual: any value near the data does), so partial results merge by plain addition.  They are
+        // taken from the fp32 value; rounding to T adds a variance of ~2^-22 x^2 (fp16) / 2^-16 x^2 (bf16) — below the kernels' noise.
+        float pv[8];
+        if (stats) {
+            const floatx4 q0 = *reinterpret_cast<const floatx4*>(tile + chunk * 8);
+            const floatx4 q1 = *reinterpret_cast<const floatx4*>(tile + chunk * 8 + 4);
+            const float pr[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = fmaf(pr[e], al, bva[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = 0.f;
+        }
         auto run = [&](auto has_res, auto has_ra) {
             constexpr bool HAS_RES = decltype(has_res)::value, HAS_RA = decltype(has_ra)::value;
 #pragma unroll
@@ -137,14 +151,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(x[q * EPC + e]);
                     st16(orow + pass * ostep + q * EPC, o);
-                    if (stats) {   // uniform
+                }
+                if (stats) {   // uniform: shifted sums about a per-column pivot shared by the whole tile (s_mean = sum, s_m2 = sum of squares)
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e) {   // statistics of what GroupNorm will read back: the rounded value
-                            const float xr = to_f(o.e[e]);
-                            const float d = xr - s_mean[q * EPC + e];
-                            s_mean[q * EPC + e] += d * (1.0f / (float)(pass + 1));
-                            s_m2[q * EPC + e] += d * (xr - s_mean[q * EPC + e]);
-                        }
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = x[e] - pv[e];
+                        s_mean[e] += d;
+                        s_m2[e] = fmaf(d, d, s_m2[e]);
                     }
                 }
             }
@@ -156,7 +169,45 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
             if (rowadd) run(std::false_type{}, std::true_type{});
             else run(std::false_type{}, std::false_type{});
         }
-    } else {
+        if (stats) {   // uniform.  lanes l, l^16, l^32, l^48 own the same 8 columns: add; then the waves through LDS
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s_mean[e] += __shfl_xor(s_mean[e], off, 64);
+                    s_m2[e] += __shfl_xor(s_m2[e], off, 64);
+                }
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            float* piv = gst + NWV * 16 * 8 * 2;
+            if (lane < 16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    gst[((wv * 16 + lane) * 8 + e) * 2] = s_mean[e];
+                    gst[((wv * 16 + lane) * 8 + e) * 2 + 1] = s_m2[e];
+                    if (wv == 0) piv[lane * 8 + e] = pv[e];
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < BN_) {
+                const int c = threadIdx.x;
+                float su = 0.f, sq = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) {
+                    su += gst[((w * 16 + c / 8) * 8 + (c & 7)) * 2];
+                    sq += gst[((w * 16 + c / 8) * 8 + (c & 7)) * 2 + 1];
+                }
+                const float nrow = (float)BM_;
+                const int img = m0 / p.rows_per_img;
+                const int slab = (m0 - img * p.rows_per_img) / BM_;
+                float* o = p.gn_partial + (((long)img * p.gn_nslabs + slab) * p.N + n0 + c) * 3;
+                o[0] = nrow;
+                o[1] = piv[c] + su / nrow;
+                o[2] = fmaxf(sq - su * su / nrow, 0.f);
+            }
+        }
+        return;
+    }
+    {
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         const int row = rbase + pass * RPP;

@@ -31,7 +31,7 @@ template <int NW> struct Geo {
     static constexpr int NSTAGE = NW == 8 ? 3 : 2;
     static constexpr int BPIECES = 16 / NW;          // B pieces (8 rows each) per wave
     static constexpr int NPIECES = 4 + BPIECES;      // DMA instructions per wave per k-tile
-    static constexpr int EPI_BYTES = BM * (BN2 + 4) * 4 + NW * 1024;   // staged fp32 tile + GroupNorm-statistics scratch
+    static constexpr int EPI_BYTES = BM * (BN2 + 4) * 4 + NW * 1024 + 512;   // staged fp32 tile + GroupNorm-statistics scratch + pivots
     static constexpr int LDS_BYTES = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;
 };
 
