@@ -32,5 +32,7 @@ names = ["prologue (start -> loop entry)", "main loop", "accumulators -> LDS + b
 for i, n in enumerate(names):
     d = s[:, i + 1] - s[:, i]
     print("%-34s mean %8.0f  median %8.0f cycles" % (n, d.mean(), np.median(d)))
+print("k-loop start-up: tile 0 %.0f cycles, tiles 1-2 %.0f, tiles 3-5 %.0f (loop entry -> after tile 0 / 2 / 5)" % (
+    (s[:, 5] - s[:, 1]).mean(), (s[:, 6] - s[:, 5]).mean(), (s[:, 7] - s[:, 6]).mean()))
 tot = s[:, 4] - s[:, 0]
 print("%-34s mean %8.0f cycles; k-tiles %d -> %.0f cycles / k-tile in the loop" % ("workgroup total", tot.mean(), k * k * Ci // 64, (s[:, 2] - s[:, 1]).mean() / (k * k * Ci // 64)))
