@@ -4,7 +4,6 @@ libe2eft (HIP) only.  Internally every activation is NHWC `[B, H, W, C]` (tokens
 The reference composes these blocks in GeoWizard/geowizard/models/unet_2d_blocks.py, transformer_2d.py, attention.py
 (vendored twins of diffusers); leaf semantics are diffusers==0.30.2 (not in the reference tree).  Citations per class.
 """
-import math
 
 import torch
 from torch import nn

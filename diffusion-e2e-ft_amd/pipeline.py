@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .modules import to_nhwc, to_nchw_view, conv_nhwc
+from .modules import to_nchw_view
 
 
 @dataclass

@@ -21,7 +21,6 @@ import torch.distributed as dist
 
 from . import autograd as F
 from . import ops
-from .modules import to_nhwc, to_nchw_view
 
 
 class IterExponential:
