@@ -57,6 +57,17 @@ constexpr unsigned int SRD_RECORDS = 0xE0000000u;
 
 template <int V> using IC = std::integral_constant<int, V>;
 
+// n / d for 0 <= n < 2^31, d >= 1 with a quotient below 2^22 (rows / image size, pixels / row length): float estimate (relative
+// error ~2^-22, so off by at most one) + one correction — 8 instructions instead of the ~25 of the generic unsigned division,
+// eight of which sit in front of the first DMA of every workgroup.
+__device__ __forceinline__ int fast_div(int n, int d) {
+    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
+    const int r = n - q * d;
+    if (r < 0) --q;
+    else if (r >= d) ++q;
+    return q;
+}
+
 // Tried and measured, not kept (conv 512->512 @192^2, B = 8, fp16; this kernel: 940-970 TF/s): a rotated loop that reads the next
 // tile's first fragments before the current tile's last MFMAs (820), a ping-pong schedule with the two waves of a SIMD in
 // opposite L/M phases (750), 4 dedicated LDS-DMA loader waves + 8 pure consumer waves (917), static s_setprio for either
@@ -115,9 +126,9 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
         } else {
             const int hw = p.hout * p.wout;
             const int mm = a_ok[i] ? m : 0;
-            const int b = mm / hw;
+            const int b = fast_div(mm, hw);
             const int rem = mm - b * hw;
-            const int oy = rem / p.wout, ox = rem - oy * p.wout;
+            const int oy = fast_div(rem, p.wout), ox = rem - oy * p.wout;
             a_base[i] = b;
             a_iy0[i] = oy * p.stride - p.pad_t;
             a_ix0[i] = ox * p.stride - p.pad_l;
@@ -131,12 +142,15 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
     }
 
     floatx16 acc[2][2];
+    auto zero_acc = [&]() {   // called after the first DMA pieces are in flight (FAST path): 64 v_mov under the cold-start latency
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    if constexpr (!FAST) zero_acc();
 
     // fragment byte offsets inside the LDS ring, per stage (static stage index in the unrolled loop -> register + immediate);
     // read-side swizzle: rows wm*64 + i*32 + l31 -> ((row >> 1) & 7) == (l31 >> 1) & 7; second row-subtile = +32*128.
@@ -223,8 +237,8 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
                 base2[i] = (pix0 * (unsigned)p.ldx2 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T);
             }
         }
+        int ky = 0, kx = 0;     // the current tap, advanced incrementally (no division per tap change)
         auto retap = [&]() {   // per-row pixel offsets of the current filter tap (uniform branch, once per tap)
-            const int ky = tap / p.kw, kx = tap - ky * p.kw;
             if (plain_taps) {
                 const unsigned d1 = (unsigned)((ky * p.win + kx) * p.ldx1) * (unsigned)sizeof(T);
                 const unsigned d2 = (unsigned)((ky * p.win + kx) * p.ldx2) * (unsigned)sizeof(T);
@@ -272,7 +286,10 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
                     for (int i = 0; i < 4; ++i) cur_a[i] += 128u;
                 }
                 tile_c += BK;
-                if (tile_c >= p.cin) { tile_c = 0; ++tap; }
+                if (tile_c >= p.cin) {
+                    tile_c = 0; ++tap;
+                    if (++kx == p.kw) { kx = 0; ++ky; }
+                }
             }
 #pragma unroll
             for (int i = 0; i < BPIECES; ++i) cur_b[i] += 128u;
@@ -333,6 +350,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
         if constexpr (D == 2) {
             if (nk > 1) { advance(); fire_all(IC<1>{}); }
         }
+        zero_acc();
         E2EFT_STAMP(1);
         int kt = 0;
         if constexpr (NSTAGE == 3) {
