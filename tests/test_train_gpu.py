@@ -164,3 +164,54 @@ def test_gradient_accumulation_equals_big_batch(dev):
         (training.e2e_ft_loss(unet, vae, h, text, "depth") / 2).backward()
     for k, v in unet.named_parameters():
         assert rel_err(v.grad, ref[k]) < 1e-5 or ref[k].abs().max() < 1e-12, k
+
+
+def test_reference_style_step_with_torch_glue(dev):
+    """The step body as training/train.py:470-566 writes it — torch arithmetic between `unet(...)` and `vae.decoder(...)`,
+    `.mean(dim=1, keepdim=True)`, `torch.clamp`, the loss as a torch module (the oracle's restatement of loss.py, pinned to the
+    reference), `loss.backward()`, `clip_grad_norm_`, `torch.optim.AdamW` — runs unchanged on the product modules and yields the
+    golden gradients: autograd crosses our Functions and torch's own ops in both directions (non-contiguous, channel-sliced and
+    permuted gradient tensors included)."""
+    from oracle import losses_ref
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    unet, vae = _models(dev)
+    batch, text = gc.train_batch()
+    gold = GOLD["depth"]
+    sched = DDIMScheduler()
+    alpha_prod = sched.alphas_cumprod.to(dev)
+    beta_prod = 1 - alpha_prod
+    optimizer = torch.optim.AdamW(unet.parameters(), lr=3e-5, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    # ---- train.py:472-500
+    with torch.no_grad():
+        h = vae.encoder(batch["rgb"].to(dev))
+        moments = vae.quant_conv(h)
+        rgb_latents, _ = torch.chunk(moments, 2, dim=1)
+        rgb_latents = rgb_latents * vae.config.scaling_factor
+    val_mask = batch["val_mask"].bool().to(dev)
+    timesteps = (torch.ones((rgb_latents.shape[0],), device=dev) * 999).long()
+    noisy_latents = torch.zeros_like(rgb_latents)
+    encoder_hidden_states = text.to(dev).repeat(len(batch["rgb"]), 1, 1)
+    unet_input = torch.cat((rgb_latents, noisy_latents), dim=1)
+    model_pred = unet(unet_input, timesteps, encoder_hidden_states, return_dict=False)[0]
+    # ---- train.py:509-540
+    alpha_prod_t = alpha_prod[timesteps].view(-1, 1, 1, 1)
+    beta_prod_t = beta_prod[timesteps].view(-1, 1, 1, 1)
+    current_latent_estimate = (alpha_prod_t ** 0.5) * noisy_latents - (beta_prod_t ** 0.5) * model_pred
+    current_latent_estimate = current_latent_estimate / vae.config.scaling_factor
+    z = vae.post_quant_conv(current_latent_estimate)
+    current_estimate = vae.decoder(z)
+    current_estimate = current_estimate.mean(dim=1, keepdim=True)
+    current_estimate = torch.clamp(current_estimate, -1, 1)
+    loss = losses_ref.ssi_loss_ref(current_estimate, batch["metric"].to(dev), val_mask)
+    assert abs(loss.item() - gold["loss"].item()) <= 1e-4 * abs(gold["loss"].item())
+    # ---- train.py:562-566
+    loss.backward()
+    _check_grads(dict(unet.named_parameters()), gold)
+    before = {k: v.detach().clone() for k, v in unet.named_parameters()}
+    torch.nn.utils.clip_grad_norm_(unet.parameters(), 1.0)
+    optimizer.step()
+    optimizer.zero_grad()
+    assert any(not torch.equal(v, before[k]) for k, v in unet.named_parameters())
+    with torch.no_grad():   # the kernels see the updated weights (packed copies are keyed on the parameter version)
+        out2 = unet(unet_input, timesteps, encoder_hidden_states, return_dict=False)[0]
+    assert not torch.equal(out2, model_pred.detach())
