@@ -87,6 +87,7 @@ SIGNATURES = {
     "e2eft_upsample_nearest_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "e2eft_groupnorm_bwd_workspace_bytes": (_Z, [C.POINTER(GroupNormDesc)]),
     "e2eft_groupnorm_bwd": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "e2eft_groupnorm_bwd_add": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "e2eft_layernorm_bwd_workspace_bytes": (_Z, [_L, _I]),
     "e2eft_layernorm_bwd": (_I, [_I, _L, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "e2eft_geglu_bwd": (_I, [_I, _L, _I, _I, _I, _I, _P, _P, _P, _P]),

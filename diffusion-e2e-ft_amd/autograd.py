@@ -299,37 +299,52 @@ def linear(x, weights, bias=None, residual=None, alpha=1.0, owner=None, name="w"
 
 # ------------------------------------------------------------------------------------------------------------
 class _GroupNormFn(torch.autograd.Function):
+    """GroupNorm(+SiLU).  split=True additionally returns an alias of x for the skip path of a residual block: the gradient that
+    comes back over it is added inside the backward apply kernel (e2eft_groupnorm_bwd_add) instead of by a separate torch add."""
+
     @staticmethod
-    def forward(ctx, x, x2, gamma, beta, groups, eps, silu, s1, s2):
+    def forward(ctx, x, x2, gamma, beta, groups, eps, silu, s1, s2, split):
         dt = x.dtype
         y, ws = ops.groupnorm_fwd_ws(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, x2=x2, s1=s1, s2=s2)
         ctx.save_for_backward(x, x2, gamma, beta, ws)
         ctx.meta = (groups, eps, silu)
+        if split:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, x2, gamma, beta, ws = ctx.saved_tensors
         groups, eps, silu = ctx.meta
         dt = x.dtype
         need = ctx.needs_input_grad
         c1 = x.shape[3]
         Cc = c1 + (0 if x2 is None else x2.shape[3])
-        g = _dense_nhwc(dy, Cc)
         want_dx = need[0] or (x2 is not None and need[1])
         want_p = need[2] or need[3]
-        dx, dg, db = ops.groupnorm_bwd(x, x2, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu, g, ws, need_dx=want_dx, need_dparams=want_p)
+        if dy is None:     # only the skip path was used downstream
+            return dskip, None, None, None, None, None, None, None, None, None
+        g = _dense_nhwc(dy, Cc)
+        add = _dense_nhwc(dskip, Cc) if (dskip is not None and need[0] and x2 is None) else None
+        dx, dg, db = ops.groupnorm_bwd(x, x2, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu, g, ws, need_dx=want_dx, need_dparams=want_p,
+                                       dx_add=add)
         d1 = dx[..., :c1] if (need[0] and dx is not None) else None
         d2 = dx[..., c1:] if (x2 is not None and need[1]) else None
-        return d1, d2, (dg.to(gamma.dtype) if need[2] else None), (db.to(beta.dtype) if need[3] else None), None, None, None, None, None
+        return d1, d2, (dg.to(gamma.dtype) if need[2] else None), (db.to(beta.dtype) if need[3] else None), None, None, None, None, None, None
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None):
+def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, split=False):
+    """split=True: returns (y, x_skip) — use x_skip wherever the block's residual reads x (see _GroupNormFn)"""
     if needs_grad(x, x2, gamma, beta):
-        return _GroupNormFn.apply(x, x2, gamma, beta, groups, eps, silu, getattr(x, "_e2eft_gn", None),
-                                  getattr(x2, "_e2eft_gn", None) if x2 is not None else None)
+        sp = split and x2 is None and x.requires_grad
+        out = _GroupNormFn.apply(x, x2, gamma, beta, groups, eps, silu, getattr(x, "_e2eft_gn", None),
+                                 getattr(x2, "_e2eft_gn", None) if x2 is not None else None, sp)
+        if split:
+            return out if sp else (out, x)
+        return out
     dt = x.dtype
-    return ops.groupnorm(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, x2=x2)
+    y = ops.groupnorm(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, x2=x2)
+    return (y, x) if split else y
 
 
 class _LayerNormFn(torch.autograd.Function):

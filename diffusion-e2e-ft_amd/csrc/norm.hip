@@ -394,7 +394,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnGeom g, int groups, int silu, int lddy, int lddx, const T* __restrict__ x1,
                                                            const T* __restrict__ x2, const T* __restrict__ dy, const float* __restrict__ ad,
                                                            const float* __restrict__ rstd, const float* __restrict__ mm,
-                                                           const T* __restrict__ gamma, const T* __restrict__ beta, T* __restrict__ dx) {
+                                                           const T* __restrict__ gamma, const T* __restrict__ beta, T* __restrict__ dx,
+                                                           const T* __restrict__ addend, int ldadd) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const int tid = threadIdx.x;
     const int chl = tid % g.cpb, pl = tid / g.cpb;
@@ -420,13 +421,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnGeom g, int groups,
         k3[e] = k.rs[e] * k.rs[e] * mm[((long)b * groups + grp) * 2 + 1];
     }
     auto one = [&](long row, const Vec16<T>& v, const Vec16<T>& d) {
-        Vec16<T> o;
+        Vec16<T> o, ad2;
+        if (addend) ad2 = ld16(addend + row * ldadd + c);   // gradient arriving over the skip path of the same tensor (uniform branch)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const float xc = to_f(v.e[e]) - k.mu[e];
             float dz = to_f(d.e[e]);
             if (silu) dz *= silu_grad_f(fmaf(xc, k.a[e], k.be[e]));
-            o.e[e] = from_f<T>(k1[e] * dz - k2[e] - xc * k3[e]);
+            float r = k1[e] * dz - k2[e] - xc * k3[e];
+            if (addend) r += to_f(ad2.e[e]);
+            o.e[e] = from_f<T>(r);
         }
         st16(dx + row * lddx + c, o);
     };
@@ -465,7 +469,7 @@ static size_t gn_bwd_ws_bytes(const E2eftGroupNormDesc* d) {
 template <typename T>
 static int gn_bwd_run(const E2eftGroupNormDesc* d, const GnGeom& g, const void* x1, const void* x2, const void* gamma, const void* beta,
                       const void* dy, int lddy, void* dx, int lddx, float* dgamma, float* dbeta, const float* fwd_ws, void* ws,
-                      hipStream_t s) {
+                      const void* addend, int ldadd, hipStream_t s) {
     const float* ad = fwd_ws + (gn_ws_bytes(d) / sizeof(float) - (size_t)d->batch * g.C * 2 - (size_t)d->batch * d->groups);
     const float* rstd = ad + (size_t)d->batch * g.C * 2;
     float* part = (float*)ws;
@@ -478,7 +482,7 @@ static int gn_bwd_run(const E2eftGroupNormDesc* d, const GnGeom& g, const void* 
                        (const T*)gamma, sc, mm);
     if (dx)
         hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), grid, dim3(256), 0, s, g, d->groups, d->silu, lddy, lddx, (const T*)x1, (const T*)x2,
-                           (const T*)dy, ad, rstd, mm, (const T*)gamma, (const T*)beta, (T*)dx);
+                           (const T*)dy, ad, rstd, mm, (const T*)gamma, (const T*)beta, (T*)dx, (const T*)addend, ldadd);
     if (dgamma || dbeta)
         hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(cdiv(g.C, 256)), dim3(256), 0, s, g.batch, g.C, sc, dgamma, dbeta);
     return check_launch("groupnorm_bwd");
@@ -841,19 +845,26 @@ extern "C" size_t e2eft_groupnorm_bwd_workspace_bytes(const E2eftGroupNormDesc* 
 extern "C" int e2eft_groupnorm_bwd(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma, const void* beta,
                                    const void* dy, int32_t lddy, void* dx, int32_t lddx, float* dgamma, float* dbeta,
                                    const void* fwd_workspace, void* workspace, size_t ws_bytes, void* stream) {
+    return e2eft_groupnorm_bwd_add(d, x1, x2, gamma, beta, dy, lddy, nullptr, 0, dx, lddx, dgamma, dbeta, fwd_workspace, workspace, ws_bytes, stream);
+}
+
+extern "C" int e2eft_groupnorm_bwd_add(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma, const void* beta,
+                                       const void* dy, int32_t lddy, const void* dx_add, int32_t ldadd, void* dx, int32_t lddx, float* dgamma,
+                                       float* dbeta, const void* fwd_workspace, void* workspace, size_t ws_bytes, void* stream) {
     if (int e = gn_validate(d)) return e;
     E2EFT_REQUIRE(x1 && dy && fwd_workspace && workspace, "groupnorm_bwd: null pointer");
     E2EFT_REQUIRE(d->c2 == 0 || x2, "groupnorm_bwd: x2 missing");
     const int epc = 16 / (int)dtype_size(d->dtype);
     const int C = d->c1 + d->c2;
     E2EFT_REQUIRE(lddy >= C && lddy % epc == 0 && (!dx || (lddx >= C && lddx % epc == 0)), "groupnorm_bwd: strides");
+    E2EFT_REQUIRE(!dx_add || (dx && ldadd >= C && ldadd % epc == 0 && ((uintptr_t)dx_add & 15) == 0), "groupnorm_bwd: dx_add");
     GnGeom g;
     gn_geom(d, g);
     const size_t need = gn_bwd_ws_bytes(d);
     if (ws_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "groupnorm_bwd: workspace %zu < %zu", ws_bytes, need);
     E2EFT_REQUIRE(g.batch <= 65535 && g.nchb <= 65535, "groupnorm_bwd: grid");
     E2EFT_DISPATCH_DTYPE(d->dtype, T, return gn_bwd_run<T>(d, g, x1, x2, gamma, beta, dy, lddy, dx, lddx, dgamma, dbeta,
-                                                          (const float*)fwd_workspace, workspace, (hipStream_t)stream));
+                                                          (const float*)fwd_workspace, workspace, dx_add, ldadd, (hipStream_t)stream));
     return 0;
 }
 

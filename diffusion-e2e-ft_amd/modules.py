@@ -63,8 +63,9 @@ class Linear(nn.Linear):
 
 
 class GroupNorm(nn.GroupNorm):
-    def nhwc(self, x, x2=None, silu=False):
-        return F.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2)
+    def nhwc(self, x, x2=None, silu=False, split=False):
+        """split=True -> (y, x_skip): x_skip is x for the residual path (its gradient is folded into this norm's backward)"""
+        return F.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2, split=split)
 
     def forward(self, x):
         return to_nchw_view(self.nhwc(to_nhwc(x)))
@@ -104,7 +105,10 @@ class ResnetBlock2D(nn.Module):
 
     def nhwc(self, x, temb_act=None, x2=None):
         """x2: second source of a fused channel concat (skip connection, unet_2d_blocks.py:2328,2456)."""
-        h = self.norm1.nhwc(x, x2=x2, silu=True)
+        if x2 is None:
+            h, x = self.norm1.nhwc(x, silu=True, split=True)     # x: the same tensor, routed through the norm for its gradient
+        else:
+            h = self.norm1.nhwc(x, x2=x2, silu=True)
         rowadd = self.time_emb_proj(temb_act) if self.time_emb_proj is not None else None
         h = conv_nhwc(self.conv1, h, rowadd=rowadd)
         h = self.norm2.nhwc(h, silu=True)
@@ -292,8 +296,8 @@ class Transformer2DModel(nn.Module):
 
     def nhwc(self, x, ctx):
         B, H, W, C = x.shape
-        h = self.norm.nhwc(x).view(B, H * W, C)
-        h = self.proj_in(h)
+        h, x = self.norm.nhwc(x, split=True)
+        h = self.proj_in(h.view(B, H * W, C))
         for blk in self.transformer_blocks:
             h = blk(h, ctx)
         out = self.proj_out(h, residual=x.reshape(B, H * W, C), gn_rows_per_image=H * W)
@@ -318,7 +322,8 @@ class VaeAttention(nn.Module):
 
     def nhwc(self, x):
         B, H, W, C = x.shape
-        n = self.group_norm.nhwc(x).view(B, H * W, C)
+        n, x = self.group_norm.nhwc(x, split=True)
+        n = n.view(B, H * W, C)
         out = self.to_out[0]
         if F.needs_grad(x, self.to_q.weight):
             bias = torch.cat([self.to_q.bias, self.to_k.bias, self.to_v.bias])

@@ -688,8 +688,8 @@ def _gn_desc(x, x2, groups, eps, silu, ldy):
     return d
 
 
-def groupnorm_bwd(x, x2, gamma, beta, groups, eps, silu, dy, fwd_ws, need_dx=True, need_dparams=True):
-    """-> (dx [B,H,W,C] or None, dgamma fp32 [C] or None, dbeta fp32 [C] or None)"""
+def groupnorm_bwd(x, x2, gamma, beta, groups, eps, silu, dy, fwd_ws, need_dx=True, need_dparams=True, dx_add=None):
+    """-> (dx [B,H,W,C] or None, dgamma fp32 [C] or None, dbeta fp32 [C] or None); dx_add: a [B,H,W,C] gradient added into dx"""
     _check_cuda(x, x2, gamma, beta, dy, fwd_ws)
     B, H, W, c1 = x.shape
     Cc = c1 + (0 if x2 is None else x2.shape[3])
@@ -703,8 +703,9 @@ def groupnorm_bwd(x, x2, gamma, beta, groups, eps, silu, dy, fwd_ws, need_dx=Tru
     dg = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_dparams else None
     db = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_dparams else None
     with _timed("groupnorm_bwd", 0.0, 5.0 * B * H * W * Cc * x.element_size(), label="gn_bwd B%d %dx%d C%d" % (B, H, W, Cc)):
-        check(lib.e2eft_groupnorm_bwd(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(dy), _nhwc_ld(dy), _ptr(dx), Cc, _ptr(dg), _ptr(db),
-                                      _ptr(fwd_ws), _ptr(ws), nbytes, _stream()))
+        check(lib.e2eft_groupnorm_bwd_add(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(dy), _nhwc_ld(dy), _ptr(dx_add),
+                                          _nhwc_ld(dx_add) if dx_add is not None else 0, _ptr(dx), Cc, _ptr(dg), _ptr(db), _ptr(fwd_ws), _ptr(ws), nbytes,
+                                          _stream()))
     return dx, dg, db
 
 

@@ -264,6 +264,11 @@ size_t e2eft_groupnorm_bwd_workspace_bytes(const E2eftGroupNormDesc* d);
 int e2eft_groupnorm_bwd(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma, const void* beta,
                         const void* dy, int32_t lddy, void* dx, int32_t lddx, float* dgamma, float* dbeta,
                         const void* fwd_workspace, void* workspace, size_t ws_bytes, void* stream);
+/* same, with dx += dx_add (row stride ldadd): the gradient that reaches the same tensor over a skip connection (ResnetBlock2D /
+ * Transformer2DModel residuals) is folded into the apply pass instead of a separate elementwise add */
+int e2eft_groupnorm_bwd_add(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma, const void* beta,
+                            const void* dy, int32_t lddy, const void* dx_add, int32_t ldadd, void* dx, int32_t lddx, float* dgamma,
+                            float* dbeta, const void* fwd_workspace, void* workspace, size_t ws_bytes, void* stream);
 /* LayerNorm backward: dx (may be NULL) and dgamma_dbeta fp32 [2][c] */
 size_t e2eft_layernorm_bwd_workspace_bytes(int64_t rows, int32_t c);
 int e2eft_layernorm_bwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldx, int32_t lddy, int32_t lddx, float eps,
