@@ -1,0 +1,95 @@
+"""BASELINE.json's full-size configuration (SD-v2 UNet 866 M + SD VAE 84 M parameters, 768x768) cannot be compared with the CPU
+oracle in test time (one 768^2 image takes the oracle ~10 s on 32 cores and there are no real weights), so the full-size path is
+checked through size-independent properties of the computation:
+  * images of a batch are independent: image i of a batch equals the same image run alone to fp16 rounding (not bit for bit: the
+    tile height — 128 or 256 rows — is chosen from the total problem size, and with it the merge order of the fused GroupNorm
+    statistics, which moves a few fp16 roundings);
+  * determinism: the same call twice gives identical bits (no atomics anywhere on the path);
+  * range / finiteness of depth in [0, 1] and unit-length normals;
+  * fp16 and bf16 runs of the same weights agree to 16-bit accuracy;
+  * one full-size E2E-FT micro-step (576x576, fp32 master weights, bf16 compute) gives a finite loss and finite, non-zero
+    gradients for every one of the 686 UNet tensors, and repeating it reproduces the loss exactly.
+Weights are the seeded synthetic initialisation bench.py uses."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def models(dev):
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    from diffusion_e2e_ft_amd.synth import init_synthetic_
+    with torch.device(dev):
+        unet = UNet2DConditionModel(in_channels=8)
+        vae = AutoencoderKL()
+    init_synthetic_(unet, seed=1234)
+    init_synthetic_(vae, seed=4321)
+    assert sum(p.numel() for p in unet.parameters()) == 865_922_244 and len(list(unet.parameters())) == 686
+    assert sum(p.numel() for p in vae.parameters()) == 83_653_863
+    return unet, vae
+
+
+def _pipe(unet, vae, dtype, dev):
+    import copy
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    from diffusion_e2e_ft_amd.pipeline import MarigoldPipeline
+    u, v = copy.deepcopy(unet).to(dtype).eval(), copy.deepcopy(vae).to(dtype).eval()
+    pipe = MarigoldPipeline(u, v, DDIMScheduler())
+    g = torch.Generator(device=dev).manual_seed(0)
+    pipe.empty_text_embed = (0.5 * torch.randn((1, 2, 1024), generator=g, device=dev)).to(dtype)
+    return pipe
+
+
+def _images(n, dev, res=768):
+    g = torch.Generator(device=dev).manual_seed(7)
+    return torch.randint(0, 256, (n, 3, res, res), generator=g, device=dev, dtype=torch.int32).float() / 255.0 * 2.0 - 1.0
+
+
+def test_fullsize_inference_properties(dev, models):
+    unet, vae = models
+    rgb = _images(3, dev)
+    pipe = _pipe(unet, vae, torch.float16, dev)
+    with torch.no_grad():
+        d3 = pipe.single_infer(rgb.half(), 1, noise="zeros", normals=False)
+        d3b = pipe.single_infer(rgb.half(), 1, noise="zeros", normals=False)
+        d1 = pipe.single_infer(rgb[1:2].half(), 1, noise="zeros", normals=False)
+        n3 = pipe.single_infer(rgb.half(), 1, noise="zeros", normals=True)
+    assert d3.shape == (3, 1, 768, 768) and torch.isfinite(d3.float()).all()
+    assert d3.min().item() >= 0.0 and d3.max().item() <= 1.0 and d3.float().std().item() > 1e-4
+    assert torch.equal(d3, d3b), "non-deterministic output"
+    dd = (d3[1:2].float() - d1.float()).abs()
+    assert dd.max().item() < 1e-2 and dd.mean().item() < 5e-4, "an image's result depends on its batch: max %g mean %g" % (dd.max().item(), dd.mean().item())
+    nn = n3.float().norm(dim=1)
+    assert torch.isfinite(n3.float()).all() and (nn - 1).abs().max().item() < 2e-2
+    del pipe
+    torch.cuda.empty_cache()
+    pb = _pipe(unet, vae, torch.bfloat16, dev)
+    with torch.no_grad():
+        db = pb.single_infer(rgb[:1].bfloat16(), 1, noise="zeros", normals=False)
+    diff = (db.float() - d3[:1].float()).abs()
+    assert diff.mean().item() < 2e-2 and torch.isfinite(db.float()).all(), diff.mean().item()
+
+
+def test_fullsize_training_micro_step(dev, models):
+    import copy
+    from diffusion_e2e_ft_amd import training
+    unet, vae = models
+    u = copy.deepcopy(unet).train().set_compute_dtype(torch.bfloat16)
+    v = copy.deepcopy(vae).to(torch.bfloat16).eval().requires_grad_(False)
+    batch = training.synthetic_batch(1, 576, 576, dev, seed=3, dtype=torch.bfloat16)
+    text = 0.5 * torch.randn((1, 77, 1024), generator=torch.Generator(device=dev).manual_seed(0), device=dev)
+    losses = []
+    for _ in range(2):
+        u.zero_grad(set_to_none=True)
+        loss = training.e2e_ft_loss(u, v, batch, text, "depth")
+        loss.backward()
+        losses.append(loss.item())
+    assert losses[0] == losses[1] and torch.isfinite(torch.tensor(losses[0])) and losses[0] > 0
+    n_zero = 0
+    for k, p in u.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32 and p.grad.shape == p.shape, k
+        assert torch.isfinite(p.grad).all(), k
+        n_zero += int(p.grad.abs().max().item() == 0)
+    assert n_zero == 0, "%d parameters received an all-zero gradient" % n_zero
