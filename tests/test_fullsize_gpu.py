@@ -4,7 +4,7 @@ checked through size-independent properties of the computation:
   * images of a batch are independent: image i of a batch equals the same image run alone to fp16 rounding (not bit for bit: the
     tile height — 128 or 256 rows — is chosen from the total problem size, and with it the merge order of the fused GroupNorm
     statistics, which moves a few fp16 roundings);
-  * determinism: the same call twice gives identical bits (no atomics anywhere on the path);
+  * determinism: the same call twice gives identical bits (no atomics on the inference path);
   * range / finiteness of depth in [0, 1] and unit-length normals;
   * fp16 and bf16 runs of the same weights agree to 16-bit accuracy;
   * one full-size E2E-FT micro-step (576x576, fp32 master weights, bf16 compute) gives a finite loss and finite, non-zero
