@@ -163,6 +163,9 @@ def test_groupnorm(ops, dev, dtype, C, H, W, c2, silu, offset):
 def test_groupnorm_with_producer_statistics(ops, dev, dtype, H, W, Ci, Co, k, c2):
     """conv / linear epilogues emit the GroupNorm partial statistics of their output; GroupNorm fed with them must match both
     the torch reference and the stand-alone statistics pass (two sources: one with, one without producer statistics)."""
+    import os
+    if os.environ.get("E2EFT_IGEMM") == "1":
+        pytest.skip("the register-staged cross-check kernel (E2EFT_IGEMM=1) does not emit statistics by design")
     g = _g(H * 3 + Co)
     B = 3
     x = q(torch.randn(B, Ci, H, W, generator=g) + 0.5, dtype)
