@@ -55,6 +55,8 @@ SIGNATURES = {
     "e2eft_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "e2eft_gemm": (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P]),
     "e2eft_conv2d_fwd_gnstats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int32), _P]),
+    "e2eft_conv2d_splitk_workspace_bytes": (_Z, [C.POINTER(ConvDesc)]),
+    "e2eft_conv2d_fwd_splitk": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "e2eft_gemm_gnstats": (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _I, _P, _Z, C.POINTER(C.c_int32), _P]),
     "e2eft_groupnorm_fwd_pre": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _Z, _P]),
     "e2eft_groupnorm_workspace_bytes": (_Z, [C.POINTER(GroupNormDesc)]),

@@ -37,6 +37,7 @@ struct IgemmParams {
     int mtiles, ntiles;
     float* gn_partial;   // optional: [img][gn_nslabs][N][3] (n, mean, M2) GroupNorm partials of the rounded output
     int gn_nslabs;       // row slabs (one per M-tile) per image
+    int ksplit_taps;     // conv split-K: batch index zi covers filter taps [zi * ksplit_taps, (zi + 1) * ksplit_taps) (0 = whole K)
 };
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -216,6 +216,63 @@ template <typename T, int MODE> static int launch_igemm(const IgemmParams& p, in
     return check_launch("igemm");
 }
 
+// split-K finish: out = alpha * (sum_z part[z] + bias + rowadd[img(m)]) + residual, 16-byte vectors; thread per (row, chunk)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(int M, int N, int nz, const T* __restrict__ part, long pstride, const T* __restrict__ bias,
+                                                            const T* __restrict__ rowadd, int rows_per_img, float alpha,
+                                                            const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int cch = N / EPC;
+    const long total = (long)M * cch;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const long m = it / cch;
+        const int n = (int)(it - m * cch) * EPC;
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        for (int z = 0; z < nz; ++z) {
+            const Vec16<T> v = ld16(part + z * pstride + m * N + n);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += to_f(v.e[e]);
+        }
+        if (bias) {
+            const Vec16<T> v = ld16(bias + n);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += to_f(v.e[e]);
+        }
+        if (rowadd) {
+            const Vec16<T> v = ld16(rowadd + (m / rows_per_img) * N + n);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += to_f(v.e[e]);
+        }
+        Vec16<T> o;
+        if (res) {
+            const Vec16<T> v = ld16(res + m * ldr + n);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(fmaf(acc[e], alpha, to_f(v.e[e])));
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(acc[e] * alpha);
+        }
+        st16(out + m * ldo + n, o);
+    }
+}
+
+// split-K plan of a convolution: by rows of filter taps, for problems that leave most CUs idle (the 9^2-24^2 UNet layers: ~90
+// 128x128 tiles with K up to 23040).  0 = do not split.
+static int conv_splitk_plan(const E2eftConvDesc* d) {
+    const int epc = 16 / (int)dtype_size(d->dtype);
+    const int bk = 128 / (int)dtype_size(d->dtype);
+    const int cin = d->c1 + d->c2;
+    const long M = (long)d->batch * d->hout * d->wout;
+    const long tiles = ((M + 127) / 128) * ((d->cout + 127) / 128);
+    if (d->kh < 2 || tiles >= 160 || (long)d->kh * d->kw * cin < 2304) return 0;
+    if (cin % bk != 0 || d->c1 % bk != 0 || d->cout % epc != 0) return 0;          // FAST path + vector finish
+    const long img_bytes = (long)d->hin * d->win * (d->ldx1 > d->ldx2 ? d->ldx1 : d->ldx2) * (long)dtype_size(d->dtype);
+    if (img_bytes * (256 / ((long)d->hout * d->wout) + 2) >= 0xD0000000L) return 0;
+    return d->kh;
+}
+
 static int run_igemm(int dtype, int mode, IgemmParams& p, int nz, void* stream) {
     p.mtiles = cdiv(p.M, BM);
     p.ntiles = cdiv(p.N, BN);
@@ -252,9 +309,35 @@ extern "C" int e2eft_conv2d_fwd(const E2eftConvDesc* d, const void* x1, const vo
     return e2eft_conv2d_fwd_gnstats(d, x1, x2, w, bias, rowadd, residual, out, nullptr, 0, nullptr, stream);
 }
 
+extern "C" size_t e2eft_conv2d_splitk_workspace_bytes(const E2eftConvDesc* d) {
+    if (!d || d->dtype < 0 || d->dtype > 2) return 0;
+    const int ns = conv_splitk_plan(d);
+    return ns ? (size_t)ns * d->batch * d->hout * d->wout * d->cout * dtype_size(d->dtype) : 0;
+}
+
+static int conv2d_core(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w, const void* bias, const void* rowadd,
+                       const void* residual, void* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* workspace,
+                       size_t ws_bytes, void* stream);
+
+extern "C" int e2eft_conv2d_fwd_splitk(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w, const void* bias,
+                                       const void* rowadd, const void* residual, void* out, void* workspace, size_t ws_bytes, void* stream) {
+    E2EFT_REQUIRE(d && workspace, "conv2d_splitk: null pointer");
+    const size_t need = e2eft_conv2d_splitk_workspace_bytes(d);
+    E2EFT_REQUIRE(need > 0, "conv2d_splitk: this problem is not split (e2eft_conv2d_splitk_workspace_bytes == 0)");
+    if (ws_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "conv2d_splitk: workspace %zu < %zu", ws_bytes, need);
+    E2EFT_REQUIRE(((uintptr_t)workspace & 15) == 0, "conv2d_splitk: workspace must be 16-byte aligned");
+    return conv2d_core(d, x1, x2, w, bias, rowadd, residual, out, nullptr, 0, nullptr, workspace, ws_bytes, stream);
+}
+
 extern "C" int e2eft_conv2d_fwd_gnstats(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w,
                                         const void* bias, const void* rowadd, const void* residual, void* out,
                                         float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* stream) {
+    return conv2d_core(d, x1, x2, w, bias, rowadd, residual, out, gn_partial, gn_partial_bytes, slab_rows, nullptr, 0, stream);
+}
+
+static int conv2d_core(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w, const void* bias, const void* rowadd,
+                       const void* residual, void* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* workspace,
+                       size_t ws_bytes, void* stream) {
     if (slab_rows) *slab_rows = 0;
     E2EFT_REQUIRE(d && x1 && w && out, "conv2d: null pointer");
     const int epc = 16 / (int)dtype_size(d->dtype);
@@ -295,6 +378,28 @@ extern "C" int e2eft_conv2d_fwd_gnstats(const E2eftConvDesc* d, const void* x1, 
         const size_t need = (size_t)d->batch * (size_t)cdiv(p.rows_per_img, 128) * (size_t)d->cout * 3 * sizeof(float);
         if (gn_partial_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "conv2d: gn_partial %zu < %zu bytes", gn_partial_bytes, need);
         p.gn_partial = gn_partial;
+    }
+    if (workspace) {   // split-K over rows of filter taps: partial sums in the workspace, then one finish pass with the whole epilogue
+        const int ns = conv_splitk_plan(d);
+        const int epc2 = 16 / (int)dtype_size(d->dtype);
+        E2EFT_REQUIRE(ns > 0 && !plain, "conv2d_splitk: not a split problem");
+        E2EFT_REQUIRE(d->ldo % epc2 == 0 && ((uintptr_t)out & 15) == 0 && (!residual || (d->ldr % epc2 == 0 && ((uintptr_t)residual & 15) == 0)) &&
+                          (!bias || ((uintptr_t)bias & 15) == 0) && (!rowadd || ((uintptr_t)rowadd & 15) == 0), "conv2d_splitk: vector alignment");
+        IgemmParams q = p;
+        q.bias = nullptr; q.rowadd = nullptr; q.residual = nullptr; q.gn_partial = nullptr;
+        q.out = workspace; q.ldo = d->cout; q.alpha = 1.f;
+        q.ksplit_taps = d->kw;
+        q.nzi = ns; q.sa_o = q.sa_i = q.sw_o = q.sw_i = 0; q.so_o = 0; q.so_i = (long)p.M * d->cout; q.sr_o = q.sr_i = 0;
+        const int rc2 = run_igemm(d->dtype, 1, q, ns, stream);
+        if (rc2) return rc2;
+        const long total = (long)p.M * (d->cout / epc2);
+        long nb = (total + 255) / 256;
+        if (nb > 16384) nb = 16384;
+        hipStream_t s = (hipStream_t)stream;
+        E2EFT_DISPATCH_DTYPE(d->dtype, T, hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3((unsigned)nb), dim3(256), 0, s, p.M, d->cout, ns, (const T*)workspace,
+                                                          (long)p.M * d->cout, (const T*)bias, (const T*)rowadd, p.rows_per_img, d->alpha, (const T*)residual,
+                                                          d->ldr, (T*)out, d->ldo));
+        return check_launch("conv2d_splitk");
     }
     const int rc = run_igemm(d->dtype, plain ? 0 : 1, p, 1, stream);
     if (rc == 0 && slab_rows && p.gn_partial) *slab_rows = p.rows_per_img / p.gn_nslabs;

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
 
     const T* __restrict__ X1 = (const T*)p.x1 + zo * p.sa_o + zi * p.sa_i;
     const T* __restrict__ X2 = (const T*)p.x2;
-    const T* __restrict__ W = (const T*)p.w + zo * p.sw_o + zi * p.sw_i;
+    const int tap0 = (MODE == 1 && p.ksplit_taps > 0) ? zi * p.ksplit_taps : 0;   // split-K over filter-tap rows (FAST path only)
+    const T* __restrict__ W = (const T*)p.w + zo * p.sw_o + zi * p.sw_i + (long)tap0 * p.cin;
     const T* zsrc = (const T*)g_zero16;
 
     // ---- loader mapping: a wave-instruction fills one 1-KiB piece = 8 rows x 8 chunks; lane -> (row lane>>3, slot lane&7).
@@ -193,14 +194,14 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = ((MODE == 1 && p.ksplit_taps > 0 ? p.ksplit_taps * p.cin : p.K) + BK - 1) / BK;
 
     if constexpr (FAST) {
         // ============================ FAST path =====================================================================
         unsigned int off1[4], off2[4];          // per-row byte offsets of the current tap in x1 / x2 (OOB_SENTINEL if invalid)
         unsigned int cur_a[4], cur_b[4];        // byte offsets of the NEXT tile to issue (advanced by 128 B per tile)
         int brel[4] = {0, 0, 0, 0};
-        int tile_c = 0, tap = 0;
+        int tile_c = 0, tap = tap0;
         const T* b1;
         const T* b2 = X2;
         if (MODE == 0) {
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
                 base2[i] = (pix0 * (unsigned)p.ldx2 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T);
             }
         }
-        int ky = 0, kx = 0;     // the current tap, advanced incrementally (no division per tap change)
+        int ky = MODE == 1 ? tap0 / p.kw : 0, kx = MODE == 1 ? tap0 - ky * p.kw : 0;   // the current tap, advanced incrementally
         auto retap = [&]() {   // per-row pixel offsets of the current filter tap (uniform branch, once per tap)
             if (plain_taps) {
                 const unsigned d1 = (unsigned)((ky * p.win + kx) * p.ldx1) * (unsigned)sizeof(T);
@@ -483,6 +484,7 @@ template <typename T, int MODE, int NW> static int launch2(IgemmParams& p, int n
         fast = p.cin % BK == 0 && p.c1 % BK == 0 && img_bytes * span_imgs < 0xD0000000L && (long)128 * p.ldw * (long)sizeof(T) < 0x40000000L;
     }
     static const bool nofast = getenv("E2EFT_IGEMM_NOFAST") != nullptr;
+    if (p.ksplit_taps > 0 && !(fast && !nofast && MODE == 1)) return fail(E2EFT_ERR_BAD_ARG, "igemm2: split-K needs the FAST conv path");
     if (fast && !nofast) hipLaunchKernelGGL((igemm2_kernel<T, MODE, true, NW>), grid, dim3(NW * 64), 0, s, p);
     else hipLaunchKernelGGL((igemm2_kernel<T, MODE, false, NW>), grid, dim3(NW * 64), 0, s, p);
     return check_launch("igemm2");

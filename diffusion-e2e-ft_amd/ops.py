@@ -140,6 +140,7 @@ class GnStats:
 
 
 GN_STATS_ENABLED = True   # tests flip this to cross-check the fused statistics against the stand-alone pass
+SPLITK_ENABLED = True     # tests flip this to cross-check split-K convolutions against the single-pass kernel
 
 
 def _gn_buffer(images, rows_per_image, cout, device):
@@ -196,7 +197,13 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
     nb = (B * H * W * (d.c1 + d.c2) + B * hout * wout * cout * (2 if residual is not None else 1) + cout * kh * kw * (d.c1 + d.c2)) * es
     with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2), nb,
                 label="conv%dx%ds%d%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", B, hout, wout, d.c1 + d.c2, cout)):
-        if want:
+        lib = _lib.load()
+        sk = lib.e2eft_conv2d_splitk_workspace_bytes(C.byref(d)) if SPLITK_ENABLED else 0
+        if sk:   # few output tiles, long reduction: split-K (the consumer GroupNorm computes its own statistics)
+            ws = torch.empty(sk // x.element_size(), dtype=x.dtype, device=x.device)
+            check(lib.e2eft_conv2d_fwd_splitk(C.byref(d), _ptr(x), _ptr(x2), _ptr(w_packed), _ptr(bias), _ptr(rowadd), _ptr(residual), _ptr(out),
+                                              _ptr(ws), sk, _stream()))
+        elif want:
             buf, nbytes = _gn_buffer(B, hout * wout, cout, x.device)
             slab = C.c_int32(0)
             check(_lib.load().e2eft_conv2d_fwd_gnstats(C.byref(d), _ptr(x), _ptr(x2), _ptr(w_packed), _ptr(bias), _ptr(rowadd),

@@ -105,6 +105,12 @@ int e2eft_gemm(const E2eftGemmDesc* d, const void* a, const void* w, const void*
 int e2eft_conv2d_fwd_gnstats(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w, const void* bias,
                              const void* rowadd, const void* residual, void* out, float* gn_partial,
                              size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
+/* Split-K variant for convolutions with few output tiles and a long reduction (the 9x9 - 24x24 UNet layers: M = B*H*W ~ 10^3,
+ * K = 9*Cin up to 23040): the reduction is split by rows of filter taps across workgroups, partial sums go to `workspace`, a finish
+ * pass applies bias / rowadd / alpha / residual.  e2eft_conv2d_splitk_workspace_bytes returns 0 when the library would not split. */
+size_t e2eft_conv2d_splitk_workspace_bytes(const E2eftConvDesc* d);
+int e2eft_conv2d_fwd_splitk(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w, const void* bias,
+                            const void* rowadd, const void* residual, void* out, void* workspace, size_t ws_bytes, void* stream);
 int e2eft_gemm_gnstats(const E2eftGemmDesc* d, const void* a, const void* w, const void* bias, const void* residual,
                        void* out, int32_t rows_per_image, float* gn_partial, size_t gn_partial_bytes,
                        int32_t* slab_rows, void* stream);

@@ -380,3 +380,34 @@ def test_errors_are_reported(ops, dev):
         ops.gemm(torch.zeros(4, 6, device=dev, dtype=torch.float16), torch.zeros(4, 6, device=dev, dtype=torch.float16))  # k % 8 != 0
     with pytest.raises(RuntimeError, match="device"):
         ops.gemm(torch.zeros(8, 8), torch.zeros(8, 8))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,c1,c2,co,stride", [(2, 12, 12, 256, 0, 128, 1), (1, 9, 9, 128, 128, 320, 1), (2, 24, 24, 256, 0, 128, 2), (3, 6, 10, 320, 0, 64, 1)])
+def test_conv_splitk_small_spatial(ops, dev, dtype, B, H, W, c1, c2, co, stride):
+    """few output tiles + long reduction: the library splits K by rows of filter taps (e2eft_conv2d_fwd_splitk); the result must match
+    both torch and the single-pass kernel, with the whole epilogue (bias, per-image rowadd, alpha, residual) applied by the finish pass"""
+    g = _g(H * 5 + co)
+    cin = c1 + c2
+    x = q(torch.randn(B, cin, H, W, generator=g), dtype)
+    w = q(torch.randn(co, cin, 3, 3, generator=g) / (cin * 9) ** 0.5, dtype)
+    bias, rowadd = q(torch.randn(co, generator=g), dtype), q(torch.randn(B, co, generator=g), dtype)
+    ho, wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    res = q(torch.randn(B, co, ho, wo, generator=g), dtype)
+    ref = 0.5 * (F.conv2d(x, w, bias, stride, 1) + rowadd[:, :, None, None]) + res
+    xn = nhwc(x, dtype, dev)
+    x1, x2 = (xn[..., :c1], xn[..., c1:]) if c2 else (xn, None)
+    wp = pack_conv_weight(w, dtype, dev)
+    args = dict(x2=x2, rowadd=rowadd.to(dtype).to(dev), residual=nhwc(res, dtype, dev), alpha=0.5)
+    from diffusion_e2e_ft_amd import _lib, ops as _o
+    import ctypes
+    d = _o._conv_desc(x1, x2, co, 3, 3, stride, (1, 1, 1, 1), None, 0.5, ldo=co)
+    assert _lib.load().e2eft_conv2d_splitk_workspace_bytes(ctypes.byref(d)) > 0, "this shape is expected to be split"
+    out = ops.conv2d(x1, wp, bias.to(dtype).to(dev), co, 3, 3, stride, (1, 1, 1, 1), **args)
+    assert_close(to_nchw(out), ref, dtype, "split-K conv", scale=2)
+    ops.SPLITK_ENABLED = False
+    try:
+        one = ops.conv2d(x1, wp, bias.to(dtype).to(dev), co, 3, 3, stride, (1, 1, 1, 1), **args)
+    finally:
+        ops.SPLITK_ENABLED = True
+    assert_close(to_nchw(out), to_nchw(one), dtype, "split-K vs single pass", scale=2)
