@@ -93,7 +93,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
     // hoisted, so the pass loop is straight-line code: x = fma(acc, alpha, bias*alpha) [+ rowadd*alpha] [+ residual], one
     // v_cvt_pk per column pair, one 16-byte store per row chunk.  (The generic loop below costs ~9k cycles per 256x128 tile in
     // exec-mask branches and scalar fallbacks even when none is taken — scripts/stamp_bench.py.)
-    const bool full = vec && m0 + BM_ <= p.M && n0 + BN_ <= p.N && !(bias && p.bias_along_m);
+    const bool full = vec && m0 + BM_ <= p.M && !(bias && p.bias_along_m);   // a ragged last N-tile only idles the threads of its missing chunks
     if (full) {
         const float al = p.alpha;
         float bva[8];
@@ -163,12 +163,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
                 }
             }
         };
-        if (res) {
-            if (rowadd) run(std::true_type{}, std::true_type{});
-            else run(std::true_type{}, std::false_type{});
-        } else {
-            if (rowadd) run(std::false_type{}, std::true_type{});
-            else run(std::false_type{}, std::false_type{});
+        if (col_ok) {
+            if (res) {
+                if (rowadd) run(std::true_type{}, std::true_type{});
+                else run(std::true_type{}, std::false_type{});
+            } else {
+                if (rowadd) run(std::false_type{}, std::true_type{});
+                else run(std::false_type{}, std::false_type{});
+            }
         }
         if (stats) {   // uniform.  lanes l, l^16, l^32, l^48 own the same 8 columns: add; then the waves through LDS
 #pragma unroll
@@ -189,7 +191,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
                 }
             }
             __syncthreads();
-            if (threadIdx.x < BN_) {
+            if (threadIdx.x < BN_ && n0 + (int)threadIdx.x < p.N) {
                 const int c = threadIdx.x;
                 float su = 0.f, sq = 0.f;
 #pragma unroll
