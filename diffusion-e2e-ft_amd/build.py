@@ -16,6 +16,12 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libe2eft.so")
 SOURCES = ["api.hip", "igemm.hip", "igemm2.hip", "igemm3.hip", "norm.hip", "attn.hip", "attn_bwd.hip", "elementwise.hip", "loss.hip", "bwd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# Per-file flags.  The implicit-GEMM files are built without the SLP vectorizer: it turns the epilogue's per-column fp32
+# arithmetic into v_pk_add_f32 with operand swizzles (op_sel:[0,1] — the low result lane reads the HIGH dword of src1), and on
+# gfx950 that form sporadically read 0.0 in lanes 48-63 while a wave of ANOTHER workgroup on the same SIMD was inside its
+# MFMA / LDS-DMA k-loop (two 4-wave workgroups per CU).  Found as one GroupNorm-statistics row in ~1e-5 tiles using pivot 0;
+# plain v_sub_f32 / v_add_f32 never showed it (scripts/stress_conv_stats.py).
+EXTRA_FLAGS = {"igemm.hip": ["-fno-slp-vectorize"], "igemm2.hip": ["-fno-slp-vectorize"], "igemm3.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -26,7 +32,7 @@ def _hipcc():
 
 
 def _newest_source_mtime():
-    paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "e2eft.h")]
+    paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "e2eft.h"), os.path.abspath(__file__)]
     return max(os.path.getmtime(p) for p in paths)
 
 
@@ -44,10 +50,10 @@ def build(force=False, verbose=True):
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
-        deps = [srcp, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm.h"), os.path.join(HERE, "..", "include", "e2eft.h")]
+        deps = [srcp, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm.h"), os.path.join(HERE, "..", "include", "e2eft.h"), os.path.abspath(__file__)]
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(d) for d in deps):
             return obj
-        cmd = [hipcc] + FLAGS + ["-c", srcp, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", srcp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -78,7 +84,7 @@ def build_stamps(verbose=True):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        r = subprocess.run([hipcc] + FLAGS + ["-DE2EFT_STAMPS", "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+        r = subprocess.run([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-DE2EFT_STAMPS", "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
         return obj
