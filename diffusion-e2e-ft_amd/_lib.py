@@ -102,6 +102,12 @@ SIGNATURES = {
     "e2eft_sumsq": (_I, [_L, _P, _P, _P]),
     "e2eft_adamw_step": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _F, _F, _P]),
     "e2eft_cast": (_I, [_I, _I, _L, _F, _I, _P, _P, _P]),
+    "e2eft_ensemble_workspace_bytes": (_Z, [_I]),
+    "e2eft_ensemble_minmax": (_I, [_I, _L, _P, _P, _P, _Z, _P]),
+    "e2eft_ensemble_gram": (_I, [_I, _L, _P, _P, _P, _P, _Z, _P]),
+    "e2eft_ensemble_depth_reduce": (_I, [_I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "e2eft_ensemble_depth_finish": (_I, [_L, _P, _P, _P, _P]),
+    "e2eft_ensemble_normals": (_I, [_I, _L, _P, _P, _P, _P, _Z, _P]),
 }
 
 
@@ -127,7 +133,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.e2eft_version() < 110:
+    if lib.e2eft_version() < 111:
         raise RuntimeError("libe2eft.so is stale (version %d)" % lib.e2eft_version())
     _LIB = lib
     return lib

@@ -844,3 +844,64 @@ def cast_(x, y, mul=1.0, accumulate=False):
     assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
     check(_lib.load().e2eft_cast(dtype_id(x.dtype), dtype_id(y.dtype), x.numel(), mul, 1 if accumulate else 0, _ptr(x), _ptr(y), _stream()))
     return y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# test-time ensembling (csrc/ensemble.hip): x is the fp32 [N, ...] stack of the N predictions of one image
+def _ens_stack(x):
+    _check_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() >= 2, "ensemble: need a contiguous fp32 [N, ...] stack"
+    n = x.shape[0]
+    lib = _lib.load()
+    nbytes = lib.e2eft_ensemble_workspace_bytes(n)
+    if nbytes == 0:
+        raise RuntimeError("ensemble: %s" % lib.e2eft_last_error().decode())
+    return n, x.numel() // n, torch.empty(nbytes // 8, dtype=torch.float64, device=x.device), nbytes
+
+
+def ensemble_minmax(x):
+    """[N, 2] (min, max) of every image of the stack"""
+    n, npix, ws, nbytes = _ens_stack(x)
+    out = torch.empty((n, 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().e2eft_ensemble_minmax(n, npix, _ptr(x), _ptr(out), _ptr(ws), nbytes, _stream()))
+    return out
+
+
+def ensemble_gram(x):
+    """fp64 (gram [N, N] = sum_p x_i x_j, sums [N] = sum_p x_i)"""
+    n, npix, ws, nbytes = _ens_stack(x)
+    gram = torch.empty((n, n), dtype=torch.float64, device=x.device)
+    sums = torch.empty(n, dtype=torch.float64, device=x.device)
+    check(_lib.load().e2eft_ensemble_gram(n, npix, _ptr(x), _ptr(gram), _ptr(sums), _ptr(ws), nbytes, _stream()))
+    return gram, sums
+
+
+def ensemble_depth_reduce(x, scale, shift, use_mean=False, want_images=True):
+    """a_i = x_i * scale_i + shift_i -> (pred, uncertainty, minmax [2]); pred / uncertainty are None when want_images is False"""
+    n, npix, ws, nbytes = _ens_stack(x)
+    _check_cuda(scale, shift)
+    assert scale.dtype == torch.float32 and shift.dtype == torch.float32 and scale.numel() == n and shift.numel() == n
+    pred = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device) if want_images else None
+    unc = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device) if want_images else None
+    minmax = torch.empty(2, dtype=torch.float32, device=x.device)
+    check(_lib.load().e2eft_ensemble_depth_reduce(n, npix, _ptr(x), _ptr(scale.contiguous()), _ptr(shift.contiguous()), 1 if use_mean else 0,
+                                                  _ptr(pred), _ptr(unc), _ptr(minmax), _ptr(ws), nbytes, _stream()))
+    return pred, unc, minmax
+
+
+def ensemble_depth_finish_(pred, unc, minmax):
+    """in place: pred = (pred - min) / (max - min), unc /= (max - min)"""
+    _check_cuda(pred, unc, minmax)
+    assert pred.dtype == torch.float32 and pred.is_contiguous() and (unc is None or (unc.is_contiguous() and unc.numel() == pred.numel()))
+    check(_lib.load().e2eft_ensemble_depth_finish(pred.numel(), _ptr(minmax), _ptr(pred), _ptr(unc), _stream()))
+    return pred, unc
+
+
+def ensemble_normals(x):
+    """x [N, 3, H, W] -> (unit vectors [N, 3, H, W], fp64 [N] summed angular error to the mean direction)"""
+    n, npix3, ws, nbytes = _ens_stack(x)
+    assert x.dim() == 4 and x.shape[1] == 3
+    unit = torch.empty_like(x)
+    err = torch.empty(n, dtype=torch.float64, device=x.device)
+    check(_lib.load().e2eft_ensemble_normals(n, npix3 // 3, _ptr(x), _ptr(unit), _ptr(err), _ptr(ws), nbytes, _stream()))
+    return unit, err

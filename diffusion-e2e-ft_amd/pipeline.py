@@ -153,10 +153,11 @@ class MarigoldPipeline:
         for s in range(0, ensemble_size, bs):
             preds.append(self.single_infer(dup[s:s + bs], denoising_steps, show_progress_bar, noise=noise, normals=normals))
         preds = torch.cat(preds, dim=0).float().squeeze()
-        if ensemble_size > 1:
-            raise NotImplementedError("test-time ensembling (ensemble_size > 1) is SURVEY.md §8f 'next'; E2E-FT uses ensemble_size=1 "
-                                      "(marigold_pipeline.py:293-297)")
-        pred, pred_uncert = preds, None
+        if ensemble_size > 1:   # marigold_pipeline.py:293-297 (E2E-FT checkpoints are run with ensemble_size=1)
+            from .ensemble import ensemble_depths, ensemble_normals
+            pred, pred_uncert = ensemble_normals(preds) if normals else ensemble_depths(preds, **(ensemble_kwargs or {}))
+        else:
+            pred, pred_uncert = preds, None
         if normals:
             pred = pred / (torch.norm(pred, p=2, dim=0, keepdim=True) + 1e-5)
         else:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define E2EFT_VERSION 110 /* 0.1.1: backward entry points */
+#define E2EFT_VERSION 111 /* 0.1.1: backward entry points; 111: test-time ensembling */
 
 enum {
     E2EFT_OK = 0,
@@ -299,6 +299,30 @@ int e2eft_ssi_loss_bwd(int32_t batch, int32_t hw, const float* pred, const float
                        void* workspace, size_t ws_bytes, void* stream);
 int e2eft_angular_loss_bwd(int32_t batch, int32_t hw, const float* pred, const float* target, const uint8_t* mask,
                            const void* fwd_workspace, const float* grad_out, float* dpred, void* stream);
+/* Test-time ensembling of the n_img (<= 32) predictions of ONE image, fp32, replacing
+ *   ensemble_depths   /root/reference/Marigold/marigold/util/ensemble.py:40-132 (called from marigold_pipeline.py:293-297;
+ *                     twin GeoWizard/geowizard/utils/depth_ensemble.py:21-115)
+ *   ensemble_normals  /root/reference/Marigold/marigold/marigold_pipeline.py:58-71 (twin GeoWizard/geowizard/utils/normal_ensemble.py:6-23)
+ * x is the [n_img][npix] stack.  Every reduction is two-stage over a fixed number of partials (bit-reproducible); one workspace of
+ * e2eft_ensemble_workspace_bytes(n_img) serves all entries.
+ *   _minmax        out[i] = (min, max) of image i                                    (the initial guess, ensemble.py:68-71)
+ *   _gram          gram[i][j] = sum_p x_i x_j, sums[i] = sum_p x_i (fp64): sufficient statistics of the pairwise term of the
+ *                  alignment objective (ensemble.py:85-86), so that one evaluation costs no pass over the stack
+ *   _depth_reduce  a_i = x_i * scale[i] + shift[i]; pred = lower median over i (use_mean = 0, torch.median) with the median
+ *                  absolute deviation as uncertainty, or mean with the unbiased standard deviation (use_mean = 1);
+ *                  minmax = (min, max) of pred.  pred / uncertainty may be NULL (objective evaluation: ensemble.py:88-96)
+ *   _depth_finish  pred = (pred - min) / (max - min), uncertainty /= (max - min), range read from device memory (ensemble.py:129-133)
+ *   _normals       x, unit: [n_img][3][hw].  unit = x / (|x| + 1e-5); err[i] = sum_p acos(clip(cos(unit_i, mean direction))), the
+ *                  mean direction built from the mean azimuth / polar angles; the caller returns unit[argmin err]. */
+size_t e2eft_ensemble_workspace_bytes(int32_t n_img);
+int e2eft_ensemble_minmax(int32_t n_img, int64_t npix, const float* x, float* out, void* workspace, size_t ws_bytes, void* stream);
+int e2eft_ensemble_gram(int32_t n_img, int64_t npix, const float* x, double* gram, double* sums, void* workspace, size_t ws_bytes,
+                        void* stream);
+int e2eft_ensemble_depth_reduce(int32_t n_img, int64_t npix, const float* x, const float* scale, const float* shift, int32_t use_mean,
+                                float* pred, float* uncertainty, float* minmax, void* workspace, size_t ws_bytes, void* stream);
+int e2eft_ensemble_depth_finish(int64_t npix, const float* minmax, float* pred, float* uncertainty, void* stream);
+int e2eft_ensemble_normals(int32_t n_img, int64_t hw, const float* x, float* unit, double* err, void* workspace, size_t ws_bytes,
+                           void* stream);
 /* Flat-buffer optimizer step (torch.optim.AdamW + accelerator.clip_grad_norm_, train.py:561-566): all trainable
  * parameters / gradients / moments are single fp32 buffers.  e2eft_sumsq: out[0] = sum g^2 (fp64).  e2eft_adamw_step
  * scales the gradient by grad_scale * min(1, max_norm / (sqrt(grad_sumsq) * grad_scale + 1e-6)) when grad_sumsq != NULL

@@ -169,3 +169,30 @@ def geo_train_grads():
     keys = [k for k in TRAIN_FULL_GRADS if k in usd] + ["class_embedding.linear_1.weight"]
     return {"loss": loss.detach(), "ssi": ssi.detach(), "angular": ang.detach(),
             "grad_norms": {k: float(v.grad.norm()) for k, v in usd.items()}, "grads": {k: sample_grad(usd[k].grad) for k in keys}}
+
+
+# ---- test-time ensembling (oracle/ensemble_ref.py, tests/golden/make_ensemble_golden.py) -------------------------------------
+def ensemble_depth_stack(n=10, H=48, W=64, seed=31):
+    """N affine-distorted, noisy copies of one smooth depth map (what the N diffusion samples of one image look like)"""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    base = 0.3 + 0.5 * yy + 0.2 * torch.sin(6 * xx) * yy
+    rows = [(0.5 + torch.rand(1, generator=g)) * base + 0.3 * torch.randn(1, generator=g) + 0.02 * torch.randn(H, W, generator=g)
+            for _ in range(n)]
+    return torch.stack(rows).float()
+
+
+def ensemble_normal_stack(n=6, H=40, W=56, seed=33):
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    base = torch.stack([0.6 * xx, 0.4 * yy + 0.2 * torch.sin(3 * xx), 0.3 + 0.7 * (1 - 0.5 * (xx ** 2 + yy ** 2))])
+    return torch.stack([1.3 * base + 0.15 * torch.randn(3, H, W, generator=g) for _ in range(n)]).float()
+
+
+ENSEMBLE_DEPTH_CASES = {
+    "median10": dict(stack=dict(n=10), kw={}),
+    "median7_odd": dict(stack=dict(n=7, H=33, W=47, seed=35), kw={}),
+    "mean5": dict(stack=dict(n=5, seed=36), kw=dict(reduction="mean")),
+    "median4_maxres": dict(stack=dict(n=4, H=40, W=72, seed=37), kw=dict(max_res=32, max_iter=5)),
+    "median2": dict(stack=dict(n=2, seed=38), kw=dict(regularizer_strength=0.1)),
+}

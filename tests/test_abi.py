@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "libe2eft.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.e2eft_version() == 110
+    assert lib.e2eft_version() == 111
 
 
 def test_struct_layouts_match_header():
