@@ -46,6 +46,7 @@ def parse():
                     "configs[2] batch in one pass, 122 GB of the 288 GB HBM; 16 in fp32)")
     ap.add_argument("--accum", type=int, default=None, help="--train: gradient-accumulation micro-steps per optimizer step (default 32 / micro-batch)")
     ap.add_argument("--modality", default="depth", choices=["depth", "normals"])
+    ap.add_argument("--no-image-encoder", action="store_true", help="--geowizard: feed a CLIP image embedding as input instead of running ViT-L/14")
     ap.add_argument("--geowizard", action="store_true", help="time GeoWizard joint depth+normals 1-step inference (BASELINE.json configs[4]: "
                     "dual-latent UNet with cross-domain attention, 2 images per GPU by default) instead of Marigold depth")
     ap.add_argument("--no-train-leg", action="store_true", help="inference mode at N=1: skip the short E2E-FT training-step measurement "
@@ -236,11 +237,18 @@ def geowizard_main(args):
         vae = AutoencoderKL().to(dtype)
     init_synthetic_(unet, seed=1234)
     init_synthetic_(vae, seed=4321)
-    pipe = DepthNormalEstimationPipeline(unet.eval(), vae.eval(), DDIMScheduler())
+    enc = None
+    if not args.no_image_encoder:   # CLIP ViT-L/14 is on GeoWizard's per-image path (geowizard_pipeline.py:232-248,283-284)
+        from diffusion_e2e_ft_amd.clip import CLIPVisionModelWithProjection
+        with torch.device(dev):
+            enc = CLIPVisionModelWithProjection().to(dtype)
+        init_synthetic_(enc, seed=2468)
+        enc.eval()
+    pipe = DepthNormalEstimationPipeline(unet.eval(), vae.eval(), DDIMScheduler(), image_encoder=enc)
     B, R = (args.batch if args.batch != 8 else 2), args.res
     g = torch.Generator(device=dev).manual_seed(rank)
     rgb = (torch.randint(0, 256, (B, 3, R, R), generator=g, device=dev, dtype=torch.int32).float() / 255.0 * 2.0 - 1.0).to(dtype)
-    emb = (0.5 * torch.randn((B, 1, 768), generator=g, device=dev)).to(dtype)
+    emb = None if enc is not None else (0.5 * torch.randn((B, 1, 768), generator=g, device=dev)).to(dtype)
     for _ in range(args.warmup):
         out = pipe.single_infer(rgb, emb, "indoor")
     torch.cuda.synchronize()
@@ -267,7 +275,7 @@ def geowizard_main(args):
                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f16" if args.dtype == "fp16" else args.dtype, "data": "synthetic",
                 "config": {"workload": "GeoWizard joint depth+normals 1-step (dual-latent UNet, cross-domain joint attention, class embedding), batch=%d/GPU at "
-                                       "%dx%d %s, random-init weights, CLIP image embedding as input" % (B, R, R, args.dtype),
+                                       "%dx%d %s, random-init weights, %s" % (B, R, R, args.dtype, "CLIP ViT-L/14 image encoder (304M) inside the timed region" if enc is not None else "CLIP image embedding as input"),
                            "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world},
                 "roofline": {"bound": "mfma", "kernel": "igemm2_kernel", "achieved": achieved, "peak": PEAK_TF[args.dtype], "unit": "TFLOP/s",
                              "frac": achieved / PEAK_TF[args.dtype], "traffic": None, "launches_per_step": ig["launches"] / args.steps,

@@ -1,0 +1,148 @@
+"""CLIP ViT image encoder on libe2eft — GeoWizard's per-image conditioning.
+
+Replaces `transformers.CLIPVisionModelWithProjection` as used by
+/root/reference/GeoWizard/geowizard/models/geowizard_pipeline.py:76-86,232-248 (`self.image_encoder(img).image_embeds`): same
+constructor config keys, same state-dict layout (`vision_model.embeddings.*`, `vision_model.encoder.layers.N.*`,
+`vision_model.pre_layrnorm` [sic], `vision_model.post_layernorm`, `visual_projection`), same output attribute.  Inference only (the
+encoder is frozen everywhere in the reference).  ViT-L/14: 24 layers x (LN -> 16-head attention d=64 -> +, LN -> 1024-4096-1024
+quick-GELU MLP -> +) over 257 tokens; every matmul runs on the implicit-GEMM kernel (residuals folded into the epilogue), the
+attention core on the fused d=64 kernel, LayerNorm / activation as HBM streams.
+"""
+import torch
+import torch.nn as nn
+
+from . import autograd as F
+from . import ops
+from .modules import Conv2d, LayerNorm, Linear, conv_nhwc, to_nhwc
+
+CLIP_VIT_L14 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=224,
+                    patch_size=14, projection_dim=768, hidden_act="quick_gelu", layer_norm_eps=1e-5, num_channels=3)
+# transformers CLIPImageProcessor defaults (feature_extractor.image_mean / image_std / crop_size of the hub preprocessor config)
+CLIP_IMAGE_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_IMAGE_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class _Out:
+    def __init__(self, image_embeds, last_hidden_state):
+        self.image_embeds, self.last_hidden_state = image_embeds, last_hidden_state
+
+    def __getitem__(self, i):
+        return (self.image_embeds, self.last_hidden_state)[i]
+
+
+class CLIPAttention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.heads, self.scale = heads, (dim // heads) ** -0.5
+        self.k_proj, self.v_proj, self.q_proj, self.out_proj = Linear(dim, dim), Linear(dim, dim), Linear(dim, dim), Linear(dim, dim)
+
+    def forward(self, x, residual):
+        bias = F.cached(self, "bqkv_%s" % x.dtype, (self.q_proj.bias, self.k_proj.bias, self.v_proj.bias),
+                        lambda: torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]).detach().to(x.dtype))
+        qkv = F.linear(x, (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight), bias, owner=self, name="wqkv")
+        return self.out_proj(F.attention(qkv, None, self.heads, self.scale), residual=residual)
+
+
+class CLIPMLP(nn.Module):
+    def __init__(self, dim, inner, act):
+        super().__init__()
+        if act not in ops.ACT_KINDS:
+            raise ValueError("unsupported CLIP hidden_act %r" % (act,))
+        self.act = act
+        self.fc1, self.fc2 = Linear(dim, inner), Linear(inner, dim)
+
+    def forward(self, x, residual):
+        return self.fc2(ops.activation(self.fc1(x), self.act), residual=residual)
+
+
+class CLIPEncoderLayer(nn.Module):
+    def __init__(self, dim, inner, heads, act, eps):
+        super().__init__()
+        self.self_attn = CLIPAttention(dim, heads)
+        self.layer_norm1 = LayerNorm(dim, eps=eps)
+        self.mlp = CLIPMLP(dim, inner, act)
+        self.layer_norm2 = LayerNorm(dim, eps=eps)
+
+    def forward(self, x):
+        x = self.self_attn(self.layer_norm1(x), residual=x)
+        return self.mlp(self.layer_norm2(x), residual=x)
+
+
+class CLIPVisionEmbeddings(nn.Module):
+    def __init__(self, dim, image_size, patch, channels):
+        super().__init__()
+        self.class_embedding = nn.Parameter(torch.randn(dim))
+        self.patch_embedding = Conv2d(channels, dim, kernel_size=patch, stride=patch, bias=False)
+        self.num_positions = (image_size // patch) ** 2 + 1
+        self.position_embedding = nn.Embedding(self.num_positions, dim)
+
+    def forward(self, pixel_values):
+        B = pixel_values.shape[0]
+        dt = self.patch_embedding.weight.dtype
+        p = conv_nhwc(self.patch_embedding, to_nhwc(pixel_values.to(dt)), gn_stats=False)      # [B, g, g, C]: the 14x14/14 conv is one GEMM, K = 14*14*8
+        C = p.shape[-1]
+        pos = self.position_embedding.weight
+        x = torch.empty((B, self.num_positions, C), dtype=dt, device=p.device)
+        x[:, 0] = self.class_embedding + pos[0]
+        torch.add(p.reshape(B, -1, C), pos[1:], out=x[:, 1:])
+        return x
+
+
+class _Encoder(nn.Module):
+    def __init__(self, n, *a):
+        super().__init__()
+        self.layers = nn.ModuleList([CLIPEncoderLayer(*a) for _ in range(n)])
+
+
+class CLIPVisionTransformer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        dim = c["hidden_size"]
+        self.embeddings = CLIPVisionEmbeddings(dim, c["image_size"], c["patch_size"], c["num_channels"])
+        self.pre_layrnorm = LayerNorm(dim, eps=c["layer_norm_eps"])   # the misspelling is the checkpoint key
+        self.encoder = _Encoder(c["num_hidden_layers"], dim, c["intermediate_size"], c["num_attention_heads"], c["hidden_act"], c["layer_norm_eps"])
+        self.post_layernorm = LayerNorm(dim, eps=c["layer_norm_eps"])
+
+    def forward(self, pixel_values):
+        x = self.pre_layrnorm(self.embeddings(pixel_values))
+        for layer in self.encoder.layers:
+            x = layer(x)
+        return x, self.post_layernorm(x[:, 0].contiguous())
+
+
+class CLIPVisionModelWithProjection(nn.Module):
+    """`image_encoder` slot of DepthNormalEstimationPipeline (geowizard_pipeline.py:76-86)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        cfg = dict(CLIP_VIT_L14)
+        cfg.update(kwargs)
+        self.config = cfg
+        self.vision_model = CLIPVisionTransformer(cfg)
+        self.visual_projection = Linear(cfg["hidden_size"], cfg["projection_dim"], bias=False)
+
+    @property
+    def dtype(self):
+        return self.visual_projection.weight.dtype
+
+    @property
+    def device(self):
+        return self.visual_projection.weight.device
+
+    def load_state_dict(self, sd, strict=True, **kw):
+        sd = {k: v for k, v in sd.items() if not k.endswith("position_ids")}   # a persistent buffer in older transformers releases
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    @torch.no_grad()
+    def forward(self, pixel_values, **unused):
+        last, pooled = self.vision_model(pixel_values.to(self.device))
+        return _Out(self.visual_projection(pooled), last)
+
+
+def preprocess_for_clip(rgb, size=224, mean=CLIP_IMAGE_MEAN, std=CLIP_IMAGE_STD):
+    """geowizard_pipeline.py:236-245: rgb in [-1, 1] [B,3,H,W] -> bicubic antialiased resize of (rgb+1)/2 to size x size, then
+    (x - mean) / std in float32 (torchvision TF.resize(antialias=True) == F.interpolate(mode="bicubic", antialias=True))."""
+    x = torch.nn.functional.interpolate((rgb + 1) / 2, size=(size, size), mode="bicubic", antialias=True, align_corners=False)
+    m = torch.tensor(mean, device=rgb.device, dtype=torch.float32)[:, None, None]
+    s = torch.tensor(std, device=rgb.device, dtype=torch.float32)[:, None, None]
+    return ((x.float() - m) / s).to(rgb.dtype)

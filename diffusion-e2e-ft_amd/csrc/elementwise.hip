@@ -78,6 +78,25 @@ __global__ __launch_bounds__(256) void silu_kernel(long n, const T* __restrict__
     for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < n; it += (long)gridDim.x * 256) y[it] = from_f<T>(silu_f(to_f(x[it])));
 }
 
+// y = act(x) on a flat buffer, 16-byte vectors + scalar tail.  kind: 0 quick_gelu x*sigmoid(1.702x) (CLIP), 1 gelu (erf), 2 silu
+template <typename T>
+__global__ __launch_bounds__(256) void act_kernel(int kind, long n, const T* __restrict__ x, T* __restrict__ y) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    auto f = [kind](float v) {
+        if (kind == 0) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
+        if (kind == 1) return gelu_erf_f(v);
+        return silu_f(v);
+    };
+    const long nv = n / EPC;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < nv; it += (long)gridDim.x * 256) {
+        Vec16<T> v = ld16(x + it * EPC), o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(f(to_f(v.e[e])));
+        st16(y + it * EPC, o);
+    }
+    for (long it = nv * EPC + (long)blockIdx.x * 256 + threadIdx.x; it < n; it += (long)gridDim.x * 256) y[it] = from_f<T>(f(to_f(x[it])));
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void depth_head_kernel(long pixels, int ldx, int to_unit, const TI* __restrict__ x, TO* __restrict__ y) {
     for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < pixels; it += (long)gridDim.x * 256) {
@@ -187,6 +206,16 @@ extern "C" int e2eft_silu(int32_t dtype, int64_t n, const void* x, void* y, void
     const unsigned g = grid_for(n);
     E2EFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((silu_kernel<T>), dim3(g), dim3(256), 0, s, (long)n, (const T*)x, (T*)y));
     return check_launch("silu");
+}
+
+extern "C" int e2eft_activation(int32_t dtype, int32_t kind, int64_t n, const void* x, void* y, void* stream) {
+    E2EFT_REQUIRE(x && y && n > 0, "activation: bad args");
+    E2EFT_REQUIRE(kind >= 0 && kind <= 2, "activation: kind %d (0 quick_gelu, 1 gelu, 2 silu)", (int)kind);
+    E2EFT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "activation: buffers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = grid_for(n / 4 + 1);
+    E2EFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((act_kernel<T>), dim3(g), dim3(256), 0, s, (int)kind, (long)n, (const T*)x, (T*)y));
+    return check_launch("activation");
 }
 
 extern "C" int e2eft_depth_head(int32_t dt_in, int32_t dt_out, int64_t pixels, int32_t ldx, int32_t to_unit, const void* x,

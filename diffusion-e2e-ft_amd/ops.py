@@ -486,6 +486,18 @@ def silu(x):
     return out
 
 
+ACT_KINDS = {"quick_gelu": 0, "gelu": 1, "silu": 2}
+
+
+def activation(x, kind):
+    """y = act(x) elementwise; kind in ACT_KINDS"""
+    _check_cuda(x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(_lib.load().e2eft_activation(dtype_id(x.dtype), ACT_KINDS[kind], x.numel(), _ptr(x), _ptr(out), _stream()))
+    return out
+
+
 def depth_head(x, to_unit, dtype=None):
     """decoder output NHWC [B,H,W,>=3 (view)] -> [B,1,H,W] = clip(mean_c, -1, 1) (optionally mapped to [0,1])"""
     _check_cuda(x)

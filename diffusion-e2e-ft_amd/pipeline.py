@@ -219,11 +219,26 @@ def pyramid_noise_like(x, discount=0.9):
 class DepthNormalEstimationPipeline:
     """GeoWizard joint depth + normal single-step inference, batched (rows [depth x B ; normal x B]) as in
     GeoWizard/geowizard/training/train_depth_normal.py:687-704; per-image semantics of geowizard_pipeline.py:252-344.
-    The CLIP image encoder is SURVEY.md §8f 'next': pass `img_embed` [B,1,X] directly."""
+    `image_encoder` (clip.CLIPVisionModelWithProjection, geowizard_pipeline.py:76-86) is optional: without it pass `img_embed`
+    [B,1,X] to single_infer directly."""
 
-    def __init__(self, unet, vae, scheduler):
+    def __init__(self, unet, vae, scheduler, image_encoder=None, feature_extractor=None):
         self.unet, self.vae, self.scheduler = unet, vae, scheduler
+        self.image_encoder, self.feature_extractor = image_encoder, feature_extractor
         self._m = MarigoldPipeline(unet, vae, scheduler)
+
+    @torch.no_grad()
+    def encode_img_embed(self, rgb):
+        """geowizard_pipeline.py:232-248 (__encode_img_embed): CLIP image embedding [B,1,X] of rgb in [-1,1]; resize + normalisation
+        constants come from `feature_extractor` when one is given (image_mean / image_std / crop_size), else CLIP's defaults."""
+        from .clip import preprocess_for_clip, CLIP_IMAGE_MEAN, CLIP_IMAGE_STD
+        assert self.image_encoder is not None, "DepthNormalEstimationPipeline was built without an image_encoder: pass img_embed"
+        fe = self.feature_extractor
+        mean = tuple(fe.image_mean) if fe is not None else CLIP_IMAGE_MEAN
+        std = tuple(fe.image_std) if fe is not None else CLIP_IMAGE_STD
+        size = fe.crop_size["height"] if fe is not None else self.image_encoder.config["image_size"]
+        x = preprocess_for_clip(rgb.to(device=self.device, dtype=self.dtype), size, mean, std)
+        return self.image_encoder(x).image_embeds.unsqueeze(1).to(self.dtype)
 
     @property
     def dtype(self):
@@ -242,9 +257,11 @@ class DepthNormalEstimationPipeline:
         return emb.to(device=device, dtype=dtype)
 
     @torch.no_grad()
-    def single_infer(self, input_rgb, img_embed, domain="indoor"):
+    def single_infer(self, input_rgb, img_embed=None, domain="indoor"):
         device, dt = self.device, self.dtype
         rgb = input_rgb.to(device=device, dtype=dt)
+        if img_embed is None:
+            img_embed = self.encode_img_embed(rgb)
         B = rgb.shape[0]
         self.scheduler.set_timesteps(1, device=device)
         t = self.scheduler.timesteps[0]

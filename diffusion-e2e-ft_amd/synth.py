@@ -12,7 +12,7 @@ def init_synthetic_(module, seed=1234):
     dev = next(module.parameters()).device
     g = torch.Generator(device=dev).manual_seed(seed)
     for name, p in module.named_parameters():
-        is_norm = ".norm" in name or "group_norm" in name or "conv_norm_out" in name
+        is_norm = ".norm" in name or "group_norm" in name or "conv_norm_out" in name or "layer_norm" in name or "layernorm" in name or "layrnorm" in name
         if name.endswith(".weight") and p.dim() >= 2:
             fan_in = p[0].numel()
             w = torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32) * (1.0 / fan_in) ** 0.5

@@ -210,6 +210,10 @@ int e2eft_add(int32_t dtype, int64_t pixels, int32_t c, int32_t lda, int32_t ldb
 int e2eft_timestep_embedding(int32_t dtype, int32_t batch, int32_t dim, const int64_t* t, void* out, void* stream);
 /* SiLU elementwise on [n] contiguous (time embedding act before time_emb_proj). */
 int e2eft_silu(int32_t dtype, int64_t n, const void* x, void* y, void* stream);
+/* y = act(x) on [n] contiguous, 16-byte aligned.  kind 0: quick_gelu x * sigmoid(1.702 x) — the MLP activation of the CLIP ViT-L/14
+ * image encoder on GeoWizard's per-image path (/root/reference/GeoWizard/geowizard/models/geowizard_pipeline.py:232-248, module
+ * transformers CLIPVisionModelWithProjection); 1: gelu (erf); 2: silu. */
+int e2eft_activation(int32_t dtype, int32_t kind, int64_t n, const void* x, void* y, void* stream);
 /* Depth head: decoder output NHWC [pixels, ldx>=3] -> depth[pixels] = clip(mean_c(x), -1, 1) (* 0.5 + 0.5 when
  * to_unit != 0)  (marigold_pipeline.py:518,476-477; train.py:533-534).  Output fp32 or dtype (dt_out). */
 int e2eft_depth_head(int32_t dt_in, int32_t dt_out, int64_t pixels, int32_t ldx, int32_t to_unit, const void* x,

@@ -1,0 +1,83 @@
+"""GPU parity of the CLIP image encoder (diffusion_e2e_ft_amd.clip) and the activation kernel against the CPU oracle
+(oracle/clip_ref.py, itself pinned to transformers in tests/test_clip_cpu.py)."""
+import pytest
+import torch
+
+from oracle import clip_ref
+from test_clip_cpu import TINY, tiny_clip_sd
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["quick_gelu", "gelu", "silu"])
+@pytest.mark.parametrize("n", [8, 1000, 4099, 257 * 4096])
+def test_activation(dev, dtype, kind, n):
+    from diffusion_e2e_ft_amd import ops
+    x = (3 * torch.randn(n, generator=torch.Generator().manual_seed(n))).to(dtype)
+    xf = x.float()
+    ref = {"quick_gelu": xf * torch.sigmoid(1.702 * xf), "gelu": torch.nn.functional.gelu(xf), "silu": torch.nn.functional.silu(xf)}[kind]
+    y = ops.activation(x.to(dev), kind).cpu().float()
+    tol = 2e-6 if dtype == torch.float32 else (1e-3 if dtype == torch.float16 else 8e-3)
+    assert (y - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,image", [(torch.float32, 56), (torch.float16, 56), (torch.bfloat16, 56), (torch.float16, 224)])
+def test_clip_vision_tiny(dev, dtype, image):
+    from diffusion_e2e_ft_amd.clip import CLIPVisionModelWithProjection
+    cfg = dict(TINY, image_size=image)
+    sd = tiny_clip_sd(cfg=cfg)                     # image 224 -> 257 tokens: the ragged sequence length of ViT-L/14 on the fused attention kernel
+    m = CLIPVisionModelWithProjection(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(device=dev, dtype=dtype).eval()
+    x = torch.randn(2, 3, image, image, generator=torch.Generator().manual_seed(5))
+    emb_ref, last_ref = clip_ref.clip_vision_ref(sd, cfg, x)
+    out = m(x.to(dev, dtype))
+    tol = 1e-3 if dtype == torch.float32 else (2e-2 if dtype == torch.float16 else 8e-2)
+    assert tuple(out.image_embeds.shape) == (2, cfg["projection_dim"])
+    e1, e2 = rel_err(out.image_embeds.float().cpu(), emb_ref), rel_err(out.last_hidden_state.float().cpu(), last_ref)
+    assert e1 <= tol and e2 <= tol, (e1, e2)
+
+
+def test_clip_against_transformers_on_gpu_box(dev):
+    tr = pytest.importorskip("transformers")
+    from diffusion_e2e_ft_amd.clip import CLIPVisionModelWithProjection
+    sd = tiny_clip_sd()
+    ref = tr.CLIPVisionModelWithProjection(tr.CLIPVisionConfig(**TINY)).eval()
+    ref.load_state_dict(sd, strict=False)
+    m = CLIPVisionModelWithProjection(**TINY)
+    m.load_state_dict(ref.state_dict())            # accepts (and ignores) a position_ids buffer if this transformers release has one
+    m = m.to(dev).eval()
+    x = torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        want = ref(pixel_values=x).image_embeds
+    assert rel_err(m(x.to(dev)).image_embeds.cpu(), want) <= 1e-3
+
+
+def test_geowizard_pipeline_with_image_encoder(dev):
+    """geowizard_pipeline.py:232-248,283-284: the embedding is recomputed from the input image on every call"""
+    import golden_cases as gc
+    from oracle import config
+    from diffusion_e2e_ft_amd.clip import CLIPVisionModelWithProjection, preprocess_for_clip
+    from diffusion_e2e_ft_amd.pipeline import DepthNormalEstimationPipeline
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    rgb, ctx = gc.geo_pipe_inputs()
+    xdim = ctx.shape[-1]
+    unet = UNet2DConditionModel(**config.TINY_GEOWIZARD_UNET)
+    unet.load_state_dict(gc.tiny_geo_sd())
+    vae = AutoencoderKL(**config.TINY_VAE)
+    vae.load_state_dict(gc.tiny_vae_sd())
+    cfg = dict(TINY, projection_dim=xdim)
+    enc = CLIPVisionModelWithProjection(**cfg)
+    enc.load_state_dict(tiny_clip_sd(cfg=cfg))
+    pipe = DepthNormalEstimationPipeline(unet.to(dev).eval(), vae.to(dev).eval(), DDIMScheduler(), image_encoder=enc.to(dev).eval())
+    emb = pipe.encode_img_embed(rgb.to(dev))
+    assert tuple(emb.shape) == (rgb.shape[0], 1, xdim)
+    emb_ref, _ = clip_ref.clip_vision_ref(tiny_clip_sd(cfg=cfg), cfg, preprocess_for_clip(rgb, cfg["image_size"]))
+    assert rel_err(emb[:, 0].cpu(), emb_ref) <= 1e-3
+    d1, n1 = pipe.single_infer(rgb)                 # embedding computed inside
+    d2, n2 = pipe.single_infer(rgb, img_embed=emb)  # embedding supplied
+    assert torch.equal(d1, d2) and torch.equal(n1, n2)
