@@ -46,6 +46,8 @@ def parse():
                     "configs[2] batch in one pass, 122 GB of the 288 GB HBM; 16 in fp32)")
     ap.add_argument("--accum", type=int, default=None, help="--train: gradient-accumulation micro-steps per optimizer step (default 32 / micro-batch)")
     ap.add_argument("--modality", default="depth", choices=["depth", "normals"])
+    ap.add_argument("--graph", action="store_true", help="inference: replay one captured hipGraph per batch instead of launching ~1.4k kernels from the host "
+                    "(measured: no difference at batch 8 - the launches already run back to back; it matters for latency at batch 1)")
     ap.add_argument("--no-image-encoder", action="store_true", help="--geowizard: feed a CLIP image embedding as input instead of running ViT-L/14")
     ap.add_argument("--geowizard", action="store_true", help="time GeoWizard joint depth+normals 1-step inference (BASELINE.json configs[4]: "
                     "dual-latent UNet with cross-domain attention, 2 images per GPU by default) instead of Marigold depth")
@@ -313,13 +315,16 @@ def main():
     def step():
         return pipe.single_infer(rgb, 1, noise="zeros", normals=False)
 
-    for _ in range(args.warmup):
+    if args.graph:
+        pipe.enable_hip_graphs()      # the timed steps replay one captured hipGraph per batch (captured during the first warm-up step)
+    for _ in range(max(args.warmup, 1) if args.graph else args.warmup):
         out = step()
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
     timer = ops.KernelTimer()
-    ops.TIMER = timer
+    if not args.graph:
+        ops.TIMER = timer             # HIP events around every launch, on the launch stream, inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -330,6 +335,15 @@ def main():
     ops.TIMER = None
     assert torch.isfinite(out.float()).all(), "non-finite depth output"
     elapsed = D.max_over_ranks(elapsed, device=dev)
+    if args.graph:
+        # a hipGraph replay cannot be bracketed per kernel: the roofline's kernel durations then come from the same K steps run
+        # eagerly right after the timed region
+        pipe.enable_hip_graphs(False)
+        ops.TIMER = timer
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        ops.TIMER = None
     ksum = timer.summary()
     if args.detail and rank == 0:
         rows = sorted(timer.by_label().items(), key=lambda kv: -kv[1]["ms"])
@@ -368,7 +382,8 @@ def main():
             "dtype": "f16" if args.dtype == "fp16" else args.dtype, "data": "synthetic",
             "config": {"workload": "marigold-e2e-ft-depth 1-step inference, batch=%d/GPU at %dx%d %s, random-init SD-v2 UNet (866M) + SD VAE (84M)%s"
                                    % (B, R, R, args.dtype, " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
-                       "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world},
+                       "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world,
+                       "launch_mode": "hipGraph replay (one captured graph per batch shape)" if args.graph else "host launches"},
             "roofline": {"bound": "mfma", "kernel": "igemm2_kernel (implicit-GEMM conv/linear, all launches of the timed region)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": traffic_note, "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),

@@ -28,6 +28,8 @@ class MarigoldPipeline:
     rgb_latent_scale_factor = 0.18215    # marigold_pipeline.py:134
     depth_latent_scale_factor = 0.18215  # marigold_pipeline.py:135
 
+    _graphs = None
+
     def __init__(self, unet, vae, scheduler, text_encoder=None, tokenizer=None):
         self.unet, self.vae, self.scheduler = unet, vae, scheduler
         self.text_encoder, self.tokenizer = text_encoder, tokenizer
@@ -92,6 +94,15 @@ class MarigoldPipeline:
         rgb_in = rgb_in.to(device=device, dtype=dt)
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         timesteps = self.scheduler.timesteps
+        if noise == "zeros" and num_inference_steps == 1:
+            # E2E-FT path (x_t = 0, one step): no host synchronisation anywhere, optionally replayed from a captured hipGraph
+            if self.empty_text_embed is None:
+                self.encode_empty_text()
+            ctx = self.empty_text_embed.to(device=device, dtype=dt)
+            _, sb = self.scheduler.x0_coefficients(self.scheduler.timesteps_host[0])
+            if self._graphs is not None:
+                return self._replay(rgb_in, timesteps[:1], sb, ctx, normals)
+            return self._e2e_ft_zero_latent(rgb_in, timesteps[:1], sb, ctx, normals)
         rgb_latent = self.encode_rgb(rgb_in)  # [B,4,h,w] logical NCHW
         B, C, h, w = rgb_latent.shape
         # UNet input buffer [B,h,w,8] NHWC: channels 0:4 rgb latent, 4:8 current latent ("this order is important" :447-449)
@@ -111,25 +122,60 @@ class MarigoldPipeline:
             self.encode_empty_text()
         ctx = self.empty_text_embed.to(device=device, dtype=dt).repeat(B, 1, 1)
         x0 = None
-        for i, t in enumerate(timesteps):
+        for i, (t, t_host) in enumerate(zip(timesteps, self.scheduler.timesteps_host)):
             v = self.unet(to_nchw_view(xin), t, encoder_hidden_states=ctx).sample
-            if latent is None and len(timesteps) == 1:
-                # E2E-FT fast path: x_t = 0  =>  x0 = -sqrt(1 - abar_t) * v   (marigold_pipeline.py:457-465, train.py:509-512)
-                _, sb = self.scheduler.x0_coefficients(int(t))
-                x0 = _scaled(v, -sb)
-            else:
-                cur = latent if latent is not None else torch.zeros((B, C, h, w), dtype=dt, device=device)
-                step = self.scheduler.step(v, t, cur)
-                latent = step.prev_sample
-                x0 = step.pred_original_sample
-                if i == num_inference_steps - 1:
-                    latent = x0
-                ops.copy_scale(latent.permute(0, 2, 3, 1).contiguous(), xin[..., C:])
+            cur = latent if latent is not None else torch.zeros((B, C, h, w), dtype=dt, device=device)
+            step = self.scheduler.step(v, t_host, cur)     # host copy of the timestep: no device synchronisation per step
+            latent = step.prev_sample
+            x0 = step.pred_original_sample
+            if i == num_inference_steps - 1:
+                latent = x0
+            ops.copy_scale(latent.permute(0, 2, 3, 1).contiguous(), xin[..., C:])
         if normals:
             dec = self.decode_normal(x0)
             return ops.normal_head(dec.permute(0, 2, 3, 1), clamp=False)
         stacked = self._decode(x0)
         return ops.depth_head(stacked.permute(0, 2, 3, 1), to_unit=True)  # clip(mean_c, -1, 1) -> (x+1)/2  (:518,476-477)
+
+    def _e2e_ft_zero_latent(self, rgb_in, t_dev, sb, ctx1, normals):
+        """encode -> UNet on [rgb latent | zeros] at t -> x0 = -sqrt(1 - abar_t) * v (marigold_pipeline.py:457-465, train.py:509-512)
+        -> decode -> head.  Only device work on the current stream: safe inside a hipGraph capture."""
+        rgb_latent = self.encode_rgb(rgb_in)
+        B, C, h, w = rgb_latent.shape
+        xin = torch.zeros((B, h, w, 2 * C), dtype=rgb_in.dtype, device=rgb_in.device)   # channels 0:4 rgb latent, 4:8 the zero latent (:447-449)
+        ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[..., :C])
+        v = self.unet(to_nchw_view(xin), t_dev, encoder_hidden_states=ctx1.repeat(B, 1, 1)).sample
+        x0 = _scaled(v, -sb)
+        if normals:
+            return ops.normal_head(self.decode_normal(x0).permute(0, 2, 3, 1), clamp=False)
+        return ops.depth_head(self._decode(x0).permute(0, 2, 3, 1), to_unit=True)   # clip(mean_c, -1, 1) -> (x+1)/2  (:518,476-477)
+
+    def enable_hip_graphs(self, enabled=True):
+        """Replay the E2E-FT path from a hipGraph captured per (input shape, dtype, modality): ~1.4k launches per batch become one
+        graph launch, which removes the host-side gaps on the small UNet levels.  Weights are baked in by address: call this again
+        after changing them (load_state_dict, .to(), an optimizer step)."""
+        self._graphs = {} if enabled else None
+        return self
+
+    def _replay(self, rgb_in, t_dev, sb, ctx1, normals):
+        from . import autograd as F
+        w0 = self.unet.conv_in.weight
+        key = (tuple(rgb_in.shape), rgb_in.dtype, bool(normals), tuple(ctx1.shape), float(sb), F.PARAM_EPOCH, w0.data_ptr(), w0._version)
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._e2e_ft_zero_latent(rgb_in, t_dev, sb, ctx1, normals)       # eager pass: fills the packed-weight caches
+            torch.cuda.synchronize()
+            s_in, s_ctx, s_t = rgb_in.clone(), ctx1.clone(), t_dev.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                s_out = self._e2e_ft_zero_latent(s_in, s_t, sb, s_ctx, normals)
+            ent = self._graphs[key] = (g, s_in, s_ctx, s_t, s_out)
+        g, s_in, s_ctx, s_t, s_out = ent
+        s_in.copy_(rgb_in)
+        s_ctx.copy_(ctx1)
+        s_t.copy_(t_dev)
+        g.replay()
+        return s_out.clone()
 
     # ---- marigold_pipeline.py:158-353 ----
     @torch.no_grad()

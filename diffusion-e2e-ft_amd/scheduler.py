@@ -40,7 +40,11 @@ class DDIMScheduler:
             ts = np.linspace(0, T - 1, n).round()[::-1].copy()
         else:
             raise ValueError(sp)
-        self.timesteps = torch.from_numpy(ts.astype(np.int64)).to(device)
+        self.timesteps_host = [int(v) for v in ts]           # host copy: reading a timestep must not synchronise with the device
+        key = (tuple(self.timesteps_host), str(device))
+        if getattr(self, "_ts_key", None) != key:            # same schedule as last call: keep the device tensor (no H2D per image)
+            self.timesteps = torch.from_numpy(ts.astype(np.int64)).to(device)
+            self._ts_key = key
 
     def x0_coefficients(self, t):
         """(sqrt(abar_t), sqrt(1 - abar_t)) as python floats computed in fp32 like the reference (train.py:509-512)."""
