@@ -64,6 +64,7 @@ SIGNATURES = {
     "e2eft_layernorm_fwd": (_I, [_I, _L, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
     "e2eft_geglu_fwd": (_I, [_I, _L, _I, _I, _I, _P, _P, _P]),
     "e2eft_softmax_rows": (_I, [_I, _L, _I, _L, _F, _P, _P]),
+    "e2eft_softmax_rows_causal": (_I, [_I, _L, _I, _L, _F, _I, _P, _P]),
     "e2eft_attn_fwd": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
     "e2eft_attn_fwd_lse": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P]),
     "e2eft_attn_bwd_workspace_bytes": (_Z, [C.POINTER(AttnDesc)]),

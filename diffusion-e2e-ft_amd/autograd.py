@@ -426,14 +426,16 @@ def _scores(q, k, heads, dt):
     return s, nkp
 
 
-def _attn_core_unfused(q, k, v, heads, scale):
-    """softmax(q k^T * scale) v through batched MFMA GEMMs (any head dim, exact fp32 capable). q [B,N,C], k/v [B,Nk,C] views."""
+def _attn_core_unfused(q, k, v, heads, scale, causal=False):
+    """softmax(q k^T * scale) v through batched MFMA GEMMs (any head dim, exact fp32 capable). q [B,N,C], k/v [B,Nk,C] views.
+    causal: query i attends to keys 0..i (self-attention only; CLIP text tower)."""
     B, N, C = q.shape
     Nk = k.shape[1]
     d = C // heads
     dt = q.dtype
     s, nkp = _scores(q, k, heads, dt)
-    ops.softmax_rows_(s.view(-1, nkp), Nk, scale)
+    assert not causal or N == Nk
+    ops.softmax_rows_(s.view(-1, nkp), Nk, scale, causal_nq=N if causal else 0)
     vt = ops.transpose(v, rows_pad=nkp)                                         # [B, C, nkp]
     o = torch.empty((B, N, C), dtype=dt, device=q.device)
     ops.bgemm_raw(dt, N, d, nkp, s, nkp, (heads * N * nkp, N * nkp), vt, nkp, (C * nkp, d * nkp), o, C, (N * C, d), B, heads)

@@ -146,3 +146,98 @@ def preprocess_for_clip(rgb, size=224, mean=CLIP_IMAGE_MEAN, std=CLIP_IMAGE_STD)
     m = torch.tensor(mean, device=rgb.device, dtype=torch.float32)[:, None, None]
     s = torch.tensor(std, device=rgb.device, dtype=torch.float32)[:, None, None]
     return ((x.float() - m) / s).to(rgb.dtype)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CLIP text tower — `text_encoder` slot of MarigoldPipeline (marigold_pipeline.py:147-153); only ever fed the empty prompt
+# (marigold_pipeline.py:356-369: 2 tokens; training/train.py:455-458: padded to 77), once per process.
+SD2_TEXT = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=23, num_attention_heads=16, max_position_embeddings=77,
+                vocab_size=49408, hidden_act="gelu", layer_norm_eps=1e-5)   # stabilityai/stable-diffusion-2 text_encoder (OpenCLIP ViT-H text, penultimate layer)
+BOS_ID, EOS_ID = 49406, 49407
+
+
+def empty_prompt_ids(padding="do_not_pad", max_length=77, pad_token_id=0):
+    """token ids of tokenizer("") without needing the vocabulary files: <|startoftext|> <|endoftext|>, then (padding="max_length")
+    the pad token — "!" = id 0 in the SD-2 tokenizer (special_tokens_map.json), <|endoftext|> = 49407 in SD-1.x / openai CLIP."""
+    ids = [BOS_ID, EOS_ID]
+    if padding == "max_length":
+        ids = ids + [pad_token_id] * (max_length - 2)
+    elif padding != "do_not_pad":
+        raise ValueError(padding)
+    return torch.tensor([ids], dtype=torch.int64)
+
+
+class _TextOut:
+    def __init__(self, last_hidden_state):
+        self.last_hidden_state = last_hidden_state
+
+    def __getitem__(self, i):
+        return (self.last_hidden_state,)[i]
+
+
+class CLIPCausalAttention(CLIPAttention):
+    def forward(self, x, residual):
+        C = x.shape[-1]
+        bias = F.cached(self, "bqkv_%s" % x.dtype, (self.q_proj.bias, self.k_proj.bias, self.v_proj.bias),
+                        lambda: torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]).detach().to(x.dtype))
+        qkv = F.linear(x, (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight), bias, owner=self, name="wqkv")
+        # <= 77 tokens, once per process: GEMM + masked row softmax + GEMM (the fused kernel has no mask input)
+        a = F._attn_core_unfused(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.heads, self.scale, causal=True)
+        return self.out_proj(a, residual=residual)
+
+
+class _TextEmbeddings(nn.Module):
+    def __init__(self, vocab, positions, dim):
+        super().__init__()
+        self.token_embedding = nn.Embedding(vocab, dim)
+        self.position_embedding = nn.Embedding(positions, dim)
+
+    def forward(self, input_ids):
+        L = input_ids.shape[1]
+        return self.token_embedding.weight[input_ids] + self.position_embedding.weight[:L]   # a 77-row gather: torch (plumbing)
+
+
+class CLIPTextTransformer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        dim = c["hidden_size"]
+        self.embeddings = _TextEmbeddings(c["vocab_size"], c["max_position_embeddings"], dim)
+        self.encoder = _Encoder(c["num_hidden_layers"], dim, c["intermediate_size"], c["num_attention_heads"], c["hidden_act"], c["layer_norm_eps"])
+        for layer in self.encoder.layers:
+            att = CLIPCausalAttention(dim, c["num_attention_heads"])
+            layer.self_attn = att
+        self.final_layer_norm = LayerNorm(dim, eps=c["layer_norm_eps"])
+
+    def forward(self, input_ids):
+        x = self.embeddings(input_ids).contiguous()
+        for layer in self.encoder.layers:
+            x = layer(x)
+        return self.final_layer_norm(x)
+
+
+class CLIPTextModel(nn.Module):
+    """`text_encoder(input_ids)[0]` -> last_hidden_state [B, L, C] (after final_layer_norm), transformers state-dict layout."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        cfg = dict(SD2_TEXT)
+        cfg.update(kwargs)
+        self.config = cfg
+        self.text_model = CLIPTextTransformer(cfg)
+
+    @property
+    def dtype(self):
+        return self.text_model.final_layer_norm.weight.dtype
+
+    @property
+    def device(self):
+        return self.text_model.final_layer_norm.weight.device
+
+    def load_state_dict(self, sd, strict=True, **kw):
+        sd = {k: v for k, v in sd.items() if not k.endswith("position_ids")}
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    @torch.no_grad()
+    def forward(self, input_ids, return_dict=True, **unused):
+        out = self.text_model(input_ids.to(self.device))
+        return _TextOut(out) if return_dict else (out,)

@@ -538,11 +538,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(long rows, int c, int ld
 // ---------------------------------------------------------------------------------------------------
 // Row softmax in place (block per row; the row is L2/L1 resident between the three sweeps).
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_rows_kernel(int n, long lds, float scale, T* __restrict__ s) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(int ntot, long lds, float scale, T* __restrict__ s, int causal_nq) {
     constexpr int EPC = 16 / (int)sizeof(T);
     __shared__ float red[8];
     T* row = s + (long)blockIdx.x * lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // causal_nq > 0: row r belongs to query r % causal_nq and sees keys 0 .. that index (CLIP text tower); the rest of the row is zeroed
+    const int n = causal_nq > 0 ? min(ntot, (int)(blockIdx.x % (unsigned)causal_nq) + 1) : ntot;
     const int nfull = n / EPC;
     const float sc = scale * 1.4426950408889634f;  // work in base 2
     float mx = -INFINITY;
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(int n, long lds, floa
         for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(exp2f(fmaf(to_f(v.e[e]), sc, -mb)) * inv);
         st16(row + ch * EPC, o);
     }
-    const int npad = (n + EPC - 1) / EPC * EPC;
+    const int npad = (ntot + EPC - 1) / EPC * EPC;
     for (int j = nfull * EPC + tid; j < npad; j += 256)
         row[j] = j < n ? from_f<T>(exp2f(fmaf(to_f(row[j]), sc, -mb)) * inv) : from_f<T>(0.f);
 }
@@ -818,8 +820,20 @@ extern "C" int e2eft_softmax_rows(int32_t dtype, int64_t rows, int32_t n, int64_
     E2EFT_REQUIRE(rows > 0 && rows < 2147483647L && n > 0 && lds >= (n + epc - 1) / epc * epc && lds % epc == 0, "softmax: shape n=%d lds=%ld", n, (long)lds);
     E2EFT_REQUIRE(scale > 0.f, "softmax: scale must be positive");
     hipStream_t s = (hipStream_t)stream;
-    E2EFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3((unsigned)rows), dim3(256), 0, s, n, (long)lds, scale, (T*)sbuf));
+    E2EFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3((unsigned)rows), dim3(256), 0, s, n, (long)lds, scale, (T*)sbuf, 0));
     return check_launch("softmax_rows");
+}
+
+extern "C" int e2eft_softmax_rows_causal(int32_t dtype, int64_t rows, int32_t n, int64_t lds, float scale, int32_t nq, void* sbuf, void* stream) {
+    E2EFT_REQUIRE(sbuf, "softmax_causal: null pointer");
+    E2EFT_REQUIRE(dtype >= 0 && dtype <= 2, "softmax_causal: bad dtype");
+    const int epc = 16 / (int)dtype_size(dtype);
+    E2EFT_REQUIRE(rows > 0 && rows < 2147483647L && n > 0 && lds >= (n + epc - 1) / epc * epc && lds % epc == 0, "softmax_causal: shape n=%d lds=%ld", n, (long)lds);
+    E2EFT_REQUIRE(nq > 0 && nq <= n && rows % nq == 0, "softmax_causal: nq=%d must divide rows and be <= n (self-attention)", nq);
+    E2EFT_REQUIRE(scale > 0.f, "softmax_causal: scale must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    E2EFT_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((softmax_rows_kernel<T>), dim3((unsigned)rows), dim3(256), 0, s, n, (long)lds, scale, (T*)sbuf, (int)nq));
+    return check_launch("softmax_rows_causal");
 }
 
 extern "C" int e2eft_geglu_fwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldh, int32_t ldy, const void* h, void* y, void* stream) {

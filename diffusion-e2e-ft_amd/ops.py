@@ -361,11 +361,15 @@ def geglu(h, out=None):
     return out
 
 
-def softmax_rows_(s, n, scale):
-    """in-place softmax(scale * s[r, :n]) over a 2-D [rows, lds] contiguous buffer; pad columns [n, roundup) zeroed."""
+def softmax_rows_(s, n, scale, causal_nq=0):
+    """in-place softmax(scale * s[r, :n]) over a 2-D [rows, lds] contiguous buffer; pad columns [n, roundup) zeroed.
+    causal_nq > 0: row r is query r % causal_nq and sees keys 0 .. r % causal_nq only."""
     _check_cuda(s)
     assert s.dim() == 2 and s.is_contiguous()
-    check(_lib.load().e2eft_softmax_rows(dtype_id(s.dtype), s.shape[0], n, s.shape[1], scale, _ptr(s), _stream()))
+    if causal_nq:
+        check(_lib.load().e2eft_softmax_rows_causal(dtype_id(s.dtype), s.shape[0], n, s.shape[1], scale, causal_nq, _ptr(s), _stream()))
+    else:
+        check(_lib.load().e2eft_softmax_rows(dtype_id(s.dtype), s.shape[0], n, s.shape[1], scale, _ptr(s), _stream()))
     return s
 
 

@@ -58,10 +58,14 @@ class MarigoldPipeline:
 
     # ---- marigold_pipeline.py:356-369 ----
     def encode_empty_text(self):
-        if self.text_encoder is None or self.tokenizer is None:
+        if self.text_encoder is None:
             raise RuntimeError("no text encoder: set pipe.empty_text_embed ([1, L, cross_attention_dim]) explicitly")
-        ids = self.tokenizer("", padding="do_not_pad", max_length=self.tokenizer.model_max_length, truncation=True,
-                             return_tensors="pt").input_ids.to(self.device)
+        if self.tokenizer is not None:
+            ids = self.tokenizer("", padding="do_not_pad", max_length=self.tokenizer.model_max_length, truncation=True,
+                                 return_tensors="pt").input_ids.to(self.device)
+        else:   # the empty prompt is <|startoftext|><|endoftext|> in every CLIP vocabulary: no tokenizer files needed
+            from .clip import empty_prompt_ids
+            ids = empty_prompt_ids("do_not_pad").to(self.device)
         self.empty_text_embed = self.text_encoder(ids)[0].to(self.dtype)
 
     # ---- marigold_pipeline.py:481-498 ----

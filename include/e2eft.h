@@ -154,6 +154,10 @@ int e2eft_geglu_fwd(int32_t dtype, int64_t rows, int32_t c, int32_t ldh, int32_t
 /* Row softmax in place: s[r, :n] = softmax(scale * s[r, :n]) for r < rows (row stride lds).
  * Used by the unfused attention path (VAE mid-block d=512 attention and the strict-fp32 path). */
 int e2eft_softmax_rows(int32_t dtype, int64_t rows, int32_t n, int64_t lds, float scale, void* s, void* stream);
+/* The same with a causal mask: row r is query r % nq and attends to keys 0 .. r % nq, the rest of the row is written as zeros
+ * (the CLIP text tower behind encode_empty_text, /root/reference/Marigold/marigold/marigold_pipeline.py:356-369 and
+ * training/train.py:455-458: transformers CLIPTextModel builds a causal attention mask). */
+int e2eft_softmax_rows_causal(int32_t dtype, int64_t rows, int32_t n, int64_t lds, float scale, int32_t nq, void* s, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Fused (flash-style) attention forward, head dim 64, fp16/bf16, MFMA + online softmax.

@@ -35,3 +35,23 @@ def clip_vision_ref(sd, cfg, pixel_values):
         x = x + lin(h, k + "mlp.fc2")
     pooled = ln(x[:, 0], p + "post_layernorm")
     return F.linear(pooled, sd["visual_projection.weight"]), x
+
+
+def clip_text_ref(sd, cfg, input_ids):
+    """transformers CLIPTextModel forward (causal self-attention, pre-LN blocks, final_layer_norm) -> last_hidden_state [B, L, C]"""
+    p = "text_model."
+    C, heads, eps = cfg["hidden_size"], cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    B, L = input_ids.shape
+    x = sd[p + "embeddings.token_embedding.weight"][input_ids] + sd[p + "embeddings.position_embedding.weight"][:L][None]
+    ln = lambda t, k: F.layer_norm(t, (C,), sd[k + ".weight"], sd[k + ".bias"], eps)
+    lin = lambda t, k: F.linear(t, sd[k + ".weight"], sd.get(k + ".bias"))
+    for i in range(cfg["num_hidden_layers"]):
+        k = p + "encoder.layers.%d." % i
+        h = ln(x, k + "layer_norm1")
+        split = lambda t: t.view(B, L, heads, C // heads).transpose(1, 2)
+        a = F.scaled_dot_product_attention(split(lin(h, k + "self_attn.q_proj")), split(lin(h, k + "self_attn.k_proj")), split(lin(h, k + "self_attn.v_proj")), is_causal=True)
+        x = x + lin(a.transpose(1, 2).reshape(B, L, C), k + "self_attn.out_proj")
+        h = lin(ln(x, k + "layer_norm2"), k + "mlp.fc1")
+        h = h * torch.sigmoid(1.702 * h) if cfg["hidden_act"] == "quick_gelu" else F.gelu(h)
+        x = x + lin(h, k + "mlp.fc2")
+    return ln(x, p + "final_layer_norm")
