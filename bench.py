@@ -390,6 +390,12 @@ def main():
                          "launches_per_step": ig["launches"] / args.steps, "kernel_ms_per_step": ig["ms"] / args.steps,
                          "algorithmic_gflop_per_step": ig["flops"] / args.steps / 1e9, "other_kernels": extra},
         }
+        try:   # stage split ("also report UNet-only"), measured after the timed region
+            st = pipe.stage_times_ms(rgb, repeats=3)
+            line["stages"] = {"ms_per_step": st, "unet_only_images_per_s": B * world / (st["unet"] * 1e-3),
+                              "note": "HIP events around VAE encode / UNet (+ v->x0) / VAE decode (+ head) of 3 extra steps on rank 0"}
+        except Exception as e:
+            line["stages"] = {"error": repr(e)}
         if R in WORK_GF and not args.tiny:
             tot = sum(WORK_GF[R].values())
             line["config"]["algorithmic_tflop_per_image"] = tot / 1e3

@@ -921,3 +921,34 @@ def ensemble_normals(x):
     err = torch.empty(n, dtype=torch.float64, device=x.device)
     check(_lib.load().e2eft_ensemble_normals(n, npix3 // 3, _ptr(x), _ptr(unit), _ptr(err), _ptr(ws), nbytes, _stream()))
     return unit, err
+
+
+# ---------------------------------------------------------------------------------------------------------
+# training-sample preparation (csrc/dataprep.hip)
+def masked_quantiles(depth, near, far, q_lo=0.02, q_hi=0.98):
+    """depth [B, ...] fp32 -> [B, 4] = (q_lo quantile, q_hi quantile, number of valid pixels, ok) over near < depth < far"""
+    _check_cuda(depth)
+    assert depth.dtype == torch.float32 and depth.is_contiguous() and depth.dim() >= 2
+    B = depth.shape[0]
+    lib = _lib.load()
+    nbytes = lib.e2eft_masked_quantiles_workspace_bytes(B)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=depth.device)
+    out = torch.empty((B, 4), dtype=torch.float32, device=depth.device)
+    check(lib.e2eft_masked_quantiles(B, depth.numel() // B, _ptr(depth), near, far, q_lo, q_hi, _ptr(out), _ptr(ws), nbytes, _stream()))
+    return out
+
+
+def prepare_sample(rgb01, depth, normal01, near, far, quantiles):
+    """rgb01 / normal01 [B,3,H,W] in [0,1], depth [B,1,H,W] metres, quantiles [B,4] -> (rgb, depth3, metric, normals, val_mask bool)"""
+    _check_cuda(rgb01, depth, normal01, quantiles)
+    B, _, H, W = rgb01.shape
+    for t in (rgb01, depth, normal01, quantiles):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert tuple(depth.shape) == (B, 1, H, W) and tuple(normal01.shape) == (B, 3, H, W) and tuple(quantiles.shape) == (B, 4)
+    dev = rgb01.device
+    rgb, depth3, normals = torch.empty_like(rgb01), torch.empty_like(rgb01), torch.empty_like(rgb01)
+    metric = torch.empty_like(depth)
+    mask = torch.empty((B, 1, H, W), dtype=torch.uint8, device=dev)
+    check(_lib.load().e2eft_prepare_sample(B, H * W, _ptr(rgb01), _ptr(depth), _ptr(normal01), near, far, _ptr(quantiles), _ptr(rgb), _ptr(depth3),
+                                           _ptr(metric), _ptr(normals), _ptr(mask), _stream()))
+    return rgb, depth3, metric, normals, mask.bool()

@@ -141,18 +141,48 @@ class MarigoldPipeline:
         stacked = self._decode(x0)
         return ops.depth_head(stacked.permute(0, 2, 3, 1), to_unit=True)  # clip(mean_c, -1, 1) -> (x+1)/2  (:518,476-477)
 
-    def _e2e_ft_zero_latent(self, rgb_in, t_dev, sb, ctx1, normals):
+    def _e2e_ft_zero_latent(self, rgb_in, t_dev, sb, ctx1, normals, marks=None):
         """encode -> UNet on [rgb latent | zeros] at t -> x0 = -sqrt(1 - abar_t) * v (marigold_pipeline.py:457-465, train.py:509-512)
-        -> decode -> head.  Only device work on the current stream: safe inside a hipGraph capture."""
+        -> decode -> head.  Only device work on the current stream: safe inside a hipGraph capture.
+        marks: optional list that receives four recorded events (start, after encode, after UNet, end) for stage timing."""
+        def mark():
+            if marks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append(e)
+        mark()
         rgb_latent = self.encode_rgb(rgb_in)
         B, C, h, w = rgb_latent.shape
         xin = torch.zeros((B, h, w, 2 * C), dtype=rgb_in.dtype, device=rgb_in.device)   # channels 0:4 rgb latent, 4:8 the zero latent (:447-449)
         ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[..., :C])
+        mark()
         v = self.unet(to_nchw_view(xin), t_dev, encoder_hidden_states=ctx1.repeat(B, 1, 1)).sample
         x0 = _scaled(v, -sb)
+        mark()
         if normals:
-            return ops.normal_head(self.decode_normal(x0).permute(0, 2, 3, 1), clamp=False)
-        return ops.depth_head(self._decode(x0).permute(0, 2, 3, 1), to_unit=True)   # clip(mean_c, -1, 1) -> (x+1)/2  (:518,476-477)
+            out = ops.normal_head(self.decode_normal(x0).permute(0, 2, 3, 1), clamp=False)
+        else:
+            out = ops.depth_head(self._decode(x0).permute(0, 2, 3, 1), to_unit=True)   # clip(mean_c, -1, 1) -> (x+1)/2  (:518,476-477)
+        mark()
+        return out
+
+    @torch.no_grad()
+    def stage_times_ms(self, rgb_in, normals=False, repeats=3):
+        """{"vae_encode", "unet", "vae_decode"}: mean milliseconds per batch of the three stages of the E2E-FT path (HIP events on the
+        launch stream; SURVEY.md §8(d) asks for the UNet-only rate next to the full path)."""
+        device, dt = self.device, self.dtype
+        rgb_in = rgb_in.to(device=device, dtype=dt)
+        self.scheduler.set_timesteps(1, device=device)
+        _, sb = self.scheduler.x0_coefficients(self.scheduler.timesteps_host[0])
+        ctx = self.empty_text_embed.to(device=device, dtype=dt)
+        tot = [0.0, 0.0, 0.0]
+        for _ in range(repeats):
+            marks = []
+            self._e2e_ft_zero_latent(rgb_in, self.scheduler.timesteps[:1], sb, ctx, normals, marks=marks)
+            torch.cuda.synchronize()
+            for i in range(3):
+                tot[i] += marks[i].elapsed_time(marks[i + 1])
+        return dict(zip(("vae_encode", "unet", "vae_decode"), (v / repeats for v in tot)))
 
     def enable_hip_graphs(self, enabled=True):
         """Replay the E2E-FT path from a hipGraph captured per (input shape, dtype, modality): ~1.4k launches per batch become one

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define E2EFT_VERSION 111 /* 0.1.1: backward entry points; 111: test-time ensembling */
+#define E2EFT_VERSION 111 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
 
 enum {
     E2EFT_OK = 0,
@@ -307,6 +307,20 @@ int e2eft_ssi_loss_bwd(int32_t batch, int32_t hw, const float* pred, const float
                        void* workspace, size_t ws_bytes, void* stream);
 int e2eft_angular_loss_bwd(int32_t batch, int32_t hw, const float* pred, const float* target, const uint8_t* mask,
                            const void* fwd_workspace, const float* grad_out, float* dpred, void* stream);
+/* Training-sample preparation on the GPU: the arithmetic of Hypersim.__getitem__ / VirtualKITTI2.__getitem__ after decode and
+ * augmentation (/root/reference/training/dataloaders/load.py:236-283, :342-375), batched.
+ *   e2eft_masked_quantiles  per image: valid = near < depth < far; out[b] = (q_lo quantile, q_hi quantile, #valid, ok) with
+ *                           torch.quantile's linear interpolation (rank = q * (n - 1) in float32) over EXACT order statistics
+ *                           (three-level radix select on integer histograms: deterministic); ok = (#valid > 0 && lo != hi).
+ *   e2eft_prepare_sample    rgb01 / normal01 [B][3][hw] in [0,1], depth [B][hw] in metres -> rgb in [-1,1]; metric = clamp(depth, lo, hi)
+ *                           with invalid pixels = hi; depth3 = three copies of clamp(2 (metric - lo) / (hi - lo) - 1, -1, 1);
+ *                           normals = normalize(2 n - 1) with invalid pixels zeroed; val_mask (uint8); everything zero / empty when !ok. */
+size_t e2eft_masked_quantiles_workspace_bytes(int32_t batch);
+int e2eft_masked_quantiles(int32_t batch, int64_t n, const float* depth, float near_plane, float far_plane, float q_lo, float q_hi, float* out,
+                           void* workspace, size_t ws_bytes, void* stream);
+int e2eft_prepare_sample(int32_t batch, int64_t hw, const float* rgb01, const float* depth, const float* normal01, float near_plane,
+                         float far_plane, const float* quantiles, float* rgb, float* depth3, float* metric, float* normals,
+                         uint8_t* val_mask, void* stream);
 /* Test-time ensembling of the n_img (<= 32) predictions of ONE image, fp32, replacing
  *   ensemble_depths   /root/reference/Marigold/marigold/util/ensemble.py:40-132 (called from marigold_pipeline.py:293-297;
  *                     twin GeoWizard/geowizard/utils/depth_ensemble.py:21-115)
