@@ -247,17 +247,20 @@ def geowizard_main(args):
         init_synthetic_(enc, seed=2468)
         enc.eval()
     pipe = DepthNormalEstimationPipeline(unet.eval(), vae.eval(), DDIMScheduler(), image_encoder=enc)
+    if args.graph:
+        pipe.enable_hip_graphs()
     B, R = (args.batch if args.batch != 8 else 2), args.res
     g = torch.Generator(device=dev).manual_seed(rank)
     rgb = (torch.randint(0, 256, (B, 3, R, R), generator=g, device=dev, dtype=torch.int32).float() / 255.0 * 2.0 - 1.0).to(dtype)
     emb = None if enc is not None else (0.5 * torch.randn((B, 1, 768), generator=g, device=dev)).to(dtype)
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1) if args.graph else args.warmup):
         out = pipe.single_infer(rgb, emb, "indoor")
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
     timer = ops.KernelTimer()
-    ops.TIMER = timer
+    if not args.graph:
+        ops.TIMER = timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = pipe.single_infer(rgb, emb, "indoor")
@@ -266,6 +269,13 @@ def geowizard_main(args):
     torch.cuda.synchronize()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev)
     ops.TIMER = None
+    if args.graph:   # per-kernel durations from the same steps run eagerly after the timed region (a graph replay cannot be bracketed per kernel)
+        pipe.enable_hip_graphs(False)
+        ops.TIMER = timer
+        for _ in range(args.steps):
+            out = pipe.single_infer(rgb, emb, "indoor")
+        torch.cuda.synchronize()
+        ops.TIMER = None
     assert torch.isfinite(out[0].float()).all() and torch.isfinite(out[1].float()).all()
     ksum = timer.summary()
     if rank == 0:
@@ -278,7 +288,8 @@ def geowizard_main(args):
                 "dtype": "f16" if args.dtype == "fp16" else args.dtype, "data": "synthetic",
                 "config": {"workload": "GeoWizard joint depth+normals 1-step (dual-latent UNet, cross-domain joint attention, class embedding), batch=%d/GPU at "
                                        "%dx%d %s, random-init weights, %s" % (B, R, R, args.dtype, "CLIP ViT-L/14 image encoder (304M) inside the timed region" if enc is not None else "CLIP image embedding as input"),
-                           "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world},
+                           "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world,
+                           "launch_mode": "hipGraph replay" if args.graph else "host launches"},
                 "roofline": {"bound": "mfma", "kernel": "igemm2_kernel", "achieved": achieved, "peak": PEAK_TF[args.dtype], "unit": "TFLOP/s",
                              "frac": achieved / PEAK_TF[args.dtype], "traffic": None, "launches_per_step": ig["launches"] / args.steps,
                              "kernel_ms_per_step": ig["ms"] / args.steps,

@@ -143,9 +143,8 @@ def preprocess_for_clip(rgb, size=224, mean=CLIP_IMAGE_MEAN, std=CLIP_IMAGE_STD)
     """geowizard_pipeline.py:236-245: rgb in [-1, 1] [B,3,H,W] -> bicubic antialiased resize of (rgb+1)/2 to size x size, then
     (x - mean) / std in float32 (torchvision TF.resize(antialias=True) == F.interpolate(mode="bicubic", antialias=True))."""
     x = torch.nn.functional.interpolate((rgb + 1) / 2, size=(size, size), mode="bicubic", antialias=True, align_corners=False)
-    m = torch.tensor(mean, device=rgb.device, dtype=torch.float32)[:, None, None]
-    s = torch.tensor(std, device=rgb.device, dtype=torch.float32)[:, None, None]
-    return ((x.float() - m) / s).to(rgb.dtype)
+    as_t = lambda v: v if isinstance(v, torch.Tensor) else torch.tensor(v, device=rgb.device, dtype=torch.float32)[:, None, None]
+    return ((x.float() - as_t(mean)) / as_t(std)).to(rgb.dtype)
 
 
 # ------------------------------------------------------------------------------------------------------------

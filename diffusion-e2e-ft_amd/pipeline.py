@@ -307,16 +307,27 @@ class DepthNormalEstimationPipeline:
         self.image_encoder, self.feature_extractor = image_encoder, feature_extractor
         self._m = MarigoldPipeline(unet, vae, scheduler)
 
+    def _clip_constants(self):
+        """(size, mean [3,1,1], std [3,1,1]) of the CLIP preprocessor, resident on the device (no host->device copy per image)"""
+        from .clip import CLIP_IMAGE_MEAN, CLIP_IMAGE_STD
+        fe = self.feature_extractor
+        key = (str(self.device), id(fe))
+        if getattr(self, "_clip_key", None) != key:
+            mean = tuple(fe.image_mean) if fe is not None else CLIP_IMAGE_MEAN
+            std = tuple(fe.image_std) if fe is not None else CLIP_IMAGE_STD
+            size = fe.crop_size["height"] if fe is not None else self.image_encoder.config["image_size"]
+            self._clip_const = (size, torch.tensor(mean, device=self.device, dtype=torch.float32)[:, None, None],
+                                torch.tensor(std, device=self.device, dtype=torch.float32)[:, None, None])
+            self._clip_key = key
+        return self._clip_const
+
     @torch.no_grad()
     def encode_img_embed(self, rgb):
         """geowizard_pipeline.py:232-248 (__encode_img_embed): CLIP image embedding [B,1,X] of rgb in [-1,1]; resize + normalisation
         constants come from `feature_extractor` when one is given (image_mean / image_std / crop_size), else CLIP's defaults."""
-        from .clip import preprocess_for_clip, CLIP_IMAGE_MEAN, CLIP_IMAGE_STD
+        from .clip import preprocess_for_clip
         assert self.image_encoder is not None, "DepthNormalEstimationPipeline was built without an image_encoder: pass img_embed"
-        fe = self.feature_extractor
-        mean = tuple(fe.image_mean) if fe is not None else CLIP_IMAGE_MEAN
-        std = tuple(fe.image_std) if fe is not None else CLIP_IMAGE_STD
-        size = fe.crop_size["height"] if fe is not None else self.image_encoder.config["image_size"]
+        size, mean, std = self._clip_constants()
         x = preprocess_for_clip(rgb.to(device=self.device, dtype=self.dtype), size, mean, std)
         return self.image_encoder(x).image_embeds.unsqueeze(1).to(self.dtype)
 
@@ -336,25 +347,64 @@ class DepthNormalEstimationPipeline:
         emb = torch.cat([torch.sin(geo), torch.cos(geo), torch.sin(dom), torch.cos(dom)], dim=-1)  # 10 constants, host
         return emb.to(device=device, dtype=dtype)
 
-    @torch.no_grad()
-    def single_infer(self, input_rgb, img_embed=None, domain="indoor"):
-        device, dt = self.device, self.dtype
-        rgb = input_rgb.to(device=device, dtype=dt)
+    _graphs = None
+
+    def enable_hip_graphs(self, enabled=True):
+        """Replay single_infer from one captured hipGraph per (batch shape, dtype, domain, embedding source) — see
+        MarigoldPipeline.enable_hip_graphs; at 2 images per step the CLIP tower and the small UNet levels are launch-bound."""
+        self._graphs = {} if enabled else None
+        return self
+
+    def _device_path(self, rgb, img_embed, t_dev, sb, cls):
+        """everything after the host-side setup; only device work on the current stream (capturable)"""
         if img_embed is None:
             img_embed = self.encode_img_embed(rgb)
         B = rgb.shape[0]
-        self.scheduler.set_timesteps(1, device=device)
-        t = self.scheduler.timesteps[0]
+        dt = rgb.dtype
         rgb_latent = self._m.encode_rgb(rgb)
         _, C, h, w = rgb_latent.shape
-        xin = torch.zeros((2 * B, h, w, 2 * C), dtype=dt, device=device)  # geo latent half stays zero
+        xin = torch.zeros((2 * B, h, w, 2 * C), dtype=dt, device=rgb.device)  # geo latent half stays zero
         ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[:B, ..., :C])
         ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[B:, ..., :C])
-        ctx = img_embed.to(device=device, dtype=dt).repeat(2, 1, 1)
-        cls = self.class_embedding(B, domain, dt, device)
-        v = self.unet(to_nchw_view(xin), t.repeat(2 * B), encoder_hidden_states=ctx, class_labels=cls).sample
-        _, sb = self.scheduler.x0_coefficients(int(t))
+        ctx = img_embed.to(dt).repeat(2, 1, 1)
+        v = self.unet(to_nchw_view(xin), t_dev.repeat(2 * B), encoder_hidden_states=ctx, class_labels=cls).sample
         x0 = _scaled(v, -sb)
         depth = ops.depth_head(self._m._decode(x0[:B]).permute(0, 2, 3, 1), to_unit=True)
         normal = ops.normal_head(self._m._decode(x0[B:]).permute(0, 2, 3, 1), clamp=False, sign=-1.0)  # :341-342
         return depth, normal
+
+    @torch.no_grad()
+    def single_infer(self, input_rgb, img_embed=None, domain="indoor"):
+        device, dt = self.device, self.dtype
+        rgb = input_rgb.to(device=device, dtype=dt)
+        B = rgb.shape[0]
+        self.scheduler.set_timesteps(1, device=device)
+        t_dev = self.scheduler.timesteps[:1]
+        _, sb = self.scheduler.x0_coefficients(self.scheduler.timesteps_host[0])   # host copy: no device read-back
+        ck = (B, domain, dt, str(device))
+        if getattr(self, "_cls_key", None) != ck:
+            self._cls, self._cls_key = self.class_embedding(B, domain, dt, device), ck
+        cls = self._cls
+        if img_embed is not None:
+            img_embed = img_embed.to(device=device, dtype=dt)
+        if self._graphs is None:
+            return self._device_path(rgb, img_embed, t_dev, sb, cls)
+        from . import autograd as F
+        w0 = self.unet.conv_in.weight
+        key = (tuple(rgb.shape), dt, domain, None if img_embed is None else tuple(img_embed.shape), float(sb), F.PARAM_EPOCH, w0.data_ptr(), w0._version)
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._device_path(rgb, img_embed, t_dev, sb, cls)        # eager pass: fills the packed-weight caches
+            torch.cuda.synchronize()
+            s_rgb, s_emb, s_t = rgb.clone(), None if img_embed is None else img_embed.clone(), t_dev.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                s_out = self._device_path(s_rgb, s_emb, s_t, sb, cls)
+            ent = self._graphs[key] = (g, s_rgb, s_emb, s_t, s_out)
+        g, s_rgb, s_emb, s_t, s_out = ent
+        s_rgb.copy_(rgb)
+        if s_emb is not None:
+            s_emb.copy_(img_embed)
+        s_t.copy_(t_dev)
+        g.replay()
+        return s_out[0].clone(), s_out[1].clone()

@@ -142,3 +142,36 @@ def test_pipeline_encode_empty_text_with_native_text_encoder(dev):
     rgb, _ = synth.synth_inputs(1, 64, 64, 2, xdim, seed=3)
     out = pipe.single_infer(rgb, 1, noise="zeros")     # the embedding produced above drives the UNet's cross-attention
     assert torch.isfinite(out).all() and tuple(out.shape) == (1, 1, 64, 64)
+
+
+def test_geowizard_pipeline_hip_graph_replay(dev):
+    """DepthNormalEstimationPipeline.enable_hip_graphs(): CLIP tower + dual-latent UNet + two decodes replayed from one graph, bit-equal
+    to the eager launches, with the embedding computed inside the graph or supplied."""
+    import golden_cases as gc
+    from oracle import config
+    from diffusion_e2e_ft_amd.clip import CLIPVisionModelWithProjection
+    from diffusion_e2e_ft_amd.pipeline import DepthNormalEstimationPipeline
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    dtype = torch.float16
+    rgb, ctx = gc.geo_pipe_inputs()
+    rgb2 = rgb.flip(-1).contiguous()
+    xdim = ctx.shape[-1]
+    unet = UNet2DConditionModel(**config.TINY_GEOWIZARD_UNET)
+    unet.load_state_dict(gc.tiny_geo_sd())
+    vae = AutoencoderKL(**config.TINY_VAE)
+    vae.load_state_dict(gc.tiny_vae_sd())
+    cfg = dict(TINY, projection_dim=xdim)
+    enc = CLIPVisionModelWithProjection(**cfg)
+    enc.load_state_dict(tiny_clip_sd(cfg=cfg))
+    pipe = DepthNormalEstimationPipeline(unet.to(dev, dtype).eval(), vae.to(dev, dtype).eval(), DDIMScheduler(), image_encoder=enc.to(dev, dtype).eval())
+    eager = [tuple(t.clone() for t in pipe.single_infer(r)) for r in (rgb, rgb2)]
+    eager_emb = tuple(t.clone() for t in pipe.single_infer(rgb, img_embed=ctx))
+    pipe.enable_hip_graphs()
+    for r, want in ((rgb, eager[0]), (rgb2, eager[1]), (rgb, eager[0])):
+        d, n = pipe.single_infer(r)
+        assert torch.equal(d, want[0]) and torch.equal(n, want[1])
+    d, n = pipe.single_infer(rgb, img_embed=ctx)
+    assert torch.equal(d, eager_emb[0]) and torch.equal(n, eager_emb[1])
+    assert len(pipe._graphs) == 2
