@@ -71,3 +71,22 @@ def test_product_never_imports_oracle_or_falls_back():
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
             assert "torch.nn.functional.conv2d" not in src and "F.conv2d" not in src and "scaled_dot_product_attention" not in src, fn
+
+
+def test_plain_c_client(tmp_path):
+    """include/e2eft.h is C (not C++) and usable from a host with no Python / torch in it: gcc compiles tests/c/abi_client.c against the
+    header, the binary dlopens libe2eft.so and walks the no-GPU entry points (version, workspace sizing, argument errors)."""
+    import shutil
+    import subprocess
+    from diffusion_e2e_ft_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    _lib.load()
+    exe = str(tmp_path / "abi_client")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "abi_client.c"),
+                        "-o", exe, "-ldl"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, _lib.lib_path()], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "ok" in r.stdout
