@@ -300,6 +300,8 @@ static int run_igemm(int dtype, int mode, IgemmParams& p, int nz, void* stream) 
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+int launch_conv3x3_narrow(const E2eftConvDesc* d, const void* x1, const void* w, const void* bias, void* out, void* stream);   // narrow.hip
+
 }  // namespace e2eft
 
 using namespace e2eft;
@@ -355,6 +357,11 @@ static int conv2d_core(const E2eftConvDesc* d, const void* x1, const void* x2, c
     E2EFT_REQUIRE((long)d->batch * d->hout * d->wout < 2147483647L, "conv2d: M overflows int32");
     // the last output row/col must read at least one in-range tap row/col origin
     E2EFT_REQUIRE((d->hout - 1) * d->stride - d->pad_t < d->hl && (d->wout - 1) * d->stride - d->pad_l < d->wl, "conv2d: output larger than padded input");
+
+    if (!x2 && !rowadd && !residual && !gn_partial && !workspace) {   // <= 4 output channels: LDS-halo dot-product kernel instead of a 128-wide MFMA tile
+        const int rn = launch_conv3x3_narrow(d, x1, w, bias, out, stream);
+        if (rn >= 0) return rn;
+    }
 
     IgemmParams p = {};
     p.x1 = x1; p.x2 = x2; p.w = w; p.bias = bias; p.rowadd = rowadd; p.residual = residual; p.out = out;

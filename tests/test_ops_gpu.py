@@ -103,6 +103,18 @@ def test_conv3x3_basic(ops, dev, dtype):
     _conv_case(ops, dev, dtype, 3, 320, 320, 12, 12, 3, 1, (1, 1, 1, 1), rowadd=True)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_conv3x3_narrow_output(ops, dev, dtype):
+    """<= 4 output channels on >= 16k pixels take the LDS-halo dot-product kernel (csrc/narrow.hip): decoder conv_out 128 -> 3,
+    UNet conv_out 320 -> 4; ragged tiles, channel counts that end in a partial 64-channel chunk, alpha, one output channel"""
+    _conv_case(ops, dev, dtype, 2, 128, 3, 96, 96, 3, 1, (1, 1, 1, 1))
+    _conv_case(ops, dev, dtype, 2, 128, 4, 100, 90, 3, 1, (1, 1, 1, 1), alpha=0.7)
+    _conv_case(ops, dev, dtype, 2, 320, 4, 100, 90, 3, 1, (1, 1, 1, 1), alpha=0.7)   # Cin > 128 stays on the MFMA kernel
+    _conv_case(ops, dev, dtype, 1, 72, 1, 131, 127, 3, 1, (1, 1, 1, 1))
+    _conv_case(ops, dev, dtype, 3, 64, 2, 80, 80, 3, 1, (1, 1, 1, 1))
+    _conv_case(ops, dev, dtype, 1, 8, 3, 128, 130, 3, 1, (1, 1, 1, 1))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_stride2(ops, dev, dtype):
     _conv_case(ops, dev, dtype, 2, 32, 32, 16, 16, 3, 2, (1, 1, 1, 1))     # UNet Downsample2D
