@@ -8,6 +8,9 @@ encoder is frozen everywhere in the reference).  ViT-L/14: 24 layers x (LN -> 16
 quick-GELU MLP -> +) over 257 tokens; every matmul runs on the implicit-GEMM kernel (residuals folded into the epilogue), the
 attention core on the fused d=64 kernel, LayerNorm / activation as HBM streams.
 """
+import json
+import os
+
 import torch
 import torch.nn as nn
 
@@ -110,8 +113,39 @@ class CLIPVisionTransformer(nn.Module):
         return x, self.post_layernorm(x[:, 0].contiguous())
 
 
-class CLIPVisionModelWithProjection(nn.Module):
+class _HubIO:
+    """transformers-style directory IO: config.json + model.safetensors (the layout of a diffusers checkpoint's text_encoder/ and
+    image_encoder/ sub-folders; Marigold/run.py:270, GeoWizard run_infer.py)."""
+    weights_name = "model.safetensors"
+    _class_name = None
+
+    def save_pretrained(self, save_directory, **kw):
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(dict(self.config, architectures=[self._class_name]), f, indent=2)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}, os.path.join(save_directory, self.weights_name))
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, variant=None, **kw):
+        from safetensors.torch import load_file
+        from .unet import _weights_file
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, "config.json")) as f:
+            raw = json.load(f)
+        raw = dict(raw.get(cls._config_section, {}), **{k: v for k, v in raw.items() if not isinstance(v, dict)}) if cls._config_section else raw
+        m = cls(**{k: raw[k] for k in cls._defaults if k in raw})
+        sd = load_file(_weights_file(d, cls.weights_name, variant))
+        pre = cls._prefix
+        if not any(k.startswith(pre) for k in sd):          # transformers >= 5 saves the tower without its wrapper prefix
+            sd = {(k if k.startswith("visual_projection") else pre + k): v for k, v in sd.items()}
+        m.load_state_dict(sd)
+        return m.to(torch_dtype) if torch_dtype is not None else m
+
+
+class CLIPVisionModelWithProjection(_HubIO, nn.Module):
     """`image_encoder` slot of DepthNormalEstimationPipeline (geowizard_pipeline.py:76-86)."""
+    _class_name, _prefix, _config_section, _defaults = "CLIPVisionModelWithProjection", "vision_model.", "vision_config", CLIP_VIT_L14
 
     def __init__(self, **kwargs):
         super().__init__()
@@ -214,8 +248,9 @@ class CLIPTextTransformer(nn.Module):
         return self.final_layer_norm(x)
 
 
-class CLIPTextModel(nn.Module):
+class CLIPTextModel(_HubIO, nn.Module):
     """`text_encoder(input_ids)[0]` -> last_hidden_state [B, L, C] (after final_layer_norm), transformers state-dict layout."""
+    _class_name, _prefix, _config_section, _defaults = "CLIPTextModel", "text_model.", "text_config", SD2_TEXT
 
     def __init__(self, **kwargs):
         super().__init__()

@@ -53,6 +53,42 @@ class MarigoldPipeline:
             self.empty_text_embed = self.empty_text_embed.to(*args, **kwargs)
         return self
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, unet=None, vae=None, scheduler=None, text_encoder=None, tokenizer=None,
+                        variant=None, torch_dtype=None, **kw):
+        """MarigoldPipeline.from_pretrained(ckpt, unet=..., vae=..., ...) (Marigold/run.py:274-282) on a diffusers-format directory
+        (unet/, vae/, scheduler/, text_encoder/).  As in diffusers, components handed in are used as they are; `variant` and
+        `torch_dtype` only shape the ones loaded here.  No tokenizer is needed (clip.empty_prompt_ids)."""
+        import os
+        from .clip import CLIPTextModel
+        from .scheduler import DDIMScheduler
+        from .unet import UNet2DConditionModel
+        from .vae import AutoencoderKL
+        root = pretrained_model_name_or_path
+        if unet is None:
+            unet = UNet2DConditionModel.from_pretrained(root, subfolder="unet", torch_dtype=torch_dtype, variant=variant)
+        if vae is None:
+            vae = AutoencoderKL.from_pretrained(root, subfolder="vae", torch_dtype=torch_dtype, variant=variant)
+        if scheduler is None:
+            scheduler = DDIMScheduler.from_pretrained(root, subfolder="scheduler")
+        if text_encoder is None and os.path.isdir(os.path.join(root, "text_encoder")):
+            text_encoder = CLIPTextModel.from_pretrained(root, subfolder="text_encoder", torch_dtype=torch_dtype, variant=variant)
+        return cls(unet, vae, scheduler, text_encoder, tokenizer)
+
+    def save_pretrained(self, save_directory, **kw):
+        """diffusers layout: model_index.json + one sub-folder per component (training/train.py:612-630 saves the UNet this way)"""
+        import json
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        index = {"_class_name": "MarigoldPipeline"}
+        for name in ("unet", "vae", "scheduler", "text_encoder"):
+            comp = getattr(self, name)
+            if comp is not None and hasattr(comp, "save_pretrained"):
+                comp.save_pretrained(os.path.join(save_directory, name))
+                index[name] = ["diffusion_e2e_ft_amd", type(comp).__name__]
+        with open(os.path.join(save_directory, "model_index.json"), "w") as f:
+            json.dump(index, f, indent=2)
+
     def enable_xformers_memory_efficient_attention(self):
         return None  # fused attention is the only path
 

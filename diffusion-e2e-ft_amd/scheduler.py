@@ -28,6 +28,31 @@ class DDIMScheduler:
         self.num_inference_steps = None
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
 
+    config_name = "scheduler_config.json"
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, **overrides):
+        """DDIMScheduler.from_pretrained(ckpt, timestep_spacing=..., subfolder="scheduler") (Marigold/run.py:272): diffusers'
+        scheduler_config.json, keyword overrides win, unknown keys (trained_betas, rescale_betas_zero_snr, ...) are ignored"""
+        import inspect
+        import json
+        import os
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, cls.config_name)) as f:
+            cfg = json.load(f)
+        cfg.update(overrides)
+        known = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        return cls(**{k: v for k, v in cfg.items() if k in known})
+
+    def save_pretrained(self, save_directory, **kw):
+        import json
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = dict(self.config)
+        cfg["_class_name"] = "DDIMScheduler"
+        with open(os.path.join(save_directory, self.config_name), "w") as f:
+            json.dump(cfg, f, indent=2)
+
     def set_timesteps(self, num_inference_steps, device=None):
         n, T = num_inference_steps, self.config.num_train_timesteps
         self.num_inference_steps = n

@@ -119,6 +119,16 @@ class _UpBlock(nn.Module):
         return h
 
 
+def _weights_file(d, name, variant=None):
+    """diffusers naming: diffusion_pytorch_model[.<variant>].safetensors (run.py:256-282 passes variant="fp16" with --half_precision)"""
+    if variant:
+        stem, ext = os.path.splitext(name)
+        cand = os.path.join(d, "%s.%s%s" % (stem, variant, ext))
+        if os.path.exists(cand):
+            return cand
+    return os.path.join(d, name)
+
+
 class UNet2DConditionModel(nn.Module):
     config_name = "config.json"
     weights_name = "diffusion_pytorch_model.safetensors"
@@ -201,13 +211,13 @@ class UNet2DConditionModel(nn.Module):
         save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}, os.path.join(save_directory, self.weights_name))
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **kw):  # training/train.py:292-296
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, variant=None, **kw):  # training/train.py:292-296
         from safetensors.torch import load_file
         d = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(d, cls.config_name)) as f:
             cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_") and k in SD2_UNET_CONFIG}
         m = cls(**cfg)
-        m.load_state_dict(load_file(os.path.join(d, cls.weights_name)))
+        m.load_state_dict(load_file(_weights_file(d, cls.weights_name, variant)))
         return m.to(torch_dtype) if torch_dtype is not None else m
 
     # ---- forward ----

@@ -142,13 +142,14 @@ class AutoencoderKL(nn.Module):
         save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}, os.path.join(save_directory, self.weights_name))
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, **kw):
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=None, variant=None, **kw):
         from safetensors.torch import load_file
         d = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(d, cls.config_name)) as f:
             cfg = {k: v for k, v in json.load(f).items() if k in SD_VAE_CONFIG}
         m = cls(**cfg)
-        sd = load_file(os.path.join(d, cls.weights_name))
+        from .unet import _weights_file
+        sd = load_file(_weights_file(d, cls.weights_name, variant))
         # older checkpoints name the mid-block attention projections query/key/value/proj_attn
         ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
         for k in list(sd):

@@ -1,0 +1,93 @@
+"""CPU tests of the checkpoint surface the reference's scripts use (Marigold/run.py:266-282, training/train.py:292-296,322-339,612-630):
+component and pipeline save_pretrained / from_pretrained on diffusers-format directories, fp16 `variant` files, scheduler overrides."""
+import json
+import os
+
+import torch
+
+import golden_cases as gc
+from oracle import config
+from test_clip_cpu import TINY, TINY_TEXT, tiny_clip_sd, tiny_text_sd
+
+
+def _same(a, b):
+    return a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_pipeline_roundtrip(tmp_path):
+    from diffusion_e2e_ft_amd.clip import CLIPTextModel
+    from diffusion_e2e_ft_amd.pipeline import MarigoldPipeline
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    unet = UNet2DConditionModel(**config.TINY_UNET)
+    unet.load_state_dict(gc.tiny_unet_sd())
+    vae = AutoencoderKL(**config.TINY_VAE)
+    vae.load_state_dict(gc.tiny_vae_sd())
+    txt = CLIPTextModel(**TINY_TEXT)
+    txt.load_state_dict(tiny_text_sd())
+    pipe = MarigoldPipeline(unet, vae, DDIMScheduler(timestep_spacing="trailing"), text_encoder=txt)
+    d = str(tmp_path / "ckpt")
+    pipe.save_pretrained(d)
+    assert sorted(os.listdir(d)) == ["model_index.json", "scheduler", "text_encoder", "unet", "vae"]
+    assert os.path.exists(os.path.join(d, "unet", "diffusion_pytorch_model.safetensors")) and os.path.exists(os.path.join(d, "text_encoder", "model.safetensors"))
+    assert json.load(open(os.path.join(d, "model_index.json")))["unet"][1] == "UNet2DConditionModel"
+    back = MarigoldPipeline.from_pretrained(d)
+    assert _same(back.unet.state_dict(), unet.state_dict()) and _same(back.vae.state_dict(), vae.state_dict())
+    assert _same(back.text_encoder.state_dict(), txt.state_dict())
+    assert dict(back.unet.config) == dict(unet.config) and back.scheduler.config.timestep_spacing == "trailing"
+    # the reference's call shape: components loaded one by one, then handed to the pipeline (run.py:266-282)
+    u2 = UNet2DConditionModel.from_pretrained(d, subfolder="unet")
+    sch = DDIMScheduler.from_pretrained(d, timestep_spacing="leading", subfolder="scheduler")
+    p2 = MarigoldPipeline.from_pretrained(pretrained_model_name_or_path=d, unet=u2, vae=back.vae, scheduler=sch, text_encoder=back.text_encoder,
+                                          tokenizer=None, variant="fp16", torch_dtype=torch.float16)
+    assert p2.unet is u2 and p2.unet.dtype == torch.float32      # handed-in components are left alone (diffusers semantics)
+    assert p2.scheduler.config.timestep_spacing == "leading"
+
+
+def test_variant_files_and_dtype(tmp_path):
+    from safetensors.torch import save_file
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    unet = UNet2DConditionModel(**config.TINY_UNET)
+    unet.load_state_dict(gc.tiny_unet_sd())
+    d = str(tmp_path / "u")
+    unet.save_pretrained(d)
+    half = {k: (v * 2).half() for k, v in unet.state_dict().items()}           # a distinguishable fp16 variant file
+    save_file(half, os.path.join(d, "diffusion_pytorch_model.fp16.safetensors"))
+    a = UNet2DConditionModel.from_pretrained(d)
+    b = UNet2DConditionModel.from_pretrained(d, variant="fp16", torch_dtype=torch.float16)
+    c = UNet2DConditionModel.from_pretrained(d, variant="nonexistent")
+    k = next(iter(half))
+    assert torch.equal(a.state_dict()[k], unet.state_dict()[k]) and torch.equal(c.state_dict()[k], unet.state_dict()[k])
+    assert b.dtype == torch.float16 and torch.equal(b.state_dict()[k], half[k])
+
+
+def test_clip_towers_roundtrip_and_prefixless_files(tmp_path):
+    from safetensors.torch import save_file
+    from diffusion_e2e_ft_amd.clip import CLIPTextModel, CLIPVisionModelWithProjection
+    vis = CLIPVisionModelWithProjection(**TINY)
+    vis.load_state_dict(tiny_clip_sd())
+    d = str(tmp_path / "image_encoder")
+    vis.save_pretrained(d)
+    back = CLIPVisionModelWithProjection.from_pretrained(d)
+    assert _same(back.state_dict(), vis.state_dict()) and back.config["projection_dim"] == TINY["projection_dim"]
+    txt = CLIPTextModel(**TINY_TEXT)
+    txt.load_state_dict(tiny_text_sd())
+    d2 = str(tmp_path / "text_encoder")
+    txt.save_pretrained(d2)
+    # a file written by transformers >= 5 has no "text_model." prefix on its keys
+    save_file({k[len("text_model."):]: v.contiguous() for k, v in txt.state_dict().items()}, os.path.join(d2, "model.safetensors"))
+    assert _same(CLIPTextModel.from_pretrained(d2).state_dict(), txt.state_dict())
+
+
+def test_scheduler_config_tolerates_unknown_keys(tmp_path):
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    d = str(tmp_path)
+    json.dump({"_class_name": "DDIMScheduler", "_diffusers_version": "0.30.2", "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear",
+               "num_train_timesteps": 1000, "prediction_type": "v_prediction", "steps_offset": 1, "clip_sample": False, "set_alpha_to_one": False,
+               "trained_betas": None, "rescale_betas_zero_snr": False, "timestep_spacing": "leading", "dynamic_thresholding_ratio": 0.995},
+              open(os.path.join(d, "scheduler_config.json"), "w"))
+    s = DDIMScheduler.from_pretrained(d, timestep_spacing="trailing")
+    assert s.config.timestep_spacing == "trailing" and s.config.prediction_type == "v_prediction"
+    s.set_timesteps(1)
+    assert s.timesteps_host == [999]
