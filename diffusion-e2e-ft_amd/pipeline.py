@@ -24,6 +24,15 @@ class MarigoldDepthOutput:
     normal_colored: object
 
 
+@dataclass
+class DepthNormalPipelineOutput:          # geowizard_pipeline.py:37-57
+    depth_np: np.ndarray
+    depth_colored: object
+    normal_np: np.ndarray
+    normal_colored: object
+    uncertainty: Optional[np.ndarray]
+
+
 class MarigoldPipeline:
     rgb_latent_scale_factor = 0.18215    # marigold_pipeline.py:134
     depth_latent_scale_factor = 0.18215  # marigold_pipeline.py:135
@@ -444,3 +453,52 @@ class DepthNormalEstimationPipeline:
         s_t.copy_(t_dev)
         g.replay()
         return s_out[0].clone(), s_out[1].clone()
+
+    # ---- geowizard_pipeline.py:88-230 ----
+    @torch.no_grad()
+    def __call__(self, input_image, denoising_steps=1, ensemble_size=1, processing_res=768, match_input_res=True, batch_size=0,
+                 domain="indoor", color_map="Spectral", show_progress_bar=False, ensemble_kwargs=None, noise="zeros"):
+        """Host orchestration of the joint prediction: resize -> [-1,1] -> `ensemble_size` passes -> depth / normal ensembling ->
+        min-max -> resize back.  Only the E2E-FT setting is a device path here (denoising_steps = 1, noise = "zeros"); with it every
+        pass is identical, so ensemble_size > 1 is accepted for interface parity only.  Resampling runs in torch (the reference goes
+        through PIL / cv2 on the host: bicubic for depth, nearest for normals) and the colourised images are left to the caller."""
+        assert processing_res >= 0 and ensemble_size >= 1
+        if denoising_steps != 1 or noise != "zeros":
+            raise NotImplementedError("DepthNormalEstimationPipeline runs the E2E-FT setting: denoising_steps=1, noise='zeros'")
+        if isinstance(input_image, torch.Tensor):
+            rgb = input_image.squeeze()
+        else:
+            rgb = torch.from_numpy(np.asarray(input_image.convert("RGB"))).permute(2, 0, 1)
+        assert rgb.dim() == 3 and rgb.shape[0] == 3
+        H0, W0 = rgb.shape[-2:]
+        rgb = rgb.to(self.device)
+        if processing_res > 0:
+            rgb = resize_max_res(rgb, processing_res)
+        rgb_norm = (rgb.float() / 255.0 * 2.0 - 1.0).clamp(-1.0, 1.0).to(self.dtype)
+        bs = batch_size if batch_size > 0 else 1
+        dup = torch.stack([rgb_norm] * ensemble_size)
+        depths, normals = [], []
+        for s0 in range(0, ensemble_size, bs):
+            d, n = self.single_infer(dup[s0:s0 + bs], domain=domain)
+            depths.append(d)
+            normals.append(n)
+        depth_preds = torch.cat(depths, 0).float().squeeze(1)         # [N, H, W]
+        normal_preds = torch.cat(normals, 0).float()                  # [N, 3, H, W]
+        uncert = None
+        if ensemble_size > 1:
+            from .ensemble import ensemble_depths, ensemble_normals
+            depth_pred, uncert = ensemble_depths(depth_preds, **(ensemble_kwargs or {}))
+            normal_pred = ensemble_normals(normal_preds)[0]
+        else:
+            depth_pred, normal_pred = depth_preds[0], normal_preds[0]
+        mn, mx = depth_pred.min(), depth_pred.max()
+        depth_pred = (depth_pred - mn) / (mx - mn)
+        hwc = False
+        if match_input_res and tuple(depth_pred.shape[-2:]) != (H0, W0):
+            depth_pred = torch.nn.functional.interpolate(depth_pred[None, None], size=(H0, W0), mode="bicubic", align_corners=False)[0, 0]
+            normal_pred = torch.nn.functional.interpolate(normal_pred[None], size=(H0, W0), mode="nearest")[0]
+        if match_input_res:
+            normal_pred, hwc = normal_pred.permute(1, 2, 0), True      # the reference returns HWC normals after its cv2 resize (:205)
+        return DepthNormalPipelineOutput(depth_np=depth_pred.clamp(0, 1).cpu().numpy().astype(np.float32), depth_colored=None,
+                                         normal_np=normal_pred.clamp(-1, 1).contiguous().cpu().numpy().astype(np.float32), normal_colored=None,
+                                         uncertainty=uncert)

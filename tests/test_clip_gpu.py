@@ -175,3 +175,42 @@ def test_geowizard_pipeline_hip_graph_replay(dev):
     d, n = pipe.single_infer(rgb, img_embed=ctx)
     assert torch.equal(d, eager_emb[0]) and torch.equal(n, eager_emb[1])
     assert len(pipe._graphs) == 2
+
+
+def test_geowizard_pipeline_call(dev):
+    """DepthNormalEstimationPipeline.__call__ (geowizard_pipeline.py:88-230): tensor input, resize to processing_res and back,
+    ensembling of the (identical, zero-noise) passes, HWC normals"""
+    import golden_cases as gc
+    from oracle import config
+    from diffusion_e2e_ft_amd.clip import CLIPVisionModelWithProjection
+    from diffusion_e2e_ft_amd.pipeline import DepthNormalEstimationPipeline
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    import warnings
+    rgb, ctx = gc.geo_pipe_inputs()
+    xdim = ctx.shape[-1]
+    unet = UNet2DConditionModel(**config.TINY_GEOWIZARD_UNET)
+    unet.load_state_dict(gc.tiny_geo_sd())
+    vae = AutoencoderKL(**config.TINY_VAE)
+    vae.load_state_dict(gc.tiny_vae_sd())
+    cfg = dict(TINY, projection_dim=xdim)
+    enc = CLIPVisionModelWithProjection(**cfg)
+    enc.load_state_dict(tiny_clip_sd(cfg=cfg))
+    pipe = DepthNormalEstimationPipeline(unet.to(dev).eval(), vae.to(dev).eval(), DDIMScheduler(), image_encoder=enc.to(dev).eval())
+    img = ((rgb[0] + 1) / 2 * 255).round()                       # [3, 64, 64] in 0..255
+    one = pipe(img, processing_res=0, match_input_res=True)
+    assert one.depth_np.shape == (64, 64) and one.normal_np.shape == (64, 64, 3) and one.uncertainty is None
+    assert float(one.depth_np.min()) == 0.0 and float(one.depth_np.max()) == 1.0
+    d_ref, n_ref = pipe.single_infer((img / 255 * 2 - 1)[None])
+    assert abs(float(((one.normal_np ** 2).sum(-1) ** 0.5).mean()) - 1.0) < 1e-3
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ens = pipe(img, ensemble_size=3, batch_size=2, processing_res=0)
+    assert torch.allclose(torch.from_numpy(ens.depth_np), torch.from_numpy(one.depth_np), atol=1e-5)   # identical passes -> same ensemble
+    assert tuple(ens.uncertainty.shape) == (64, 64) and float(ens.uncertainty.abs().max()) < 1e-6
+    big = torch.nn.functional.interpolate(img[None], size=(128, 96), mode="bilinear")[0]
+    out = pipe(big, processing_res=64, match_input_res=True)      # processed at 64 x 48, resized back
+    assert out.depth_np.shape == (128, 96) and out.normal_np.shape == (128, 96, 3)
+    with pytest.raises(NotImplementedError):
+        pipe(img, denoising_steps=10, noise="gaussian")
