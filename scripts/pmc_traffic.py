@@ -1,0 +1,61 @@
+"""HBM traffic per kernel launch from rocprofv3 PMC counters -> profiles/r01_pmc_hbm_traffic.json (read by bench.py's roofline.traffic).
+
+Collect (on the GPU box; counters in their OWN runs, --kernel-trace only, as gpurun requires):
+    cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -o p -- \\
+          python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train-leg
+    done
+    python scripts/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE profiles/r01_pmc_hbm_traffic.json
+Units and corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide
+coalesced read -> doubled.  The correction is re-checked on every collection with gn_apply, whose read and write volumes are equal by
+construction (raw FETCH / WRITE must come out at 0.50)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+GROUPS = {"igemm2": "igemm2_kernel", "gn_apply": "gn_apply_kernel", "attn_fwd": "attn_fwd_kernel", "conv3x3_narrow": "conv3x3_narrow_kernel"}
+
+
+def load(d, counter):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    assert files, "no *_counter_collection.csv under %s" % d
+    per = {}
+    with open(files[0]) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            for g, pat in GROUPS.items():
+                if pat in row["Kernel_Name"]:
+                    a = per.setdefault(g, [0, 0.0])
+                    a[0] += 1
+                    a[1] += float(row["Counter_Value"])
+    return per
+
+
+def main():
+    fd, wd, out = sys.argv[1:4]
+    fetch, write = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python bench.py --steps 1 --warmup 1 "
+                     "--no-cpu-baseline --no-train-leg` (B=8, 768x768, fp16), aggregated by scripts/pmc_traffic.py; counter unit KiB; FETCH_SIZE doubled "
+                     "per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads) - re-checked on gn_apply, whose read and write volumes are "
+                     "equal by construction (raw FETCH / WRITE ratio recorded below)", "kernels": {}}
+    for g in GROUPS:
+        if g not in fetch or g not in write:
+            continue
+        n = fetch[g][0]
+        rf, rw = fetch[g][1] / n, write[g][1] / write[g][0]
+        res["kernels"][g] = {"launches": n, "fetch_bytes_per_launch_corrected": 2 * rf * 1024, "write_bytes_per_launch": rw * 1024,
+                             "hbm_bytes_per_launch": (2 * rf + rw) * 1024, "raw_fetch_kib_per_launch": rf, "raw_write_kib_per_launch": rw}
+    if "gn_apply" in res["kernels"]:
+        k = res["kernels"]["gn_apply"]
+        res["calibration_gn_apply_raw_fetch_over_write"] = k["raw_fetch_kib_per_launch"] / k["raw_write_kib_per_launch"]
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({g: round(v["hbm_bytes_per_launch"] / 1e6, 1) for g, v in res["kernels"].items()}), res.get("calibration_gn_apply_raw_fetch_over_write"))
+
+
+if __name__ == "__main__":
+    main()
