@@ -419,10 +419,48 @@ class DepthNormalEstimationPipeline:
         return depth, normal
 
     @torch.no_grad()
-    def single_infer(self, input_rgb, img_embed=None, domain="indoor"):
+    def _multi_step(self, rgb, img_embed, cls, num_inference_steps, noise, generator):
+        """geowizard_pipeline.py:266-343 for the pre-E2E-FT checkpoints: DDIM over the joint geometry latent (the SAME initial noise for
+        the depth and the normal row of an image, :271), host launches only."""
+        device, dt = rgb.device, rgb.dtype
+        B = rgb.shape[0]
+        if img_embed is None:
+            img_embed = self.encode_img_embed(rgb)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        rgb_latent = self._m.encode_rgb(rgb)
+        _, C, h, w = rgb_latent.shape
+        if isinstance(noise, torch.Tensor):          # an explicit initial latent [B,4,h,w] (tests, reproducibility across devices)
+            geo = noise.to(device=device, dtype=dt)
+        elif noise == "gaussian":
+            geo = torch.randn((B, C, h, w), device=device, dtype=dt, generator=generator)
+        elif noise == "pyramid":
+            geo = pyramid_noise_like(rgb_latent).to(device=device, dtype=dt)
+        elif noise == "zeros":
+            geo = torch.zeros((B, C, h, w), device=device, dtype=dt)
+        else:
+            raise ValueError("Invalid noise type: %s" % noise)
+        geo = geo.repeat(2, 1, 1, 1)
+        xin = torch.zeros((2 * B, h, w, 2 * C), dtype=dt, device=device)
+        ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[:B, ..., :C])
+        ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[B:, ..., :C])
+        ctx = img_embed.to(dt).repeat(2, 1, 1)
+        for i, (t, t_host) in enumerate(zip(self.scheduler.timesteps, self.scheduler.timesteps_host)):
+            ops.copy_scale(geo.permute(0, 2, 3, 1).contiguous(), xin[..., C:])
+            v = self.unet(to_nchw_view(xin), t.repeat(2 * B), encoder_hidden_states=ctx, class_labels=cls).sample
+            step = self.scheduler.step(v, t_host, geo)
+            geo = step.pred_original_sample if i == num_inference_steps - 1 else step.prev_sample   # :332-336
+        depth = ops.depth_head(self._m._decode(geo[:B]).permute(0, 2, 3, 1), to_unit=True)
+        normal = ops.normal_head(self._m._decode(geo[B:]).permute(0, 2, 3, 1), clamp=False, sign=-1.0)
+        return depth, normal
+
+    @torch.no_grad()
+    def single_infer(self, input_rgb, img_embed=None, domain="indoor", num_inference_steps=1, noise="zeros", show_pbar=False, generator=None):
         device, dt = self.device, self.dtype
         rgb = input_rgb.to(device=device, dtype=dt)
         B = rgb.shape[0]
+        if num_inference_steps != 1 or isinstance(noise, torch.Tensor) or noise != "zeros":
+            cls = self.class_embedding(B, domain, dt, device)
+            return self._multi_step(rgb, None if img_embed is None else img_embed.to(device=device, dtype=dt), cls, num_inference_steps, noise, generator)
         self.scheduler.set_timesteps(1, device=device)
         t_dev = self.scheduler.timesteps[:1]
         _, sb = self.scheduler.x0_coefficients(self.scheduler.timesteps_host[0])   # host copy: no device read-back
@@ -459,12 +497,10 @@ class DepthNormalEstimationPipeline:
     def __call__(self, input_image, denoising_steps=1, ensemble_size=1, processing_res=768, match_input_res=True, batch_size=0,
                  domain="indoor", color_map="Spectral", show_progress_bar=False, ensemble_kwargs=None, noise="zeros"):
         """Host orchestration of the joint prediction: resize -> [-1,1] -> `ensemble_size` passes -> depth / normal ensembling ->
-        min-max -> resize back.  Only the E2E-FT setting is a device path here (denoising_steps = 1, noise = "zeros"); with it every
-        pass is identical, so ensemble_size > 1 is accepted for interface parity only.  Resampling runs in torch (the reference goes
+        min-max -> resize back.  Defaults are the E2E-FT setting (denoising_steps = 1, noise = "zeros": every pass identical, ensembling
+        is a no-op); the reference's own defaults for the original checkpoints are 10 steps, 10 members, gaussian noise.  Resampling runs in torch (the reference goes
         through PIL / cv2 on the host: bicubic for depth, nearest for normals) and the colourised images are left to the caller."""
-        assert processing_res >= 0 and ensemble_size >= 1
-        if denoising_steps != 1 or noise != "zeros":
-            raise NotImplementedError("DepthNormalEstimationPipeline runs the E2E-FT setting: denoising_steps=1, noise='zeros'")
+        assert processing_res >= 0 and ensemble_size >= 1 and denoising_steps >= 1
         if isinstance(input_image, torch.Tensor):
             rgb = input_image.squeeze()
         else:
@@ -479,7 +515,7 @@ class DepthNormalEstimationPipeline:
         dup = torch.stack([rgb_norm] * ensemble_size)
         depths, normals = [], []
         for s0 in range(0, ensemble_size, bs):
-            d, n = self.single_infer(dup[s0:s0 + bs], domain=domain)
+            d, n = self.single_infer(dup[s0:s0 + bs], domain=domain, num_inference_steps=denoising_steps, noise=noise)
             depths.append(d)
             normals.append(n)
         depth_preds = torch.cat(depths, 0).float().squeeze(1)         # [N, H, W]

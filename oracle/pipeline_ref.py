@@ -85,6 +85,36 @@ def geowizard_infer_ref(unet_sd, unet_cfg, vae_sd, vae_cfg, rgb, img_embed, doma
     return (depth, normal, x0) if return_latent else (depth, normal)
 
 
+def ddim_step_ref(v, t, x_t, prev_t):
+    """diffusers DDIMScheduler.step for v_prediction, eta = 0, clip_sample False (scheduling_ddim.py): returns (prev_sample, x0).
+    prev_t < 0 uses final_alpha_cumprod = alphas_cumprod[0] (set_alpha_to_one False)."""
+    ac = alphas_cumprod()
+    a_t = ac[t]
+    a_prev = ac[prev_t] if prev_t >= 0 else ac[0]
+    x0 = a_t ** 0.5 * x_t - (1 - a_t) ** 0.5 * v
+    eps = a_t ** 0.5 * v + (1 - a_t) ** 0.5 * x_t
+    return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps, x0
+
+
+def geowizard_multistep_ref(unet_sd, unet_cfg, vae_sd, vae_cfg, rgb, img_embed, init_latent, steps, domain="indoor"):
+    """geowizard_pipeline.py:266-343 with an explicit initial geometry latent [B,4,h,w] (shared by the depth and the normal row, :271),
+    `steps` DDIM steps on the trailing schedule, the last step returning x0 (:335-336)."""
+    B = rgb.shape[0]
+    rgb_latent = encode_rgb_ref(vae_sd, vae_cfg, rgb).repeat(2, 1, 1, 1)
+    geo = init_latent.repeat(2, 1, 1, 1)
+    ctx = img_embed.repeat(2, 1, 1)
+    cls = geowizard_class_embedding(B, domain, rgb.dtype)
+    ts = [int(t) for t in trailing_timesteps(steps)]
+    for i, t in enumerate(ts):
+        v = unet_ref.unet_forward(unet_sd, unet_cfg, torch.cat([rgb_latent, geo], dim=1), t, ctx, class_labels=cls)
+        prev, x0 = ddim_step_ref(v, t, geo, t - 1000 // steps)
+        geo = x0 if i == steps - 1 else prev
+    dd = decode_ref(vae_sd, vae_cfg, geo[:B])
+    depth = (torch.clip(dd.mean(dim=1, keepdim=True), -1.0, 1.0) + 1.0) / 2.0
+    dn = decode_ref(vae_sd, vae_cfg, geo[B:])
+    return depth, -(dn / (torch.norm(dn, p=2, dim=1, keepdim=True) + 1e-5))
+
+
 def train_forward_ref(unet_sd, unet_cfg, vae_sd, vae_cfg, batch, text_embed, modality="depth"):
     """Forward half of training/train.py:470-556; returns (loss, current_estimate)."""
     rgb_latents = encode_rgb_ref(vae_sd, vae_cfg, batch["rgb"])

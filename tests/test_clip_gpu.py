@@ -212,5 +212,41 @@ def test_geowizard_pipeline_call(dev):
     big = torch.nn.functional.interpolate(img[None], size=(128, 96), mode="bilinear")[0]
     out = pipe(big, processing_res=64, match_input_res=True)      # processed at 64 x 48, resized back
     assert out.depth_np.shape == (128, 96) and out.normal_np.shape == (128, 96, 3)
-    with pytest.raises(NotImplementedError):
-        pipe(img, denoising_steps=10, noise="gaussian")
+    # the original (multi-step, noisy) GeoWizard setting: 3 DDIM steps, 3 ensemble members with different noise
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        multi = pipe(img, denoising_steps=3, ensemble_size=3, batch_size=3, processing_res=0, noise="gaussian")
+    assert multi.depth_np.shape == (64, 64) and float(multi.uncertainty.float().max()) > 0     # members differ now
+    assert abs(float(((multi.normal_np ** 2).sum(-1) ** 0.5).mean()) - 1.0) < 1e-3
+    # one noisy step reproduces the scheduler arithmetic of the Marigold loop: same UNet call, same DDIM step
+    g = torch.Generator(device=dev).manual_seed(3)
+    d1, n1 = pipe.single_infer((img / 255 * 2 - 1)[None], num_inference_steps=2, noise="gaussian", generator=g)
+    g = torch.Generator(device=dev).manual_seed(3)
+    d2, n2 = pipe.single_infer((img / 255 * 2 - 1)[None], num_inference_steps=2, noise="gaussian", generator=g)
+    assert torch.equal(d1, d2) and torch.equal(n1, n2) and torch.isfinite(d1).all()
+
+
+@pytest.mark.parametrize("steps", [2, 3])
+def test_geowizard_multistep_matches_oracle(dev, steps):
+    """the original GeoWizard setting (DDIM over the joint geometry latent, geowizard_pipeline.py:266-343) against the CPU oracle's
+    restatement of the loop and of diffusers' DDIM v-prediction step, from the same explicit initial latent"""
+    import golden_cases as gc
+    from oracle import config, pipeline_ref
+    from diffusion_e2e_ft_amd.pipeline import DepthNormalEstimationPipeline
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    rgb, emb = gc.geo_pipe_inputs()
+    usd, vsd = gc.tiny_geo_sd(), gc.tiny_vae_sd()
+    init = 0.8 * torch.randn(rgb.shape[0], 4, rgb.shape[2] // 8, rgb.shape[3] // 8, generator=torch.Generator().manual_seed(steps))
+    want_d, want_n = pipeline_ref.geowizard_multistep_ref(usd, config.TINY_GEOWIZARD_UNET, vsd, config.TINY_VAE, rgb, emb, init, steps)
+    unet = UNet2DConditionModel(**config.TINY_GEOWIZARD_UNET)
+    unet.load_state_dict(usd)
+    vae = AutoencoderKL(**config.TINY_VAE)
+    vae.load_state_dict(vsd)
+    pipe = DepthNormalEstimationPipeline(unet.to(dev).eval(), vae.to(dev).eval(), DDIMScheduler())
+    d, n = pipe.single_infer(rgb, img_embed=emb, num_inference_steps=steps, noise=init)
+    assert rel_err(d.cpu(), want_d) <= 2e-3, rel_err(d.cpu(), want_d)
+    cos = (n.cpu() * want_n).sum(1)
+    assert float(cos.mean()) > 0.999 and float(cos.min()) > 0.9
