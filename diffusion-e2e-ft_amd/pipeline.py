@@ -143,7 +143,7 @@ class MarigoldPipeline:
         rgb_in = rgb_in.to(device=device, dtype=dt)
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         timesteps = self.scheduler.timesteps
-        if noise == "zeros" and num_inference_steps == 1:
+        if isinstance(noise, str) and noise == "zeros" and num_inference_steps == 1:
             # E2E-FT path (x_t = 0, one step): no host synchronisation anywhere, optionally replayed from a captured hipGraph
             if self.empty_text_embed is None:
                 self.encode_empty_text()
@@ -157,7 +157,9 @@ class MarigoldPipeline:
         # UNet input buffer [B,h,w,8] NHWC: channels 0:4 rgb latent, 4:8 current latent ("this order is important" :447-449)
         xin = torch.zeros((B, h, w, 2 * C), dtype=dt, device=device)
         ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[..., :C])
-        if noise == "gaussian":
+        if isinstance(noise, torch.Tensor):      # an explicit initial latent [B,4,h,w]
+            latent = noise.to(device=device, dtype=dt)
+        elif noise == "gaussian":
             latent = torch.randn((B, C, h, w), device=device, dtype=dt, generator=generator)
         elif noise == "pyramid":
             latent = pyramid_noise_like(rgb_latent).to(device)

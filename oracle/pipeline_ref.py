@@ -96,6 +96,23 @@ def ddim_step_ref(v, t, x_t, prev_t):
     return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps, x0
 
 
+def marigold_multistep_ref(unet_sd, unet_cfg, vae_sd, vae_cfg, rgb, text_embed, init_latent, steps, normals=False):
+    """marigold_pipeline.py:372-478 for the multi-step checkpoints: DDIM on the trailing schedule from an explicit initial latent, the
+    last step returning x0 (:462-465)"""
+    rgb_latent = encode_rgb_ref(vae_sd, vae_cfg, rgb)
+    latent = init_latent
+    ctx = text_embed.repeat(rgb_latent.shape[0], 1, 1)
+    ts = [int(t) for t in trailing_timesteps(steps)]
+    for i, t in enumerate(ts):
+        v = unet_ref.unet_forward(unet_sd, unet_cfg, torch.cat([rgb_latent, latent], dim=1), t, ctx)
+        prev, x0 = ddim_step_ref(v, t, latent, t - 1000 // steps)
+        latent = x0 if i == steps - 1 else prev
+    dec = decode_ref(vae_sd, vae_cfg, latent)
+    if normals:
+        return dec / (torch.norm(dec, p=2, dim=1, keepdim=True) + 1e-5)
+    return (torch.clip(dec.mean(dim=1, keepdim=True), -1.0, 1.0) + 1.0) / 2.0
+
+
 def geowizard_multistep_ref(unet_sd, unet_cfg, vae_sd, vae_cfg, rgb, img_embed, init_latent, steps, domain="indoor"):
     """geowizard_pipeline.py:266-343 with an explicit initial geometry latent [B,4,h,w] (shared by the depth and the normal row, :271),
     `steps` DDIM steps on the trailing schedule, the last step returning x0 (:335-336)."""
