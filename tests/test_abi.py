@@ -90,3 +90,10 @@ def test_plain_c_client(tmp_path):
     r = subprocess.run([exe, _lib.lib_path()], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "ok" in r.stdout
+
+
+def test_every_symbol_is_documented_for_integrators():
+    """INTEGRATION.md is the maintainer-facing map from the reference's call sites to the C entry points: no exported symbol may be missing"""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in _declared() if n not in doc]
+    assert not missing, missing
