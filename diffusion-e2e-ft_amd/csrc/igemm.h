@@ -118,6 +118,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
 #pragma unroll
             for (int e = 0; e < 8; ++e) pv[e] = 0.f;
         }
+        // The row passes work on float2 values: explicit packed math (v_pk_fma_f32 / v_pk_add_f32 on NATURAL register pairs — the pairs
+        // are the dword pairs of the ds_read_b128 results, so no operand swizzle is needed; the swizzled forms the SLP vectorizer used
+        // to generate here are the ones that misread on gfx950, DESIGN.md §3.6, and build.py keeps that vectorizer off).  The
+        // statistics cost 4.6k cycles per 256x128 tile as scalar code (3 VALU per element) against 3.6k packed.
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 al2 = {al, al};
+        f2 bva2[4], pv2[4], sm2[4], sq2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bva2[q] = f2{bva[2 * q], bva[2 * q + 1]};
+            pv2[q] = f2{pv[2 * q], pv[2 * q + 1]};
+            sm2[q] = f2{0.f, 0.f};
+            sq2[q] = f2{0.f, 0.f};
+        }
         auto run = [&](auto has_res, auto has_ra) {
             constexpr bool HAS_RES = decltype(has_res)::value, HAS_RA = decltype(has_ra)::value;
 #pragma unroll
@@ -125,9 +139,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
                 const int row = rbase + pass * RPP;
                 const floatx4 t0 = *reinterpret_cast<const floatx4*>(tile + row * LDT + chunk * 8);
                 const floatx4 t1 = *reinterpret_cast<const floatx4*>(tile + row * LDT + chunk * 8 + 4);
-                float x[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                f2 x2[4] = {f2{t0[0], t0[1]}, f2{t0[2], t0[3]}, f2{t1[0], t1[1]}, f2{t1[2], t1[3]}};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], al, bva[e]);
+                for (int q = 0; q < 4; ++q) x2[q] = __builtin_elementwise_fma(x2[q], al2, bva2[q]);
                 if constexpr (HAS_RA) {
                     const int img = one_img ? img0 : (m0 + row) / p.rows_per_img;
                     const T* ra = rowadd + (long)img * p.N + n;
@@ -135,7 +149,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
                     for (int q = 0; q < 8 / EPC; ++q) {
                         const Vec16<T> t = ld16(ra + q * EPC);
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e) x[q * EPC + e] = fmaf(to_f(t.e[e]), al, x[q * EPC + e]);
+                        for (int e = 0; e < EPC; e += 2) {
+                            const int j = (q * EPC + e) >> 1;
+                            x2[j] = __builtin_elementwise_fma(f2{to_f(t.e[e]), to_f(t.e[e + 1])}, al2, x2[j]);
+                        }
                     }
                 }
                 if constexpr (HAS_RES) {
@@ -143,22 +160,25 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
                     for (int q = 0; q < 8 / EPC; ++q) {
                         const Vec16<T> t = ld16(rrow + pass * rstep + q * EPC);
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e) x[q * EPC + e] += to_f(t.e[e]);
+                        for (int e = 0; e < EPC; e += 2) {
+                            const int j = (q * EPC + e) >> 1;
+                            x2[j] += f2{to_f(t.e[e]), to_f(t.e[e + 1])};
+                        }
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < 8 / EPC; ++q) {
                     Vec16<T> o;
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(x[q * EPC + e]);
+                    for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(x2[(q * EPC + e) >> 1][(q * EPC + e) & 1]);
                     st16(orow + pass * ostep + q * EPC, o);
                 }
-                if (stats) {   // uniform: shifted sums about a per-column pivot shared by the whole tile (s_mean = sum, s_m2 = sum of squares)
+                if (stats) {   // uniform: shifted sums about a per-column pivot shared by the whole tile (sm2 = sum, sq2 = sum of squares)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float d = x[e] - pv[e];
-                        s_mean[e] += d;
-                        s_m2[e] = fmaf(d, d, s_m2[e]);
+                    for (int q = 0; q < 4; ++q) {
+                        const f2 d = x2[q] - pv2[q];
+                        sm2[q] += d;
+                        sq2[q] = __builtin_elementwise_fma(d, d, sq2[q]);
                     }
                 }
             }
@@ -171,6 +191,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
                 if (rowadd) run(std::false_type{}, std::true_type{});
                 else run(std::false_type{}, std::false_type{});
             }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s_mean[2 * q] = sm2[q][0]; s_mean[2 * q + 1] = sm2[q][1];
+            s_m2[2 * q] = sq2[q][0]; s_m2[2 * q + 1] = sq2[q][1];
         }
         if (stats) {   // uniform.  lanes l, l^16, l^32, l^48 own the same 8 columns: add; then the waves through LDS
 #pragma unroll
