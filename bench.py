@@ -254,7 +254,7 @@ def geowizard_main(args):
     rgb = (torch.randint(0, 256, (B, 3, R, R), generator=g, device=dev, dtype=torch.int32).float() / 255.0 * 2.0 - 1.0).to(dtype)
     emb = None if enc is not None else (0.5 * torch.randn((B, 1, 768), generator=g, device=dev)).to(dtype)
     for _ in range(max(args.warmup, 1) if args.graph else args.warmup):
-        out = pipe.single_infer(rgb, emb, "indoor")
+        out = pipe.single_infer(rgb, 1, "indoor", img_embed=emb)
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
@@ -263,7 +263,7 @@ def geowizard_main(args):
         ops.TIMER = timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pipe.single_infer(rgb, emb, "indoor")
+        out = pipe.single_infer(rgb, 1, "indoor", img_embed=emb)
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
@@ -273,7 +273,7 @@ def geowizard_main(args):
         pipe.enable_hip_graphs(False)
         ops.TIMER = timer
         for _ in range(args.steps):
-            out = pipe.single_infer(rgb, emb, "indoor")
+            out = pipe.single_infer(rgb, 1, "indoor", img_embed=emb)
         torch.cuda.synchronize()
         ops.TIMER = None
     assert torch.isfinite(out[0].float()).all() and torch.isfinite(out[1].float()).all()

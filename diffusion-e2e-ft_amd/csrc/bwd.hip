@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256) void ssi_bwd_apply_kernel(int hw, const float*
     const double nv = acc[1];
     const double Gs = gsum[b * 2], Gh = gsum[b * 2 + 1];
     double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    if (det > 0.0 && nv > 0.0) {
+    const bool live = nv > 0.0 && !isnan(acc[0]);     // skipped loss term (no valid pixel / NaN loss, train.py:504,548): zero gradient
+    if (det > 0.0 && live) {
         const double dd = a00 * a11 - a01 * a01;
         c0 = s / nv;
         c1 = (Gs * (-b1 + 2 * s * a01) + Gh * (-b0 + 2 * h * a01)) / (dd * nv);
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void ssi_bwd_apply_kernel(int hw, const float*
     float* d = dpred + (long)b * hw;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
         float g = 0.f;
-        if (m[i]) {
+        if (live && m[i]) {
             const float r = sc * p[i] + sh - t[i];
             const float sg = r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f);
             g = f0 * sg + f1 + f2 * t[i] + f3 * p[i];
@@ -305,16 +306,17 @@ __global__ __launch_bounds__(256) void angular_bwd_kernel(int hw, const float* _
     const float* t = tgt + (long)b * 3 * hw;
     const uint8_t* m = mask + (long)b * hw;
     float* d = dpred + (long)b * 3 * hw;
-    const float k = gout[0] / (float)acc[1];
+    const bool live = acc[1] > 0.0 && !isnan(acc[0]);   // skipped loss term (train.py:504,552): zero gradient
+    const float k = live ? gout[0] / (float)acc[1] : 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
         float g = 0.f;
-        if (m[i]) {
+        if (live && m[i]) {
             const float dt = p[i] * t[i] + p[hw + i] * t[hw + i] + p[2 * hw + i] * t[2 * hw + i];
             if (dt >= -1.f && dt <= 1.f) g = -k / sqrtf(1.f - dt * dt);
         }
-        d[i] = g * t[i];
-        d[hw + i] = g * t[hw + i];
-        d[2 * hw + i] = g * t[2 * hw + i];
+        d[i] = live ? g * t[i] : 0.f;
+        d[hw + i] = live ? g * t[hw + i] : 0.f;
+        d[2 * hw + i] = live ? g * t[2 * hw + i] : 0.f;
     }
 }
 
@@ -336,6 +338,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(long n, float* __restrict__ 
                                                     float* __restrict__ v, float lr, float b1, float b2, float eps, float wd, float bc1,
                                                     float bc2_sqrt, const double* __restrict__ sumsq, float gscale, float max_norm) {
     float clip = gscale;
+    // a non-finite gradient norm (overflow in a 16-bit forward, NaN input) must not reach the master weights and moments: skip the
+    // whole update, as the reference's step does nothing useful either once its loss term was dropped (train.py:548-553)
+    if (sumsq && !isfinite(sumsq[0])) return;
     if (sumsq && max_norm > 0.f) {
         const float nrm = (float)sqrt(sumsq[0]) * gscale;
         clip *= fminf(1.f, max_norm / (nrm + 1e-6f));

@@ -79,7 +79,11 @@ __global__ __launch_bounds__(256) void ssi_l1_kernel(int hw, const float* __rest
     block_atomic_add<2>(v, acc);
 }
 
-__global__ void mean_kernel(const double* __restrict__ acc, float* __restrict__ out) { out[0] = (float)(acc[0] / acc[1]); }
+// mean over the valid pixels.  No valid pixel -> 0 (the reference skips the loss term: `if val_mask.any()`, training/train.py:504);
+// a NaN sum -> 0 as well (`if not torch.isnan(...)`, train.py:548,552): the term contributes neither loss nor gradient (bwd.hip).
+__global__ void mean_kernel(const double* __restrict__ acc, float* __restrict__ out) {
+    out[0] = (acc[1] > 0.0 && !isnan(acc[0])) ? (float)(acc[0] / acc[1]) : 0.f;
+}
 
 __global__ __launch_bounds__(256) void angular_kernel(int hw, const float* __restrict__ pred, const float* __restrict__ tgt,
                                                       const uint8_t* __restrict__ mask, double* __restrict__ acc) {

@@ -87,9 +87,22 @@ def round_up(v, m):
 
 
 def _check_cuda(*ts):
+    """Every wrapper passes its tensors through here before it launches: they must be HIP tensors of ONE device, and that device
+    becomes the calling thread's current device (the library launches on `torch.cuda.current_stream()` of the current device, so a
+    model moved with `pipe.to("cuda:1")` in a process whose current device is still 0 would otherwise launch on device 0's stream
+    with device-1 pointers).  One process drives one GPU; the switch is sticky on purpose."""
+    idx = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("libe2eft ops need device (HIP) tensors; got a %s tensor. There is no CPU fallback." % t.device)
+        if idx is None:
+            idx = t.device.index
+        elif t.device.index != idx:
+            raise RuntimeError("libe2eft ops need all tensors of a call on one device; got cuda:%d and cuda:%d" % (idx, t.device.index))
+    if idx is not None and idx != torch.cuda.current_device():
+        torch.cuda.set_device(idx)
 
 
 def _nhwc_ld(t):

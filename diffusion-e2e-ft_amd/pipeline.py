@@ -352,6 +352,7 @@ class DepthNormalEstimationPipeline:
     def __init__(self, unet, vae, scheduler, image_encoder=None, feature_extractor=None):
         self.unet, self.vae, self.scheduler = unet, vae, scheduler
         self.image_encoder, self.feature_extractor = image_encoder, feature_extractor
+        self.img_embed = None                      # geowizard_pipeline.py:86
         self._m = MarigoldPipeline(unet, vae, scheduler)
 
     def _clip_constants(self):
@@ -456,7 +457,14 @@ class DepthNormalEstimationPipeline:
         return depth, normal
 
     @torch.no_grad()
-    def single_infer(self, input_rgb, img_embed=None, domain="indoor", num_inference_steps=1, noise="zeros", show_pbar=False, generator=None):
+    def single_infer(self, input_rgb, num_inference_steps=1, domain="indoor", show_pbar=False, noise="zeros", img_embed=None, generator=None):
+        """Positional order of the reference (geowizard_pipeline.py:252-258: input_rgb, num_inference_steps, domain, show_pbar, noise).
+        The CLIP embedding [B,1,X] comes from `img_embed=`, else from `self.img_embed` when a caller has set it as the reference's
+        `__call__` does (:222,283-284), else from the image encoder.  Defaults are the E2E-FT setting (one step, zeros)."""
+        if isinstance(num_inference_steps, torch.Tensor):        # older call form single_infer(rgb, img_embed[, domain])
+            img_embed, num_inference_steps = num_inference_steps, 1
+        if img_embed is None:
+            img_embed = self.img_embed
         device, dt = self.device, self.dtype
         rgb = input_rgb.to(device=device, dtype=dt)
         B = rgb.shape[0]

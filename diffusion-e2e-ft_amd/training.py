@@ -66,9 +66,11 @@ def encode_image(vae, image):
 def e2e_ft_loss(unet, vae, batch, empty_encoding, modality="depth", alpha_prod_999=None, return_estimate=False):
     """Forward half of one micro-step (train.py:472-556) with the zeros latent at t = 999 (the E2E-FT recipe).
     batch: rgb [b,3,H,W] in [-1,1], val_mask [b,1,H,W] bool, metric [b,1,H,W] / normals [b,3,H,W].  Returns the scalar loss
-    (device tensor with a grad_fn through the decoder and the UNet)."""
-    dev = unet.device
-    dt = getattr(unet, "compute_dtype", unet.dtype)
+    (device tensor with a grad_fn through the decoder and the UNet).  `unet` may be wrapped (DistributedDataParallel by
+    `accelerator.prepare`, train.py:369): attributes are read from `.module`, the forward goes through the wrapper."""
+    core = getattr(unet, "module", unet)
+    dev = core.device
+    dt = getattr(core, "compute_dtype", core.dtype)
     with torch.no_grad():
         rgb_latents = encode_image(vae, batch["rgb"].to(device=dev, dtype=dt)) * vae.config.scaling_factor
     val_mask = batch["val_mask"].bool().to(dev)
@@ -109,8 +111,9 @@ def geowizard_e2e_ft_loss(unet, vae, batch, imgs_embed, domain="indoor", depth_s
     noise): the UNet runs the doubled batch [depth rows; normal rows] with cross-domain joint self-attention and the class
     embedding, the frozen decoder decodes both halves, loss = 0.5 * SSI(depth) + 1.0 * angular(normals vs -GT).
     imgs_embed: CLIP image embeddings [b,1,768] (an input here)."""
-    dev = unet.device
-    dt = getattr(unet, "compute_dtype", unet.dtype)
+    core = getattr(unet, "module", unet)
+    dev = core.device
+    dt = getattr(core, "compute_dtype", core.dtype)
     with torch.no_grad():
         rgb_latents = encode_image(vae, batch["rgb"].to(device=dev, dtype=dt)) * vae.config.scaling_factor
     val_mask = batch["val_mask"].bool().to(dev)

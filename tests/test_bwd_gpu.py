@@ -395,6 +395,33 @@ def test_ssi_loss_gradient_degenerate_images(F, dev):
     assert p.grad[1].abs().max().item() == 0 and p.grad[2].abs().max().item() == 0
 
 
+def test_skipped_loss_terms_match_reference_guards(F, ops, dev):
+    """training/train.py:504 (`if val_mask.any()`) and :548,552 (`if not torch.isnan(loss)`): such a micro-batch contributes loss 0 and
+    no gradient; a non-finite gradient norm must leave parameters and Adam moments untouched"""
+    g = _g(4)
+    mask0 = torch.zeros(2, 1, 8, 8, dtype=torch.bool)
+    for fn, C in ((F.ssi_loss, 1), (F.angular_loss, 3)):
+        pred = torch.randn(2, C, 8, 8, generator=g)
+        tgt = torch.randn(2, C, 8, 8, generator=g)
+        p = pred.to(dev).requires_grad_(True)
+        loss = fn(p, tgt.to(dev), mask0.to(dev))
+        loss.backward()
+        assert loss.item() == 0.0 and p.grad.abs().max().item() == 0.0, fn
+        pn = pred.clone()
+        pn[0, 0, 1, 1] = float("nan")
+        p = pn.to(dev).requires_grad_(True)
+        loss = fn(p, tgt.to(dev), torch.ones(2, 1, 8, 8, dtype=torch.bool, device=dev))
+        loss.backward()
+        assert loss.item() == 0.0 and torch.isfinite(p.grad).all() and p.grad.abs().max().item() == 0.0, fn
+    n = 1000
+    p0 = torch.randn(n, generator=g).to(dev)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    gr = torch.randn(n, generator=g).to(dev)
+    gr[7] = float("inf")
+    ops.adamw_step_(p, gr, m, v, 3e-3, 0.9, 0.999, 1e-8, 1e-2, 1, grad_sumsq=ops.sumsq(gr), grad_scale=1.0, max_norm=1.0)
+    assert torch.equal(p, p0) and m.abs().max().item() == 0 and v.abs().max().item() == 0
+
+
 def test_flat_adamw_matches_torch(ops, dev):
     g = _g(8)
     n = 10007

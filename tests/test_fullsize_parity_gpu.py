@@ -1,0 +1,230 @@
+"""Parity of the HIP path with the CPU oracle ON BASELINE.json's CONFIGURATIONS: the full SD-v2 UNet (866 M
+parameters) and SD VAE (84 M), seeded synthetic weights, the same tensors on both sides.
+
+  (i)   configs[0] — one 256x256 image, strict fp32: predicted x0 latent within 1e-3 relative of `oracle.pipeline_ref.single_infer_ref`
+        (the north-star tolerance), depth within 2e-3;
+  (ii)  configs[1] resolution — one 768x768 image, fp16 compute, against the fp32 oracle at the stated 16-bit tolerance 2e-2;
+  (iii) the layer shapes that dominate configs[1] / [2] one by one against torch CPU fp32: conv 128->128 @768^2, fused nearest-upsample
+        conv 512->512 @192^2->384^2, split-K conv 1280->1280 @12^2, GroupNorm(+SiLU) 128 ch @768^2, fused self-attention 5 heads x 9216
+        tokens, the VAE mid-block attention (one 512-wide head, 9216 tokens) — the full-size code paths no tiny config reaches:
+        256x128 tiles on thousands of workgroups with the XCD tile map, 32-bit buffer offsets on GB-sized tensors, split-K at K = 11520,
+        9216-key online softmax;
+  (iv)  configs[2] resolution — one 576x576 image, strict fp32 E2E-FT micro-step: loss and sampled UNet gradients (first / middle / last
+        layers) against torch autograd over the oracle.
+The oracle is pinned to the reference's own wiring by tests/test_reference_wiring_cpu.py.  CPU cost of the oracle legs on the GPU
+box's host: about 2 s (256^2), 10 s (768^2), 1-2 min (576^2 forward + backward)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from oracle import config, pipeline_ref, unet_ref
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cpu_threads():
+    n = torch.get_num_threads()
+    torch.set_num_threads(max(n, min(64, os.cpu_count() or 1)))     # conftest caps at 8 for the small tests; the oracle legs here are big
+    yield
+    torch.set_num_threads(n)
+
+
+@pytest.fixture(scope="module")
+def models(dev):
+    from diffusion_e2e_ft_amd.synth import init_synthetic_
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    with torch.device(dev):
+        unet = UNet2DConditionModel(in_channels=8)
+        vae = AutoencoderKL()
+    init_synthetic_(unet, seed=1234)
+    init_synthetic_(vae, seed=4321)
+    usd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    vsd = {k: v.detach().float().cpu() for k, v in vae.state_dict().items()}
+    assert set(usd) == set(unet_ref.unet_param_shapes(config.SD2_UNET)) and sum(v.numel() for v in usd.values()) == 865_922_244
+    g = torch.Generator().manual_seed(0)
+    ctx = 0.5 * torch.randn((1, 2, 1024), generator=g)
+    return unet.eval(), vae.eval(), usd, vsd, ctx
+
+
+def _image(res, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, 256, (1, 3, res, res), generator=g, dtype=torch.int64).float() / 255.0 * 2.0 - 1.0
+
+
+def _pipe(unet, vae, dtype, ctx, dev):
+    import copy
+    from diffusion_e2e_ft_amd.pipeline import MarigoldPipeline
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    if dtype != torch.float32:
+        unet, vae = copy.deepcopy(unet).to(dtype), copy.deepcopy(vae).to(dtype)
+    pipe = MarigoldPipeline(unet, vae, DDIMScheduler())
+    pipe.empty_text_embed = ctx.to(dev, dtype)
+    return pipe
+
+
+def test_config0_256_fp32_latent_and_depth(dev, models, cpu_threads):
+    """BASELINE configs[0]: single 256x256 image, fp32 (Marigold/marigold/marigold_pipeline.py:372-478)"""
+    from diffusion_e2e_ft_amd import ops
+    from diffusion_e2e_ft_amd.modules import to_nchw_view
+    from diffusion_e2e_ft_amd.pipeline import _scaled
+    unet, vae, usd, vsd, ctx = models
+    rgb = _image(256, 5)
+    with torch.no_grad():
+        want_d, want_x0 = pipeline_ref.single_infer_ref(usd, config.SD2_UNET, vsd, config.SD_VAE, rgb, ctx, return_latent=True)
+    pipe = _pipe(unet, vae, torch.float32, ctx, dev)
+    with torch.no_grad():
+        depth = pipe.single_infer(rgb, 1, False, noise="zeros", normals=False)
+        lat = pipe.encode_rgb(rgb.to(dev))
+        xin = torch.zeros((1, lat.shape[2], lat.shape[3], 8), device=dev)
+        ops.copy_scale(lat.permute(0, 2, 3, 1), xin[..., :4])
+        v = pipe.unet(to_nchw_view(xin), pipe.scheduler.timesteps[0], encoder_hidden_states=ctx.to(dev)).sample
+        x0 = _scaled(v, -pipe.scheduler.x0_coefficients(999)[1])
+    e_x0, e_d = rel_err(x0, want_x0), rel_err(depth, want_d)
+    print("256^2 fp32: x0 latent rel err %.3e, depth rel err %.3e" % (e_x0, e_d))
+    assert e_x0 <= 1e-3, e_x0
+    assert e_d <= 2e-3, e_d
+
+
+def test_config1_768_fp16_against_fp32_oracle(dev, models, cpu_threads):
+    """BASELINE configs[1] resolution, one image: fp16 storage / fp32 accumulation against the fp32 oracle, 2e-2 of the output range"""
+    unet, vae, usd, vsd, ctx = models
+    rgb = _image(768, 6)
+    with torch.no_grad():
+        want_d, want_x0 = pipeline_ref.single_infer_ref(usd, config.SD2_UNET, vsd, config.SD_VAE, rgb, ctx, return_latent=True)
+        want_n = pipeline_ref.decode_ref(vsd, config.SD_VAE, want_x0)
+        want_n = want_n / (torch.norm(want_n, p=2, dim=1, keepdim=True) + 1e-5)
+    pipe = _pipe(unet, vae, torch.float16, ctx, dev)
+    with torch.no_grad():
+        depth = pipe.single_infer(rgb, 1, False, noise="zeros", normals=False)
+        normal = pipe.single_infer(rgb, 1, False, noise="zeros", normals=True)
+    e = rel_err(depth.float(), want_d)
+    mae = (depth.float().cpu() - want_d).abs().mean().item()
+    cos = (TF.normalize(normal.float().cpu(), dim=1) * want_n).sum(1).clamp(-1, 1)
+    ang = torch.rad2deg(torch.acos(cos)).mean().item()
+    print("768^2 fp16: depth max rel err %.3e, mean abs err %.3e; normals mean angle %.3f deg" % (e, mae, ang))
+    assert e <= 2e-2 and mae <= 2e-3, (e, mae)
+    assert ang <= 1.0, ang
+
+
+# ---- (iii) the dominant layer shapes, one by one -------------------------------------------------------------------------------
+def _conv_big(dev, dtype, B, Ci, Co, H, W, stride=1, up_to=None, seed=0, tol=None):
+    from diffusion_e2e_ft_amd import ops
+    from util import TOL, nhwc, pack_conv_weight, q, to_nchw
+    g = torch.Generator().manual_seed(seed)
+    x = q(torch.randn(B, Ci, H, W, generator=g), dtype)
+    w = q(torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5, dtype)
+    b = q(torch.randn(Co, generator=g), dtype)
+    xin = x if up_to is None else TF.interpolate(x, size=up_to, mode="nearest")
+    ref = TF.conv2d(xin, w, b, stride=stride, padding=1)
+    out = ops.conv2d(nhwc(x, dtype, dev), pack_conv_weight(w, dtype, dev), b.to(dtype).to(dev), Co, 3, 3, stride, (1, 1, 1, 1), up_to=up_to)
+    e = rel_err(to_nchw(out), ref)
+    assert e <= (tol or TOL[dtype]), e
+    return e
+
+
+def test_conv_128_at_768(dev, cpu_threads):
+    """VAE 128-channel level at full resolution: 2304 tiles of 256x128, K = 1152 (14 % of the inference step)"""
+    print("conv 128->128 @768^2 fp16 rel err %.2e" % _conv_big(dev, torch.float16, 1, 128, 128, 768, 768))
+
+
+def test_conv_upsample_512_at_192_to_384(dev, cpu_threads):
+    """decoder up-block: nearest 2x fused into the gather, K = 4608"""
+    print("upsample conv 512->512 @192->384 fp16 rel err %.2e" % _conv_big(dev, torch.float16, 1, 512, 512, 192, 192, up_to=(384, 384), seed=1))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_conv_splitk_1280_at_12(dev, dtype, cpu_threads):
+    """UNet mid level at 768^2 input with batch 8: 1152 pixels, K = 11520, split-K over filter-tap rows"""
+    print("split-K conv 1280->1280 @12^2 %s rel err %.2e" % (dtype, _conv_big(dev, dtype, 8, 1280, 1280, 12, 12, seed=2)))
+
+
+def test_groupnorm_128_at_768(dev, cpu_threads):
+    from diffusion_e2e_ft_amd import ops
+    from util import nhwc, q, to_nchw
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(3)
+    x = q(torch.randn(2, 128, 768, 768, generator=g) * 1.5 + torch.randn(1, 128, 1, 1, generator=g), dtype)
+    ga, be = q(1 + 0.3 * torch.randn(128, generator=g), dtype), q(0.3 * torch.randn(128, generator=g), dtype)
+    ref = TF.silu(TF.group_norm(x, 32, ga, be, 1e-6))
+    out = ops.groupnorm(nhwc(x, dtype, dev), ga.to(dtype).to(dev), be.to(dtype).to(dev), 32, 1e-6, True)
+    e = rel_err(to_nchw(out), ref)
+    print("GroupNorm+SiLU 128 ch @768^2 fp16 rel err %.2e" % e)
+    assert e <= 4.5e-3, e
+
+
+def test_attention_5_heads_9216_tokens(dev, cpu_threads):
+    """UNet level 0 self-attention at 768^2: 9216 queries x 9216 keys, 5 heads of 64"""
+    from diffusion_e2e_ft_amd import ops
+    from util import q
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(4)
+    qq, kk, vv = (q(torch.randn(1, 9216, 320, generator=g), dtype) for _ in range(3))
+    kk[0, 9000] = 3.0 * qq[0, 17]              # one dominant key late in the sequence: exercises the running-max rescale at full length
+    sp = lambda t: t.reshape(1, 9216, 5, 64).transpose(1, 2)
+    ref = TF.scaled_dot_product_attention(sp(qq), sp(kk), sp(vv)).transpose(1, 2).reshape(1, 9216, 320)
+    out = ops.attention(qq.to(dtype).to(dev), kk.to(dtype).to(dev), vv.to(dtype).to(dev), 5, 64 ** -0.5)
+    e = rel_err(out, ref)
+    print("attention 5 x 9216 x 9216 fp16 rel err %.2e" % e)
+    assert e <= 4.5e-3, e
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vae_midblock_attention_512_wide_9216_tokens(dev, dtype, cpu_threads):
+    """AutoencoderKL mid-block attention at 768^2 (unet_2d_blocks.py:589-601): one head of width 512, biases, 9216 tokens"""
+    from diffusion_e2e_ft_amd.modules import Attention
+    from util import q
+    g = torch.Generator().manual_seed(5)
+    C, N = 512, 9216
+    m = Attention(C, 1, bias=True)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(q(torch.randn(p.shape, generator=g) * (C ** -0.5 if p.dim() == 2 else 0.1), dtype))
+    x = q(torch.randn(1, N, C, generator=g), dtype)
+    res = q(torch.randn(1, N, C, generator=g), dtype)
+    with torch.no_grad():
+        qv, kv, vv = (TF.linear(x, getattr(m, n).weight, getattr(m, n).bias) for n in ("to_q", "to_k", "to_v"))
+        a = TF.scaled_dot_product_attention(qv[:, None], kv[:, None], vv[:, None])[:, 0]
+        ref = TF.linear(a, m.to_out[0].weight, m.to_out[0].bias) + res
+        out = m.to(dev, dtype)(x.to(dev, dtype), residual=res.to(dev, dtype))
+    e = rel_err(out.float(), ref)
+    print("VAE attention d=512 N=9216 %s rel err %.2e" % (dtype, e))
+    assert e <= (6e-3 if dtype == torch.float16 else 4e-2), e
+
+
+# ---- (iv) training micro-step at the configs[2] resolution ------------------------------------------------------------------------
+GRAD_KEYS = ["conv_in.weight", "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight", "down_blocks.1.resnets.0.conv1.weight",
+             "mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj.weight", "mid_block.resnets.1.conv2.weight",
+             "up_blocks.1.resnets.0.conv_shortcut.weight", "up_blocks.3.attentions.2.transformer_blocks.0.attn2.to_k.weight",
+             "up_blocks.3.resnets.2.norm2.weight", "conv_norm_out.bias", "conv_out.weight"]
+
+
+def test_config2_576_fp32_micro_step_gradients(dev, models, cpu_threads):
+    """BASELINE configs[2] resolution (576x576, 77-token context, `--mixed_precision no`): loss and sampled UNet gradients of one
+    micro-step (training/train.py:470-556) against torch autograd over the oracle"""
+    import copy
+    from diffusion_e2e_ft_amd import training
+    unet, vae, usd, vsd, _ = models
+    g = torch.Generator().manual_seed(9)
+    text = 0.5 * torch.randn((1, 77, 1024), generator=g)
+    batch = {k: v.cpu() for k, v in training.synthetic_batch(1, 576, 576, dev, seed=3).items()}
+    sd = dict(usd)
+    for k in GRAD_KEYS:
+        sd[k] = usd[k].clone().requires_grad_(True)
+    loss_ref, _ = pipeline_ref.train_forward_ref(sd, config.SD2_UNET, vsd, config.SD_VAE, batch, text, "depth")
+    loss_ref.backward()
+    u = copy.deepcopy(unet).train()
+    v = vae.requires_grad_(False)
+    loss = training.e2e_ft_loss(u, v, batch, text, "depth")
+    loss.backward()
+    torch.cuda.synchronize()
+    el = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+    named = dict(u.named_parameters())
+    errs = {k: rel_err(named[k].grad, sd[k].grad) for k in GRAD_KEYS}
+    print("576^2 fp32 micro-step: loss rel err %.3e; gradient rel errs %s" % (el, {k.split(".")[0] + ".." + k.split(".")[-2]: "%.1e" % e for k, e in errs.items()}))
+    assert el <= 1e-3, el
+    assert max(errs.values()) <= 5e-3, errs
