@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void angular_kernel(int hw, const float* __res
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
         if (m[i]) {
             float d = p[i] * t[i] + p[hw + i] * t[hw + i] + p[2 * hw + i] * t[2 * hw + i];
-            d = fminf(fmaxf(d, -1.f), 1.f);
+            d = isnan(d) ? d : fminf(fmaxf(d, -1.f), 1.f);   // torch.clamp propagates NaN (fminf / fmaxf would swallow it, loss.py:62)
             v[0] += (double)acosf(d);
             v[1] += 1.0;
         }
