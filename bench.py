@@ -14,6 +14,8 @@ timing over the timed region) and `cpu_baseline` (the CPU oracle timed on the ho
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,19 +48,91 @@ def parse():
                     "configs[2] batch in one pass, 122 GB of the 288 GB HBM; 16 in fp32)")
     ap.add_argument("--accum", type=int, default=None, help="--train: gradient-accumulation micro-steps per optimizer step (default 32 / micro-batch)")
     ap.add_argument("--modality", default="depth", choices=["depth", "normals"])
+    ap.add_argument("--grad-ckpt", action="store_true", help="--train: activation recompute in the UNet blocks and the frozen decoder "
+                    "(`--gradient_checkpointing` of the reference's training scripts); off by default: the whole batch fits in 288 GB")
     ap.add_argument("--graph", action="store_true", help="inference: replay one captured hipGraph per batch instead of launching ~1.4k kernels from the host "
                     "(measured: no difference at batch 8 - the launches already run back to back; it matters for latency at batch 1)")
     ap.add_argument("--no-image-encoder", action="store_true", help="--geowizard: feed a CLIP image embedding as input instead of running ViT-L/14")
     ap.add_argument("--geowizard", action="store_true", help="time GeoWizard joint depth+normals 1-step inference (BASELINE.json configs[4]: "
                     "dual-latent UNet with cross-domain attention, 2 images per GPU by default) instead of Marigold depth")
-    ap.add_argument("--no-train-leg", action="store_true", help="inference mode at N=1: skip the short E2E-FT training-step measurement "
-                    "that is appended to the JSON line as `train_step`")
+    ap.add_argument("--no-train-leg", action="store_true", help="inference mode at N=1: skip the E2E-FT training-step measurements "
+                    "that are appended to the JSON line as `train_step` (bf16 compute) and `train_step_fp32` (the reference recipe)")
+    ap.add_argument("--plumbing-check", action="store_true", help="launcher / rendezvous / timing-reduction check without GPU work (gloo, CPU): "
+                    "prints a line with value null; used by tests/test_distributed_cpu.py")
     args = ap.parse_args()
     if args.res is None:
         args.res = 576 if args.train else 768
     if args.dtype is None:
         args.dtype = "bf16" if args.train else "fp16"
     return args
+
+
+T_START = time.time()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_command(gpus, argv, port):
+    """the command `bench.py --gpus N` re-executes itself under when it was started as ONE process: one rank per GPU over RCCL, the
+    launch line of the task contract (the reference: `accelerate launch --multi_gpu`, training/scripts/multi_gpu.yaml:1-15)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_spawn_ranks(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself and exits with their status."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    if not args.plumbing_check:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but this node exposes %d GPU(s); refusing to report a number for fewer ranks" % (args.gpus, have))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(launcher_command(args.gpus, sys.argv[1:], _free_port()), env=env))
+
+
+def check_world(args, world):
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d - refusing to print a line whose n_gpus differs from --gpus" % (args.gpus, world))
+
+
+def rank_table(rank, local_rank, world, dev):
+    """[{rank, local_rank, device, name}] of every rank (all-gathered), so the JSON line shows which GPUs took part"""
+    me = {"rank": rank, "local_rank": local_rank, "device": str(dev),
+          "name": torch.cuda.get_device_name(dev) if (dev is not None and dev.type == "cuda") else "cpu"}
+    if world == 1:
+        return [me]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, me)
+    return out
+
+
+def plumbing_main(args):
+    """no GPU work: rendezvous (gloo), barrier, max-over-ranks, one JSON line from rank 0 - the launcher path on a CPU-only host"""
+    from diffusion_e2e_ft_amd import dist as D
+    rank, local_rank, world = D.init_from_env(backend="gloo")
+    check_world(args, world)
+    D.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    ranks = rank_table(rank, local_rank, world, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing check (no GPU work)", "value": None, "unit": "images/s", "n_gpus": world, "world": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3, "plumbing_check": True, "ranks": ranks}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 def train_batching(args):
@@ -90,42 +164,74 @@ def build_pipeline(dev, dtype, tiny):
     return pipe
 
 
-def cpu_baseline(res_hint):
-    """CPU oracle (oracle/ — the restatement of the reference's diffusers CPU path) on this host's cores, bounded sample."""
+def cpu_baseline(res_hint, budget_s=75.0):
+    """CPU oracle (oracle/ - the restatement of the reference's diffusers CPU path, pinned to the reference's wiring by
+    tests/test_reference_wiring_cpu.py) on this host's cores: 1 warm-up + up to 3 timed runs per case, MEDIAN reported, in
+    torch's default NCHW layout (what the reference would run) and in channels_last.  Bounded: a case stops adding runs once the whole leg
+    has used `budget_s` seconds (at least one timed run each)."""
+    import statistics
     from oracle import config, unet_ref, vae_ref, pipeline_ref, synth
     cores = min(os.cpu_count() or 1, 32)   # torch's CPU convs get slower, not faster, beyond a few dozen threads
     torch.set_num_threads(cores)
+    t_leg = time.perf_counter()
     usd = synth.fast_state_dict(unet_ref.unet_param_shapes(config.SD2_UNET), seed=1234)   # values are irrelevant for timing
     vsd = synth.fast_state_dict(vae_ref.vae_param_shapes(config.SD_VAE), seed=4321)
+    cl = lambda sd: {k: (v.contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v) for k, v in sd.items()}
+    sds = {"nchw": (usd, vsd), "channels_last": (cl(usd), cl(vsd))}
 
-    def run(res):
+    def run(res, layout):
         rgb, ctx = synth.synth_inputs(1, res, res, 2, 1024, seed=0)
+        if layout == "channels_last":
+            rgb = rgb.contiguous(memory_format=torch.channels_last)
+        u, v = sds[layout]
         t0 = time.perf_counter()
         with torch.no_grad():
-            pipeline_ref.single_infer_ref(usd, config.SD2_UNET, vsd, config.SD_VAE, rgb, ctx)
+            pipeline_ref.single_infer_ref(u, config.SD2_UNET, v, config.SD_VAE, rgb, ctx)
         return time.perf_counter() - t0
 
-    run(64)  # warm-up (thread pool, allocator, first touch of the 3.8 GB of weights)
-    t256 = run(256)   # BASELINE.json configs[0]: one 256x256 image, fp32, CPU
+    def case(res, layout, warm=True):
+        if warm:
+            run(res, layout)
+        ts = []
+        for _ in range(3):
+            ts.append(run(res, layout))
+            if time.perf_counter() - t_leg > budget_s:
+                break
+        return statistics.median(ts), len(ts)
+
+    run(64, "nchw")  # thread pool, allocator, first touch of the 3.8 GB of weights
+    out = {}
+    for layout in ("nchw", "channels_last"):
+        out[(256, layout)] = case(256, layout)          # BASELINE.json configs[0]: one 256x256 image, fp32, CPU
     tf256 = sum(WORK_GF[256].values()) / 1e3
     tf768 = sum(WORK_GF[768].values()) / 1e3
-    if t256 * tf768 / tf256 < 30.0:
-        t768 = run(768)
-        return dict(value=1.0 / t768, unit="images/s", cores=cores, kind="port",
-                    sample="CPU oracle (pure-torch fp32 restatement of the diffusers path), 1 image 768x768, 1 run, %d threads; "
-                           "the 256x256 image (BASELINE configs[0]) took %.2f s" % (cores, t256))
-    return dict(value=(tf256 / tf768) / t256, unit="images/s", cores=cores, kind="port",
-                sample="CPU oracle (pure-torch fp32), 1 image 256x256 (BASELINE configs[0]) in %.2f s, scaled to 768x768 by algorithmic "
-                       "FLOPs (%.2f/%.2f TFLOP), %d threads" % (t256, tf256, tf768, cores))
+    est768 = out[(256, "nchw")][0] * tf768 / tf256
+    if est768 < 20.0:
+        for layout in ("nchw", "channels_last"):
+            out[(768, layout)] = case(768, layout, warm=time.perf_counter() - t_leg + 4 * est768 < budget_s)
+        t768, n768 = out[(768, "nchw")]
+        value, how = 1.0 / t768, "1 image 768x768, median of %d run(s)" % n768
+    else:
+        value, how = (tf256 / tf768) / out[(256, "nchw")][0], "256x256 time scaled to 768x768 by algorithmic FLOPs (%.2f / %.2f TFLOP)" % (tf256, tf768)
+    table = {"%dx%d_%s" % (r, r, l): {"median_s": round(t, 4), "runs": n} for (r, l), (t, n) in out.items()}
+    return dict(value=value, unit="images/s", cores=cores, kind="port",
+                sample="CPU oracle (pure-torch fp32 restatement of the diffusers path, NCHW as the reference would run it), %s, 1 warm-up, %d threads; "
+                       "BASELINE configs[0] (one 256x256 image): %.2f s median" % (how, cores, out[(256, "nchw")][0]),
+                channels_last_value=(1.0 / out[(768, "channels_last")][0]) if (768, "channels_last") in out else None,
+                runs=table, leg_seconds=round(time.perf_counter() - t_leg, 1))
 
 
 def train_main(args):
     from diffusion_e2e_ft_amd import dist as D
     rank, local_rank, world = D.init_from_env()
+    check_world(args, world)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
-    line = run_train(args, rank, world, torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    ranks = rank_table(rank, local_rank, world, dev)
+    line = run_train(args, rank, world, dev)
     if rank == 0:
+        line["world"], line["ranks"], line["rccl_ranks"] = world, ranks, (world if world > 1 else 0)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -156,6 +262,9 @@ def run_train(args, rank, world, dev):
     init_synthetic_(vae, seed=4321)
     unet.train().set_compute_dtype(cdt)
     vae.eval().requires_grad_(False)
+    if getattr(args, "grad_ckpt", False):
+        unet.enable_gradient_checkpointing()
+        vae.enable_gradient_checkpointing()
     opt = training.FlatAdamW(unet.parameters(), lr=3e-5, max_grad_norm=1.0)
     R = args.res
     mb, acc = train_batching(args)
@@ -206,7 +315,8 @@ def run_train(args, rank, world, dev):
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "images_per_s": n_img / sec, "final_loss": float(loss), "peak_mem_gib": peak_mem,
             "config": {"workload": "E2E-FT training step (%s loss, UNet bwd) batch=%d/GPU (%d micro-steps x %d) at %dx%d, %s compute, fp32 master "
-                                   "weights + flat AdamW, no activation recompute%s" % (args.modality, mb * acc, acc, mb, R, R, args.dtype,
+                                   "weights + flat AdamW, %s%s" % (args.modality, mb * acc, acc, mb, R, R, args.dtype,
+                                                                                         "per-block activation recompute (UNet + decoder)" if getattr(args, "grad_ckpt", False) else "no activation recompute",
                                                                                          " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
                        "images_per_step": n_img, "resolution": R, "parallelism": "dp%d (RCCL all-reduce of the flat fp32 gradient, overlapped)" % world},
             "roofline": {"bound": "mfma", "kernel": "igemm kernels (fwd, dgrad, wgrad GEMMs, attention-backward GEMMs)", "achieved": achieved, "peak": peak,
@@ -228,9 +338,11 @@ def geowizard_main(args):
     from diffusion_e2e_ft_amd.pipeline import DepthNormalEstimationPipeline
     from diffusion_e2e_ft_amd.synth import init_synthetic_
     rank, local_rank, world = D.init_from_env()
+    check_world(args, world)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks = rank_table(rank, local_rank, world, dev)
     dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     with torch.device(dev):
@@ -283,7 +395,8 @@ def geowizard_main(args):
         achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         at = ksum.get("attn", dict(launches=0, ms=0.0, flops=0.0))
         line = {"metric": "images/sec (768x768, GeoWizard joint depth+normals, 1-step dual-latent UNet fwd) full path",
-                "value": B * world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "value": B * world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "world": world, "ranks": ranks,
+                "rccl_ranks": world if world > 1 else 0, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f16" if args.dtype == "fp16" else args.dtype, "data": "synthetic",
                 "config": {"workload": "GeoWizard joint depth+normals 1-step (dual-latent UNet, cross-domain joint attention, class embedding), batch=%d/GPU at "
@@ -300,8 +413,18 @@ def geowizard_main(args):
         dist.destroy_process_group()
 
 
+def _mark(timeline, what):
+    """leg boundaries in seconds since process start: lets a GPU-busy trace sampled around this process be read (the CPU baseline leg
+    keeps the GPU idle for about a minute BEFORE any GPU work)"""
+    timeline.append({"t": round(time.time() - T_START, 2), "event": what})
+    print("[bench %.1fs] %s" % (time.time() - T_START, what), file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
+    maybe_spawn_ranks(args)          # `--gpus N` from one process: re-executes under torch.distributed.run and exits
+    if args.plumbing_check:
+        return plumbing_main(args)
     if args.train:
         return train_main(args)
     if args.geowizard:
@@ -309,12 +432,22 @@ def main():
     from diffusion_e2e_ft_amd import dist as D
     from diffusion_e2e_ft_amd import ops
     rank, local_rank, world = D.init_from_env()
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    check_world(args, world)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks = rank_table(rank, local_rank, world, dev)
     dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
+    timeline = []
+    cpu_leg = None
+    if world == 1 and not args.no_cpu_baseline:
+        # the CPU leg runs FIRST (GPU idle), so that everything after its end marker is GPU work
+        _mark(timeline, "cpu_baseline start (GPU idle)")
+        try:
+            cpu_leg = cpu_baseline(args.res)
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            cpu_leg = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        _mark(timeline, "cpu_baseline end")
     torch.set_num_threads(min(8, os.cpu_count() or 1))
 
     pipe = build_pipeline(dev, dtype, args.tiny)
@@ -328,11 +461,13 @@ def main():
 
     if args.graph:
         pipe.enable_hip_graphs()      # the timed steps replay one captured hipGraph per batch (captured during the first warm-up step)
+    _mark(timeline, "inference warm-up start")
     for _ in range(max(args.warmup, 1) if args.graph else args.warmup):
         out = step()
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
+    _mark(timeline, "inference timed region start")
     timer = ops.KernelTimer()
     if not args.graph:
         ops.TIMER = timer             # HIP events around every launch, on the launch stream, inside the timed region
@@ -344,6 +479,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    _mark(timeline, "inference timed region end")
     assert torch.isfinite(out.float()).all(), "non-finite depth output"
     elapsed = D.max_over_ranks(elapsed, device=dev)
     if args.graph:
@@ -378,17 +514,18 @@ def main():
                                 tflops=kk["flops"] / (kk["ms"] * 1e-3) / 1e12, gbs=kk["bytes"] / (kk["ms"] * 1e-3) / 1e9)
         # HBM bytes per igemm launch from the PMC counters: collected offline (rocprofv3 --pmc cannot wrap its own process) on exactly
         # this workload and committed with its provenance; null for any other workload
-        traffic, traffic_note = None, "no PMC profile for this workload"
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if os.path.exists(pmc) and (B, R, args.dtype, args.tiny) == (8, 768, "fp16", False):
-            with open(pmc) as f:
+        traffic, traffic_note, traffic_source = None, "no PMC profile for this workload", None
+        pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if pmcs and (B, R, args.dtype, args.tiny) == (8, 768, "fp16", False):
+            with open(os.path.join(ROOT, "profiles", pmcs[-1])) as f:
                 pj = json.load(f)
             traffic = pj["kernels"]["igemm2"]["hbm_bytes_per_launch"]
-            traffic_note = "bytes per launch (average over the %d igemm launches of a step), profiles/r01_pmc_hbm_traffic.json: %s" % (
-                ig["launches"] / args.steps, pj["source"])
+            traffic_source = "static: profiles/%s (NOT measured in this run)" % pmcs[-1]
+            traffic_note = "bytes per launch (average over the %d igemm launches of a step), %s: %s" % (ig["launches"] / args.steps, pmcs[-1], pj["source"])
         line = {
             "metric": "images/sec (768x768, 1-step UNet fwd) full path: VAE encode + SD-v2 UNet @t=999 + VAE decode",
-            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "images/s", "n_gpus": world, "world": world, "ranks": ranks, "rccl_ranks": world if world > 1 else 0,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.dtype == "fp16" else args.dtype, "data": "synthetic",
             "config": {"workload": "marigold-e2e-ft-depth 1-step inference, batch=%d/GPU at %dx%d %s, random-init SD-v2 UNet (866M) + SD VAE (84M)%s"
@@ -397,7 +534,7 @@ def main():
                        "launch_mode": "hipGraph replay (one captured graph per batch shape)" if args.graph else "host launches"},
             "roofline": {"bound": "mfma", "kernel": "igemm2_kernel (implicit-GEMM conv/linear, all launches of the timed region)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "traffic_note": traffic_note, "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
+                         "traffic_source": traffic_source, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
                          "launches_per_step": ig["launches"] / args.steps, "kernel_ms_per_step": ig["ms"] / args.steps,
                          "algorithmic_gflop_per_step": ig["flops"] / args.steps / 1e9, "other_kernels": extra},
         }
@@ -411,24 +548,28 @@ def main():
             tot = sum(WORK_GF[R].values())
             line["config"]["algorithmic_tflop_per_image"] = tot / 1e3
             line["effective_tflops"] = value * tot / 1e3
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(R)
-            except Exception as e:  # the baseline must never take the GPU number down with it
-                line["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        if cpu_leg is not None:
+            line["cpu_baseline"] = cpu_leg
         if world == 1 and not args.no_train_leg and not args.tiny:
-            # second part of BASELINE.json's metric ("...; E2E-FT step time"): configs[2], batch 32 at 576x576, one GPU
-            try:
-                del pipe, out, rgb, img
-                torch.cuda.empty_cache()
-                targs = argparse.Namespace(**vars(args))
-                targs.dtype, targs.res, targs.steps, targs.warmup, targs.detail, targs.micro_batch, targs.accum = "bf16", 576, 2, 1, None, None, None
-                t = run_train(targs, 0, 1, dev)
-                line["train_step"] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "images_per_s", "dtype", "steps", "warmup", "peak_mem_gib")}
-                line["train_step"]["workload"] = t["config"]["workload"]
-                line["train_step"]["roofline"] = {k: t["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac")}
-            except Exception as e:
-                line["train_step"] = {"value": None, "error": repr(e)}
+            # second part of BASELINE.json's metric ("...; E2E-FT step time"): configs[2], batch 32 at 576x576, one GPU - in the reference
+            # recipe's precision (`--mixed_precision no`, training/scripts/train_marigold_e2e_ft_depth.sh:15) AND with bf16 compute over
+            # fp32 master weights
+            del pipe, out, rgb, img
+            for key, tdt, tsteps in (("train_step", "bf16", 3), ("train_step_fp32", "fp32", 3)):
+                try:
+                    torch.cuda.empty_cache()
+                    torch.cuda.reset_peak_memory_stats()
+                    _mark(timeline, "%s leg start" % key)
+                    targs = argparse.Namespace(**vars(args))
+                    targs.dtype, targs.res, targs.steps, targs.warmup, targs.detail, targs.micro_batch, targs.accum = tdt, 576, tsteps, 1, None, None, None
+                    t = run_train(targs, 0, 1, dev)
+                    line[key] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "images_per_s", "dtype", "steps", "warmup", "peak_mem_gib")}
+                    line[key]["workload"] = t["config"]["workload"]
+                    line[key]["roofline"] = {k: t["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac")}
+                except Exception as e:
+                    line[key] = {"value": None, "error": repr(e)}
+            _mark(timeline, "train legs end")
+        line["timeline"] = timeline
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

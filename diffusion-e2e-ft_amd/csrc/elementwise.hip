@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void depth_head_kernel(long pixels, int ldx, i
         const TI* s = x + it * ldx;
         // torch: stacked.mean(dim=1) computed in the tensor dtype; we average the three values in fp32
         float v = (to_f(s[0]) + to_f(s[1]) + to_f(s[2])) / 3.0f;
-        v = fminf(fmaxf(v, -1.f), 1.f);
-        if (to_unit) v = (v + 1.0f) * 0.5f;
+        if (to_unit != 2) v = fminf(fmaxf(v, -1.f), 1.f);     // 2: the bare channel mean `decode_depth` returns (marigold_pipeline.py:517-519)
+        if (to_unit == 1) v = (v + 1.0f) * 0.5f;
         y[it] = from_f<TO>(v);
     }
 }

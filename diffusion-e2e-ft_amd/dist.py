@@ -1,6 +1,7 @@
 """One-process-per-GPU helpers.  Inference shards images across ranks with NO data-path collective;
 the E2E-FT training step exchanges UNet gradients once per optimizer step (the reference does this through
-accelerate/DDP: training/train.py:369,563; training/scripts/multi_gpu.yaml:1-15).  Backend "nccl" is RCCL on ROCm;
+accelerate/DDP: training/train.py:369,563; training/scripts/multi_gpu.yaml:1-15) — that exchange lives in training.FlatAdamW (slices of
+one flat gradient buffer, all-reduced from autograd hooks), the only gradient exchange in the product.  Backend "nccl" is RCCL on ROCm;
 the same code runs on gloo for the CPU tests."""
 import os
 
@@ -53,37 +54,3 @@ def sum_over_ranks(value, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
-
-
-@torch.no_grad()
-def allreduce_grads_(params, bucket_bytes=256 << 20, average=True):
-    """Bucketed gradient all-reduce (mean) over all ranks: flat fp32/bf16 buckets of ~bucket_bytes, one collective each.
-    xGMI is point-to-point (7 links x ~153 GB/s): few, large buckets keep every link busy (3.46 GB of
-    fp32 UNet gradients per optimizer step); buckets are launched asynchronously and waited on together."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return 0
-    world = dist.get_world_size()
-    grads = [p.grad for p in params if p.grad is not None]
-    buckets, cur, cur_bytes = [], [], 0
-    for g in grads:
-        nb = g.numel() * g.element_size()
-        if cur and (cur_bytes + nb > bucket_bytes or g.dtype != cur[0].dtype):
-            buckets.append(cur)
-            cur, cur_bytes = [], 0
-        cur.append(g)
-        cur_bytes += nb
-    if cur:
-        buckets.append(cur)
-    works = []
-    for b in buckets:
-        flat = torch.cat([g.reshape(-1) for g in b])
-        works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, b))
-    for w, flat, b in works:
-        w.wait()
-        if average:
-            flat.div_(world)
-        off = 0
-        for g in b:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
-    return len(buckets)

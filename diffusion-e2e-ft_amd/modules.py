@@ -31,6 +31,18 @@ def conv_nhwc(conv, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.
     return F.conv(conv, x, x2=x2, up_to=up_to, rowadd=rowadd, residual=residual, alpha=alpha, pad=pad, gn_stats=gn_stats)
 
 
+def checkpointed(enabled, fn, *args):
+    """Activation recompute of one block (the reference: `torch.utils.checkpoint.checkpoint(create_custom_forward(resnet), ...)` inside
+    every UNet block when `unet.enable_gradient_checkpointing()` was called, unet_2d_blocks.py:1136-1161, training/train.py:342-343).
+    Non-reentrant torch checkpointing over the libe2eft autograd Functions: nothing the block saved for its backward is kept, the block's
+    forward kernels run again when its backward is reached; the recompute is deterministic, so gradients are bit-equal.  GroupNorm
+    statistics ride on the tensors as attributes and survive (the block's input / output objects are the same ones)."""
+    if enabled and torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in args):
+        from torch.utils.checkpoint import checkpoint
+        return checkpoint(fn, *args, use_reentrant=False)
+    return fn(*args)
+
+
 def to_nhwc(x):
     """Logical NCHW tensor -> NHWC [B,H,W,C] (zero-copy when x is channels_last with a 16-byte-multiple C)."""
     assert x.dim() == 4

@@ -516,12 +516,14 @@ def activation(x, kind):
 
 
 def depth_head(x, to_unit, dtype=None):
-    """decoder output NHWC [B,H,W,>=3 (view)] -> [B,1,H,W] = clip(mean_c, -1, 1) (optionally mapped to [0,1])"""
+    """decoder output NHWC [B,H,W,>=3 (view)] -> [B,1,H,W]: to_unit False clip(mean_c, -1, 1); True the same mapped to [0,1];
+    "mean" the bare channel mean (no clip)"""
     _check_cuda(x)
     B, H, W, _ = x.shape
     dtype = dtype or x.dtype
     y = torch.empty((B, 1, H, W), dtype=dtype, device=x.device)
-    check(_lib.load().e2eft_depth_head(dtype_id(x.dtype), dtype_id(dtype), B * H * W, _nhwc_ld(x), 1 if to_unit else 0, _ptr(x), _ptr(y), _stream()))
+    mode = 2 if to_unit == "mean" else (1 if to_unit else 0)
+    check(_lib.load().e2eft_depth_head(dtype_id(x.dtype), dtype_id(dtype), B * H * W, _nhwc_ld(x), mode, _ptr(x), _ptr(y), _stream()))
     return y
 
 

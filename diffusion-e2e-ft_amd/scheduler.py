@@ -76,6 +76,23 @@ class DDIMScheduler:
         ac = self.alphas_cumprod[int(t)]
         return float(ac ** 0.5), float((1 - ac) ** 0.5)
 
+    def zero_latent_x0_scale(self, t):
+        """c with x0 = c * model_output when x_t = 0 (the E2E-FT recipe, training/train.py:480-518): the scheduler's own
+        `prediction_type` decides — v_prediction -sqrt(1 - abar_t), epsilon -sqrt(1 - abar_t) / sqrt(abar_t), sample 1 — as in step().
+        clip_sample / thresholding configurations are refused rather than silently ignored by the fused single-step paths."""
+        if self.config.clip_sample or self.config.thresholding:
+            raise NotImplementedError("the fused single-step path does not clip / threshold x0 (scheduler config clip_sample=%s, thresholding=%s)"
+                                      % (self.config.clip_sample, self.config.thresholding))
+        sa, sb = self.x0_coefficients(t)
+        pt = self.config.prediction_type
+        if pt == "v_prediction":
+            return -sb
+        if pt == "epsilon":
+            return -sb / sa
+        if pt == "sample":
+            return 1.0
+        raise ValueError("Unknown prediction type %s" % pt)
+
     def step(self, model_output, timestep, sample, eta=0.0, **kw):
         """DDIM step for epsilon / sample / v_prediction with eta = 0 (elementwise torch ops on tiny latents; the
         pipelines' fused path uses ops.copy_scale instead)."""
@@ -96,5 +113,7 @@ class DDIMScheduler:
             eps = a_t ** 0.5 * model_output + b_t ** 0.5 * sample
         else:
             raise ValueError(pt)
+        if self.config.clip_sample or self.config.thresholding:
+            raise NotImplementedError("clip_sample / thresholding are not implemented (SD-v2 / Marigold / GeoWizard schedulers set neither)")
         prev = a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
         return SchedulerOutput(prev, x0)

@@ -10,9 +10,9 @@
   replace_unet_conv_in — training/util/unet_prep.py:6-20
 
 The reference wraps the UNet in DDP via accelerate; here one process per GPU (torchrun) calls FlatAdamW.step(), which waits for
-the outstanding all-reduces.  xGMI is point-to-point, so few large collectives (default 4 slices of the 3.46 GB gradient)
-keep all seven links busy; the first slice to finish its backward (the up blocks) starts its exchange while the down blocks
-are still computing.
+the outstanding all-reduces.  xGMI is point-to-point, so few large collectives (default 4 byte-sized slices of the 3.46 GB
+gradient, the last-finishing one the smallest) keep all seven links busy; the first slice to finish its backward (the up blocks)
+starts its exchange while the down blocks are still computing.
 """
 import math
 
@@ -63,7 +63,7 @@ def encode_image(vae, image):
     return latent
 
 
-def e2e_ft_loss(unet, vae, batch, empty_encoding, modality="depth", alpha_prod_999=None, return_estimate=False):
+def e2e_ft_loss(unet, vae, batch, empty_encoding, modality="depth", noise_scheduler=None, return_estimate=False):
     """Forward half of one micro-step (train.py:472-556) with the zeros latent at t = 999 (the E2E-FT recipe).
     batch: rgb [b,3,H,W] in [-1,1], val_mask [b,1,H,W] bool, metric [b,1,H,W] / normals [b,3,H,W].  Returns the scalar loss
     (device tensor with a grad_fn through the decoder and the UNet).  `unet` may be wrapped (DistributedDataParallel by
@@ -80,11 +80,11 @@ def e2e_ft_loss(unet, vae, batch, empty_encoding, modality="depth", alpha_prod_9
     ctx = empty_encoding.to(device=dev, dtype=dt).repeat(b, 1, 1)
     unet_input = torch.cat((rgb_latents, noisy), dim=1).contiguous(memory_format=torch.channels_last)
     model_pred = unet(unet_input, timesteps, ctx, return_dict=False)[0]
-    if alpha_prod_999 is None:
+    if noise_scheduler is None:
         from .scheduler import DDIMScheduler
-        alpha_prod_999 = float(DDIMScheduler().alphas_cumprod[999])
-    # v-prediction with x_t = 0: x0 = -sqrt(1 - alpha_prod) * v   (train.py:509-512), then / scaling_factor (:528)
-    x0 = model_pred * (-math.sqrt(1.0 - alpha_prod_999) / vae.config.scaling_factor)
+        noise_scheduler = DDIMScheduler()
+    # x_t = 0: x0 = c * model_pred with c by the scheduler's prediction_type (v: -sqrt(1 - alpha_prod), train.py:509-518), then / scaling_factor (:528)
+    x0 = model_pred * (noise_scheduler.zero_latent_x0_scale(999) / vae.config.scaling_factor)
     est = vae.decoder(vae.post_quant_conv(x0))                     # [b,3,H,W] logical NCHW, NHWC memory
     est_nhwc = est.permute(0, 2, 3, 1)
     if modality == "depth":
@@ -125,8 +125,7 @@ def geowizard_e2e_ft_loss(unet, vae, batch, imgs_embed, domain="indoor", depth_s
     unet_input = torch.cat((rgb_latents.repeat(2, 1, 1, 1), noisy), dim=1).contiguous(memory_format=torch.channels_last)
     noise_pred = unet(unet_input, timesteps, ctx, class_labels=cls, return_dict=False)[0]
     from .scheduler import DDIMScheduler
-    a999 = float(DDIMScheduler().alphas_cumprod[999])
-    x0 = noise_pred * (-math.sqrt(1.0 - a999) / vae.config.scaling_factor)
+    x0 = noise_pred * (DDIMScheduler().zero_latent_x0_scale(999) / vae.config.scaling_factor)
     est = vae.decoder(vae.post_quant_conv(x0)).permute(0, 2, 3, 1)          # NHWC view [2b,H,W,3]
     depth = F.depth_head(est[:b], to_unit=False)
     normal = F.normal_head(est[b:], clamp=True)
@@ -173,14 +172,26 @@ class FlatAdamW:
         self.step_count = 0
         self.group = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        # slices of the flat buffer in BACKWARD order: the last parameters (up blocks, conv_out) get their gradients first
+        # Slices of the flat buffer, cut by BYTES.  Parameters are stored in module order (conv_in, down, mid, up, conv_out) and the
+        # backward produces gradients roughly in reverse, so the slice holding the FIRST parameters completes last and its exchange is
+        # the one that cannot hide under the backward: slice sizes grow geometrically (1 : 2 : 4 : ...), the exposed one is the smallest
+        # (n_slices = 4 on the 3.46 GB SD-v2 gradient: 0.23 / 0.46 / 0.92 / 1.85 GB).  Large messages keep all seven xGMI links busy.
         n_slices = max(1, min(n_slices, len(self.params)))
-        per = (len(self.params) + n_slices - 1) // n_slices
+        total_w = float(2 ** n_slices - 1)
+        targets, acc_w = [], 0.0
+        for s_ in range(n_slices - 1):
+            acc_w += 2 ** s_
+            targets.append(n * acc_w / total_w)
+        cuts, ti = [0], 0
+        for i in range(1, len(self.params)):
+            if ti < len(targets) and self.offsets[i] >= targets[ti] and i > cuts[-1]:
+                cuts.append(i)
+                ti += 1
+                while ti < len(targets) and self.offsets[i] >= targets[ti]:
+                    ti += 1
+        cuts.append(len(self.params))
         self.slices = []
-        for s in range(n_slices):
-            lo, hi = s * per, min(len(self.params), (s + 1) * per)
-            if lo >= hi:
-                continue
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
             start = self.offsets[lo]
             end = self.offsets[hi] if hi < len(self.params) else n
             self.slices.append(dict(lo=lo, hi=hi, start=start, end=end, ready=0, work=None))

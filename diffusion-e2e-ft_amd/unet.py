@@ -16,7 +16,7 @@ from torch import nn
 from . import ops
 from . import autograd as F
 from .modules import (Conv2d, GroupNorm, ResnetBlock2D, Transformer2DModel, Downsample2D, Upsample2D, TimestepEmbedding,
-                      conv_nhwc, to_nhwc, to_nchw_view)
+                      checkpointed, conv_nhwc, to_nhwc, to_nchw_view)
 
 
 class Config(OrderedDict):
@@ -62,13 +62,15 @@ class _DownBlock(nn.Module):
         if add_down:
             self.downsamplers = nn.ModuleList([Downsample2D(out_c, padding=1)])
         self.add_down = add_down
+        self.gradient_checkpointing = False
 
     def nhwc(self, h, temb_act, ctx):
         outs = []
+        ck = self.gradient_checkpointing and self.training
         for j, res in enumerate(self.resnets):
-            h = res.nhwc(h, temb_act)
+            h = checkpointed(ck, res.nhwc, h, temb_act)
             if self.has_cross_attention:
-                h = self.attentions[j].nhwc(h, ctx)
+                h = checkpointed(ck, self.attentions[j].nhwc, h, ctx)
             outs.append(h)
         if self.add_down:
             h = self.downsamplers[0].nhwc(h)
@@ -83,11 +85,13 @@ class _MidBlock(nn.Module):
         super().__init__()
         self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb, groups, eps), ResnetBlock2D(c, c, temb, groups, eps)])
         self.attentions = nn.ModuleList([Transformer2DModel(c, heads, xdim, groups, joint)])
+        self.gradient_checkpointing = False
 
     def nhwc(self, h, temb_act, ctx):
-        h = self.resnets[0].nhwc(h, temb_act)
-        h = self.attentions[0].nhwc(h, ctx)
-        return self.resnets[1].nhwc(h, temb_act)
+        ck = self.gradient_checkpointing and self.training
+        h = checkpointed(ck, self.resnets[0].nhwc, h, temb_act)
+        h = checkpointed(ck, self.attentions[0].nhwc, h, ctx)
+        return checkpointed(ck, self.resnets[1].nhwc, h, temb_act)
 
 
 class _UpBlock(nn.Module):
@@ -108,12 +112,14 @@ class _UpBlock(nn.Module):
         if add_up:
             self.upsamplers = nn.ModuleList([Upsample2D(out_c)])
         self.add_up = add_up
+        self.gradient_checkpointing = False
 
     def nhwc(self, h, skips, temb_act, ctx, upsample_size=None):
+        ck = self.gradient_checkpointing and self.training
         for j, res in enumerate(self.resnets):
-            h = res.nhwc(h, temb_act, x2=skips.pop())
+            h = checkpointed(ck, res.nhwc, h, temb_act, skips.pop())
             if self.has_cross_attention:
-                h = self.attentions[j].nhwc(h, ctx)
+                h = checkpointed(ck, self.attentions[j].nhwc, h, ctx)
         if self.add_up:
             h = self.upsamplers[0].nhwc(h, size=upsample_size)
         return h
@@ -127,6 +133,39 @@ def _weights_file(d, name, variant=None):
         if os.path.exists(cand):
             return cand
     return os.path.join(d, name)
+
+
+# diffusers UNet2DConditionModel config keys this implementation does not carry, with the only value it implements.  A checkpoint
+# whose config.json says otherwise would load into the wrong architecture: refuse it (unknown keys with a None / False / default
+# value are ignored, as diffusers ignores keys it does not know).
+IMPLEMENTED_ONLY = dict(center_input_sample=False, mid_block_type="UNetMidBlock2DCrossAttn", only_cross_attention=False, downsample_padding=1,
+                        mid_block_scale_factor=1, dropout=0.0, act_fn="silu", transformer_layers_per_block=1, encoder_hid_dim=None,
+                        encoder_hid_dim_type=None, num_attention_heads=None, dual_cross_attention=False, addition_embed_type=None,
+                        addition_time_embed_dim=None, num_class_embeds=None, resnet_time_scale_shift="default",
+                        resnet_skip_time_act=False, resnet_out_scale_factor=1.0, time_embedding_type="positional", time_embedding_dim=None,
+                        time_embedding_act_fn=None, timestep_post_act=None, time_cond_proj_dim=None, conv_in_kernel=3, conv_out_kernel=3,
+                        attention_type="default", class_embeddings_concat=False, mid_block_only_cross_attention=None,
+                        cross_attention_norm=None, reverse_transformer_layers_per_block=None)
+
+
+def check_unsupported_config(raw):
+    # (`upcast_attention` is accepted either way: softmax statistics and accumulation are fp32 in every attention kernel here)
+    bad = {k: v for k, v in raw.items() if k in IMPLEMENTED_ONLY and v != IMPLEMENTED_ONLY[k]}
+    if bad:
+        raise NotImplementedError("UNet config.json asks for features this implementation does not have (SD-v2 / Marigold / GeoWizard "
+                                  "configurations only): %s" % bad)
+
+
+def load_weights(d, weights_name, variant=None):
+    """diffusion_pytorch_model[.<variant>].safetensors, else the pickled .bin twin diffusers falls back to"""
+    f = _weights_file(d, weights_name, variant)
+    if os.path.exists(f):
+        from safetensors.torch import load_file
+        return load_file(f)
+    b = _weights_file(d, weights_name.replace(".safetensors", ".bin"), variant)
+    if os.path.exists(b):
+        return torch.load(b, map_location="cpu", weights_only=True)
+    raise FileNotFoundError("no %s (or .bin) under %s" % (weights_name, d))
 
 
 class UNet2DConditionModel(nn.Module):
@@ -192,8 +231,19 @@ class UNet2DConditionModel(nn.Module):
         self._compute_dtype = dtype
         return self
 
-    def enable_gradient_checkpointing(self):  # training/train.py:343
-        self.gradient_checkpointing = True
+    def enable_gradient_checkpointing(self):  # training/train.py:342-343 (--gradient_checkpointing in every training script)
+        """per-block activation recompute in training mode, as diffusers' `_set_gradient_checkpointing` flips it on every block
+        (unet_2d_condition.py `_supports_gradient_checkpointing`, unet_2d_blocks.py:1136-1161); see modules.checkpointed"""
+        self._set_gradient_checkpointing(True)
+
+    def disable_gradient_checkpointing(self):
+        self._set_gradient_checkpointing(False)
+
+    def _set_gradient_checkpointing(self, value):
+        self.gradient_checkpointing = value
+        for m in self.modules():
+            if isinstance(m, (_DownBlock, _MidBlock, _UpBlock)):
+                m.gradient_checkpointing = value
 
     def enable_xformers_memory_efficient_attention(self, *a, **k):  # train.py:317, run.py:284-289: fused attention is always on
         return None
@@ -215,9 +265,10 @@ class UNet2DConditionModel(nn.Module):
         from safetensors.torch import load_file
         d = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(d, cls.config_name)) as f:
-            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_") and k in SD2_UNET_CONFIG}
-        m = cls(**cfg)
-        m.load_state_dict(load_file(_weights_file(d, cls.weights_name, variant)))
+            raw = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        check_unsupported_config(raw)
+        m = cls(**{k: v for k, v in raw.items() if k in SD2_UNET_CONFIG})
+        m.load_state_dict(load_weights(d, cls.weights_name, variant))
         return m.to(torch_dtype) if torch_dtype is not None else m
 
     # ---- forward ----

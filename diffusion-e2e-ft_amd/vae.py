@@ -9,7 +9,7 @@ import os
 import torch
 from torch import nn
 
-from .modules import (Conv2d, GroupNorm, ResnetBlock2D, Downsample2D, Upsample2D, VaeAttention, conv_nhwc, to_nhwc, to_nchw_view)
+from .modules import (Conv2d, GroupNorm, ResnetBlock2D, Downsample2D, Upsample2D, VaeAttention, checkpointed, conv_nhwc, to_nhwc, to_nchw_view)
 from .unet import Config
 
 SD_VAE_CONFIG = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
@@ -49,10 +49,11 @@ class _DecBlock(nn.Module):
         if add_up:
             self.upsamplers = nn.ModuleList([Upsample2D(out_c)])
         self.add_up = add_up
+        self.gradient_checkpointing = False
 
     def nhwc(self, h):
         for r in self.resnets:
-            h = r.nhwc(h)
+            h = checkpointed(self.gradient_checkpointing, r.nhwc, h)
         return self.upsamplers[0].nhwc(h) if self.add_up else h
 
 
@@ -132,6 +133,17 @@ class AutoencoderKL(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
+    def enable_gradient_checkpointing(self):
+        """recompute the decoder's ResNet blocks in the backward (diffusers' AutoencoderKL supports the switch; the reference's training
+        never flips it, train.py:304 only freezes the VAE): the frozen decoder still has to keep every activation for its input
+        gradient — 3-5 GB per 576x576 image in fp32 — and this drops them"""
+        for m in self.decoder.up_blocks:
+            m.gradient_checkpointing = True
+
+    def disable_gradient_checkpointing(self):
+        for m in self.decoder.up_blocks:
+            m.gradient_checkpointing = False
+
     def save_pretrained(self, save_directory, **kw):
         from safetensors.torch import save_file
         os.makedirs(save_directory, exist_ok=True)
@@ -148,8 +160,8 @@ class AutoencoderKL(nn.Module):
         with open(os.path.join(d, cls.config_name)) as f:
             cfg = {k: v for k, v in json.load(f).items() if k in SD_VAE_CONFIG}
         m = cls(**cfg)
-        from .unet import _weights_file
-        sd = load_file(_weights_file(d, cls.weights_name, variant))
+        from .unet import load_weights
+        sd = load_weights(d, cls.weights_name, variant)
         # older checkpoints name the mid-block attention projections query/key/value/proj_attn
         ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
         for k in list(sd):

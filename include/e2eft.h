@@ -218,8 +218,9 @@ int e2eft_silu(int32_t dtype, int64_t n, const void* x, void* y, void* stream);
  * image encoder on GeoWizard's per-image path (/root/reference/GeoWizard/geowizard/models/geowizard_pipeline.py:232-248, module
  * transformers CLIPVisionModelWithProjection); 1: gelu (erf); 2: silu. */
 int e2eft_activation(int32_t dtype, int32_t kind, int64_t n, const void* x, void* y, void* stream);
-/* Depth head: decoder output NHWC [pixels, ldx>=3] -> depth[pixels] = clip(mean_c(x), -1, 1) (* 0.5 + 0.5 when
- * to_unit != 0)  (marigold_pipeline.py:518,476-477; train.py:533-534).  Output fp32 or dtype (dt_out). */
+/* Depth head: decoder output NHWC [pixels, ldx>=3] -> depth[pixels].  to_unit 0: clip(mean_c(x), -1, 1) (train.py:533-534);
+ * 1: the same mapped to [0, 1] by * 0.5 + 0.5 (marigold_pipeline.py:518,476-477); 2: the bare channel mean that
+ * `decode_depth` returns (marigold_pipeline.py:517-519).  Output fp32 or dtype (dt_out). */
 int e2eft_depth_head(int32_t dt_in, int32_t dt_out, int64_t pixels, int32_t ldx, int32_t to_unit, const void* x,
                      void* y, void* stream);
 /* Normal head: NHWC [B*hw, ldx>=3] -> NCHW [B,3,hw]: n / (||n||_2 + 1e-5), optional clamp to [-1,1] and sign

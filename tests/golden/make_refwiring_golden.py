@@ -72,6 +72,35 @@ def marigold_cases(ref):
     return out
 
 
+def call_input():
+    """uint8 image [3, 96, 144] with smooth structure + noise (a PIL image converts to exactly this, marigold_pipeline.py:222-227)"""
+    g = torch.Generator().manual_seed(17)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, 96), torch.linspace(0, 1, 144), indexing="ij")
+    base = torch.stack([0.5 + 0.4 * torch.sin(5 * xx + 2 * yy), 0.3 + 0.6 * yy, 0.5 + 0.3 * torch.cos(7 * xx * yy)])
+    return ((base + 0.08 * torch.randn(3, 96, 144, generator=g)).clamp(0, 1) * 255).round().to(torch.uint8)
+
+
+def marigold_call_cases(ref):
+    """MarigoldPipeline.__call__ (marigold_pipeline.py:158-353) from source: resize_max_res to 96 -> 64x96, normalise, one pass, min-max,
+    resize back to 96x144, colourise"""
+    import numpy as np
+    out = {}
+    unet, vae = build_models(ref)
+    _, ctx = synth.synth_inputs(1, 64, 96, 2, 128, seed=3)
+    for name, normals in (("depth", False), ("normals", True)):
+        log = []
+        pipe = ref.MarigoldPipeline(Spy(unet, "unet", log), Spy(vae, "vae", log), scheduler(ref), None, None)
+        pipe.empty_text_embed = ctx
+        res = pipe(call_input(), denoising_steps=1, ensemble_size=1, processing_res=96, match_input_res=True, resample_method="bilinear",
+                   batch_size=0, color_map="Spectral", show_progress_bar=False, noise="zeros", normals=normals)
+        arr = res.normal_np if normals else res.depth_np
+        col = res.normal_colored if normals else res.depth_colored
+        out[name] = {"np": torch.from_numpy(np.ascontiguousarray(arr)), "colored": torch.from_numpy(np.asarray(col).copy()),
+                     "net_input": log[0]["args"]["__seq__"][0]["__tensor__"].clone()}
+        print("marigold __call__", name, tuple(arr.shape), "colored", tuple(np.asarray(col).shape))
+    return out
+
+
 def geowizard_case(ref):
     unet, vae = build_models(ref, geo=True)
     rgb, emb = gc.geo_pipe_inputs()
@@ -168,7 +197,7 @@ def main():
     torch.manual_seed(0)
     with refimport.reference_modules() as ref:
         out = {"meta": {"stub_diffusers": ref.uses_stub_diffusers, "torch": torch.__version__},
-               "model": model_cases(ref), "marigold": marigold_cases(ref), "geowizard": geowizard_case(ref), "train": train_cases(ref)}
+               "model": model_cases(ref), "marigold": marigold_cases(ref), "marigold_call": marigold_call_cases(ref), "geowizard": geowizard_case(ref), "train": train_cases(ref)}
     path = os.path.join(HERE, "refwiring_golden.pt")
     torch.save(out, path)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -23,6 +23,17 @@ class BaseOutput(OrderedDict):
             return dict(self.items())[k]
         return self.to_tuple()[k]
 
+    def __setitem__(self, key, value):
+        # keys are mirrored as attributes, so that subclasses that are NOT dataclasses (the reference's MarigoldDepthOutput) still
+        # give `out.depth_np` after `MarigoldDepthOutput(depth_np=...)` — as diffusers.utils.outputs.BaseOutput does
+        super().__setitem__(key, value)
+        super().__setattr__(key, value)
+
+    def __setattr__(self, name, value):
+        if name in self.keys() and value is not None:
+            super().__setitem__(name, value)
+        super().__setattr__(name, value)
+
     def to_tuple(self):
         return tuple(self[k] for k in self.keys())
 

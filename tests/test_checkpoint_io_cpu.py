@@ -91,3 +91,31 @@ def test_scheduler_config_tolerates_unknown_keys(tmp_path):
     assert s.config.timestep_spacing == "trailing" and s.config.prediction_type == "v_prediction"
     s.set_timesteps(1)
     assert s.timesteps_host == [999]
+
+
+def test_unet_config_json_is_validated_and_bin_files_load(tmp_path):
+    """a config.json of the SD-v2 family (every diffusers key present, at its default) loads; one that asks for an unimplemented feature is
+    refused instead of loading into the wrong architecture; diffusion_pytorch_model.bin is read when no .safetensors exists"""
+    import pytest
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    unet = UNet2DConditionModel(**config.TINY_UNET)
+    unet.load_state_dict(gc.tiny_unet_sd())
+    d = str(tmp_path / "u")
+    unet.save_pretrained(d)
+    cfg = json.load(open(os.path.join(d, "config.json")))
+    full = dict(cfg, act_fn="silu", center_input_sample=False, downsample_padding=1, dual_cross_attention=False, mid_block_scale_factor=1,
+                only_cross_attention=False, upcast_attention=True, resnet_time_scale_shift="default", time_embedding_type="positional",
+                num_class_embeds=None, _diffusers_version="0.30.2", mid_block_type="UNetMidBlock2DCrossAttn", dropout=0.0, conv_in_kernel=3)
+    json.dump(full, open(os.path.join(d, "config.json"), "w"))
+    os.rename(os.path.join(d, "diffusion_pytorch_model.safetensors"), os.path.join(d, "keep.safetensors"))
+    torch.save({k: v.clone() for k, v in unet.state_dict().items()}, os.path.join(d, "diffusion_pytorch_model.bin"))
+    back = UNet2DConditionModel.from_pretrained(d)
+    assert _same(back.state_dict(), unet.state_dict())
+    for key, val in (("act_fn", "gelu"), ("resnet_time_scale_shift", "scale_shift"), ("dual_cross_attention", True), ("time_embedding_type", "fourier")):
+        json.dump(dict(full, **{key: val}), open(os.path.join(d, "config.json"), "w"))
+        with pytest.raises(NotImplementedError):
+            UNet2DConditionModel.from_pretrained(d)
+    os.remove(os.path.join(d, "diffusion_pytorch_model.bin"))
+    json.dump(full, open(os.path.join(d, "config.json"), "w"))
+    with pytest.raises(FileNotFoundError):
+        UNet2DConditionModel.from_pretrained(d)

@@ -89,6 +89,15 @@ def test_scheduler_matches_oracle_constants():
     s.set_timesteps(1)
     v, x = torch.randn(1, 4, 3, 3), torch.randn(1, 4, 3, 3)
     assert torch.allclose(s.step(v, 999, x).pred_original_sample, pipeline_ref.v_to_x0(v, x, 999), atol=1e-6)
+    # the fused single-step paths take x0 = c * model_output at x_t = 0 from the scheduler's prediction_type, like step() (train.py:511-518)
+    for pt in ("v_prediction", "epsilon", "sample"):
+        sp = DDIMScheduler(prediction_type=pt)
+        sp.set_timesteps(1)
+        want = sp.step(v, 999, torch.zeros_like(v)).pred_original_sample
+        assert torch.allclose(sp.zero_latent_x0_scale(999) * v, want, rtol=1e-5, atol=1e-6), pt
+    import pytest
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler(clip_sample=True).zero_latent_x0_scale(999)
     lead = DDIMScheduler(timestep_spacing="leading")
     lead.set_timesteps(1)
     assert lead.timesteps.tolist() == [1]  # why the reference forces trailing (Marigold/run.py:157-162)
@@ -128,3 +137,28 @@ def test_training_host_mirrors_match_reference_fixtures():
     assert u.config["in_channels"] == int(hooks["conv_in_cfg"])
     for dom in ("indoor", "outdoor", "object"):
         assert torch.equal(training.geowizard_class_embedding(3, dom, torch.float32, "cpu"), pipeline_ref.geowizard_class_embedding(3, dom))
+
+
+REF_NOISE = "/root/reference/training/util/noise.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_NOISE), reason="reference tree not present")
+def test_pyramid_noise_like_draws_the_reference_sequence():
+    """a13: multi-resolution noise (training/util/noise.py:8-18, marigold_pipeline.py:76-86) — same RNG draws in the same order as the
+    reference's function imported from its file (the noise type is non-default; E2E-FT uses zeros)"""
+    import importlib.util
+    import random
+    from diffusion_e2e_ft_amd.pipeline import pyramid_noise_like
+    spec = importlib.util.spec_from_file_location("ref_noise", REF_NOISE)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    for shape in ((2, 4, 12, 16), (1, 4, 9, 7), (3, 4, 32, 32)):
+        x = torch.zeros(shape)
+        torch.manual_seed(5)
+        random.seed(5)
+        want = ref.pyramid_noise_like(x)
+        torch.manual_seed(5)
+        random.seed(5)
+        got = pyramid_noise_like(x)
+        assert got.shape == want.shape and torch.allclose(got, want, rtol=1e-6, atol=1e-6), shape
+        assert abs(got.std().item() - 1.0) < 1e-5

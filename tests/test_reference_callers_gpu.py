@@ -210,3 +210,49 @@ def test_ddp_wrap_gives_identical_gradients(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("normals", [False, True])
+def test_call_equals_reference_call_from_source(dev, normals):
+    """`MarigoldPipeline.__call__` (marigold_pipeline.py:158-353) value for value: resize_max_res (uint8 in, rounded like torchvision),
+    normalisation, one pass, min-max / re-normalisation, resize back, clip, colourised image — against the reference's `__call__` run
+    from source (tests/golden/make_refwiring_golden.py::marigold_call_cases)"""
+    import numpy as np
+    from diffusion_e2e_ft_amd.pipeline import MarigoldPipeline, resize_max_res
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    from oracle import synth
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_refwiring_golden import call_input
+    fx = FX["marigold_call"]["normals" if normals else "depth"]
+    unet, vae = _models(dev)
+    _, ctx = synth.synth_inputs(1, 64, 96, 2, 128, seed=3)
+    pipe = MarigoldPipeline(unet, vae, DDIMScheduler())
+    pipe.empty_text_embed = ctx.to(dev)
+    img = call_input()
+    # what reaches the network: the reference's resized + normalised image (first vae.encoder call of its trace)
+    mine = resize_max_res(img, 96, "bilinear")
+    assert mine.dtype == torch.uint8 and tuple(mine.shape) == (3, 64, 96)
+    net_in = mine / 255.0 * 2.0 - 1.0
+    assert (net_in - fx["net_input"][0]).abs().max().item() <= 2.0 / 255.0 + 1e-6          # at most one uint8 rounding step apart
+    assert ((net_in - fx["net_input"][0]).abs() > 1e-6).float().mean().item() < 0.01
+    res = pipe(img, denoising_steps=1, ensemble_size=1, processing_res=96, match_input_res=True, resample_method="bilinear", batch_size=0,
+               color_map="Spectral", show_progress_bar=False, noise="zeros", normals=normals)
+    arr = res.normal_np if normals else res.depth_np
+    col = np.asarray(res.normal_colored if normals else res.depth_colored)
+    want, want_col = fx["np"].numpy(), fx["colored"].numpy()
+    assert arr.shape == want.shape and arr.dtype == want.dtype and col.shape == want_col.shape and col.dtype == np.uint8
+    assert (res.depth_np is None) == normals and (res.normal_colored is None) == (not normals) and res.uncertainty is None
+    err = np.abs(arr - want)
+    print("__call__ %s: max abs err %.2e mean %.2e" % ("normals" if normals else "depth", err.max(), err.mean()))
+    assert err.max() <= (2e-2 if normals else 5e-3) and err.mean() <= 1e-3       # a rounding step of the uint8 input moves the output slightly
+    assert (np.abs(col.astype(np.int32) - want_col.astype(np.int32)) > 2).mean() < 0.01
+
+
+def test_find_batch_size_rule(dev):
+    """util/batchsize.py:59-81: never more than the ensemble, a batch between half and all of it is cut to half"""
+    from diffusion_e2e_ft_amd.pipeline import find_batch_size
+    assert find_batch_size(1, 768, torch.float16) == 1 and find_batch_size(10, 768, torch.float16) == 10
+    assert find_batch_size(100, 768, torch.float16) == 64 == find_batch_size(128, 768, torch.float16)
+    assert find_batch_size(70, 768, torch.float16) == 35            # 64 > ceil(70 / 2): two balanced passes
+    assert find_batch_size(10, 2048, torch.float32) == 4

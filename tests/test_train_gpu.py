@@ -215,3 +215,54 @@ def test_reference_style_step_with_torch_glue(dev):
     with torch.no_grad():   # the kernels see the updated weights (packed copies are keyed on the parameter version)
         out2 = unet(unet_input, timesteps, encoder_hidden_states, return_dict=False)[0]
     assert not torch.equal(out2, model_pred.detach())
+
+
+@pytest.mark.parametrize("geo", [False, True])
+def test_gradient_checkpointing_gives_bit_equal_gradients_and_saves_memory(dev, geo):
+    """`unet.enable_gradient_checkpointing()` (training/train.py:342-343): per-block activation recompute as in
+    unet_2d_blocks.py:1136-1161 — the loss and every parameter gradient are bit-identical to the run that kept all activations, and the
+    peak memory of the step is lower; `vae.enable_gradient_checkpointing()` does the same for the frozen decoder's ResNet blocks"""
+    from diffusion_e2e_ft_amd import training
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+
+    def run(ckpt):
+        if geo:
+            unet = UNet2DConditionModel(**config.TINY_GEOWIZARD_UNET)
+            unet.load_state_dict(gc.tiny_geo_sd())
+            unet = unet.to(dev).train()
+            _, vae = _models(dev)
+            batch, emb = gc.geo_train_inputs()
+        else:
+            unet, vae = _models(dev)
+            batch, emb = gc.train_batch(B=4, H=128, W=128)
+        if ckpt:
+            unet.enable_gradient_checkpointing()
+            vae.enable_gradient_checkpointing()
+            assert unet.gradient_checkpointing and all(b.gradient_checkpointing for b in unet.down_blocks)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        loss = (training.geowizard_e2e_ft_loss(unet, vae, batch, emb, "indoor") if geo else training.e2e_ft_loss(unet, vae, batch, emb, "depth"))
+        loss.backward()
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - base
+        return loss.item(), {k: p.grad.clone() for k, p in unet.named_parameters()}, peak
+
+    l0, g0, m0 = run(False)
+    l1, g1, m1 = run(True)
+    assert l0 == l1
+    assert all(torch.equal(g0[k], g1[k]) for k in g0), [k for k in g0 if not torch.equal(g0[k], g1[k])][:5]
+    print("peak step memory: %.1f MB kept, %.1f MB with recompute" % (m0 / 2 ** 20, m1 / 2 ** 20))
+    assert m1 < 0.8 * m0, (m0, m1)
+    # eval mode: the switch is inert (the reference checks `self.training and self.gradient_checkpointing`)
+    unet, vae = _models(dev)
+    unet.enable_gradient_checkpointing()
+    unet.eval()
+    x, ctx = gc.unet_inputs((16, 16))
+    with torch.no_grad():
+        a = unet(x.to(dev), torch.tensor(999, device=dev), ctx.to(dev)).sample
+    unet.disable_gradient_checkpointing()
+    with torch.no_grad():
+        b = unet(x.to(dev), torch.tensor(999, device=dev), ctx.to(dev)).sample
+    assert torch.equal(a, b)
