@@ -388,3 +388,211 @@ def pyramid_noise_like(x, discount=0.9):
         if rows == 1 or cols == 1:
             break
     return total / total.std()
+
+
+class DepthNormalEstimationPipeline:
+    """GeoWizard joint depth + normal single-step inference, batched (rows [depth x B ; normal x B]) as in
+    GeoWizard/geowizard/training/train_depth_normal.py:687-704; per-image semantics of geowizard_pipeline.py:252-344.
+    `image_encoder` (clip.CLIPVisionModelWithProjection, geowizard_pipeline.py:76-86) is optional: without it pass `img_embed`
+    [B,1,X] to single_infer directly."""
+
+    def __init__(self, unet, vae, scheduler, image_encoder=None, feature_extractor=None):
+        self.unet, self.vae, self.scheduler = unet, vae, scheduler
+        self.image_encoder, self.feature_extractor = image_encoder, feature_extractor
+        self.img_embed = None                      # geowizard_pipeline.py:86
+        self._m = MarigoldPipeline(unet, vae, scheduler)
+
+    def _clip_constants(self):
+        """(size, mean [3,1,1], std [3,1,1]) of the CLIP preprocessor, resident on the device (no host->device copy per image)"""
+        from .clip import CLIP_IMAGE_MEAN, CLIP_IMAGE_STD
+        fe = self.feature_extractor
+        key = (str(self.device), id(fe))
+        if getattr(self, "_clip_key", None) != key:
+            mean = tuple(fe.image_mean) if fe is not None else CLIP_IMAGE_MEAN
+            std = tuple(fe.image_std) if fe is not None else CLIP_IMAGE_STD
+            size = fe.crop_size["height"] if fe is not None else self.image_encoder.config["image_size"]
+            self._clip_const = (size, torch.tensor(mean, device=self.device, dtype=torch.float32)[:, None, None],
+                                torch.tensor(std, device=self.device, dtype=torch.float32)[:, None, None])
+            self._clip_key = key
+        return self._clip_const
+
+    @torch.no_grad()
+    def encode_img_embed(self, rgb):
+        """geowizard_pipeline.py:232-248 (__encode_img_embed): CLIP image embedding [B,1,X] of rgb in [-1,1]; resize + normalisation
+        constants come from `feature_extractor` when one is given (image_mean / image_std / crop_size), else CLIP's defaults."""
+        from .clip import preprocess_for_clip
+        assert self.image_encoder is not None, "DepthNormalEstimationPipeline was built without an image_encoder: pass img_embed"
+        size, mean, std = self._clip_constants()
+        x = preprocess_for_clip(rgb.to(device=self.device, dtype=self.dtype), size, mean, std)
+        return self.image_encoder(x).image_embeds.unsqueeze(1).to(self.dtype)
+
+    @property
+    def dtype(self):
+        return self.unet.dtype
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    @staticmethod
+    def class_embedding(batch, domain, dtype, device):
+        geo = torch.tensor([[0.0, 1.0], [1.0, 0.0]], dtype=torch.float32).repeat_interleave(batch, 0)
+        dom = {"indoor": [1.0, 0.0, 0.0], "outdoor": [0.0, 1.0, 0.0], "object": [0.0, 0.0, 1.0]}[domain]
+        dom = torch.tensor([dom], dtype=torch.float32).repeat(2 * batch, 1)
+        emb = torch.cat([torch.sin(geo), torch.cos(geo), torch.sin(dom), torch.cos(dom)], dim=-1)  # 10 constants, host
+        return emb.to(device=device, dtype=dtype)
+
+    _graphs = None
+
+    def enable_hip_graphs(self, enabled=True):
+        """Replay single_infer from one captured hipGraph per (batch shape, dtype, domain, embedding source) — see
+        MarigoldPipeline.enable_hip_graphs; at 2 images per step the CLIP tower and the small UNet levels are launch-bound."""
+        self._graphs = {} if enabled else None
+        return self
+
+    def _device_path(self, rgb, img_embed, t_dev, sb, cls):
+        """everything after the host-side setup; only device work on the current stream (capturable)"""
+        if img_embed is None:
+            img_embed = self.encode_img_embed(rgb)
+        B = rgb.shape[0]
+        dt = rgb.dtype
+        rgb_latent = self._m.encode_rgb(rgb)
+        _, C, h, w = rgb_latent.shape
+        xin = torch.zeros((2 * B, h, w, 2 * C), dtype=dt, device=rgb.device)  # geo latent half stays zero
+        ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[:B, ..., :C])
+        ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[B:, ..., :C])
+        ctx = img_embed.to(dt).repeat(2, 1, 1)
+        v = self.unet(to_nchw_view(xin), t_dev.repeat(2 * B), encoder_hidden_states=ctx, class_labels=cls).sample
+        x0 = _scaled(v, -sb)
+        depth = ops.depth_head(self._m._decode(x0[:B]).permute(0, 2, 3, 1), to_unit=True)
+        normal = ops.normal_head(self._m._decode(x0[B:]).permute(0, 2, 3, 1), clamp=False, sign=-1.0)  # :341-342
+        return depth, normal
+
+    @torch.no_grad()
+    def _multi_step(self, rgb, img_embed, cls, num_inference_steps, noise, generator):
+        """geowizard_pipeline.py:266-343 for the pre-E2E-FT checkpoints: DDIM over the joint geometry latent (the SAME initial noise for
+        the depth and the normal row of an image, :271), host launches only."""
+        device, dt = rgb.device, rgb.dtype
+        B = rgb.shape[0]
+        if img_embed is None:
+            img_embed = self.encode_img_embed(rgb)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        rgb_latent = self._m.encode_rgb(rgb)
+        _, C, h, w = rgb_latent.shape
+        if isinstance(noise, torch.Tensor):          # an explicit initial latent [B,4,h,w] (tests, reproducibility across devices)
+            geo = noise.to(device=device, dtype=dt)
+        elif noise == "gaussian":
+            geo = torch.randn((B, C, h, w), device=device, dtype=dt, generator=generator)
+        elif noise == "pyramid":
+            geo = pyramid_noise_like(rgb_latent).to(device=device, dtype=dt)
+        elif noise == "zeros":
+            geo = torch.zeros((B, C, h, w), device=device, dtype=dt)
+        else:
+            raise ValueError("Invalid noise type: %s" % noise)
+        geo = geo.repeat(2, 1, 1, 1)
+        xin = torch.zeros((2 * B, h, w, 2 * C), dtype=dt, device=device)
+        ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[:B, ..., :C])
+        ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[B:, ..., :C])
+        ctx = img_embed.to(dt).repeat(2, 1, 1)
+        for i, (t, t_host) in enumerate(zip(self.scheduler.timesteps, self.scheduler.timesteps_host)):
+            ops.copy_scale(geo.permute(0, 2, 3, 1).contiguous(), xin[..., C:])
+            v = self.unet(to_nchw_view(xin), t.repeat(2 * B), encoder_hidden_states=ctx, class_labels=cls).sample
+            step = self.scheduler.step(v, t_host, geo)
+            geo = step.pred_original_sample if i == num_inference_steps - 1 else step.prev_sample   # :332-336
+        depth = ops.depth_head(self._m._decode(geo[:B]).permute(0, 2, 3, 1), to_unit=True)
+        normal = ops.normal_head(self._m._decode(geo[B:]).permute(0, 2, 3, 1), clamp=False, sign=-1.0)
+        return depth, normal
+
+    @torch.no_grad()
+    def single_infer(self, input_rgb, num_inference_steps=1, domain="indoor", show_pbar=False, noise="zeros", img_embed=None, generator=None):
+        """Positional order of the reference (geowizard_pipeline.py:252-258: input_rgb, num_inference_steps, domain, show_pbar, noise).
+        The CLIP embedding [B,1,X] comes from `img_embed=`, else from `self.img_embed` when a caller has set it as the reference's
+        `__call__` does (:222,283-284), else from the image encoder.  Defaults are the E2E-FT setting (one step, zeros)."""
+        if isinstance(num_inference_steps, torch.Tensor):        # older call form single_infer(rgb, img_embed[, domain])
+            img_embed, num_inference_steps = num_inference_steps, 1
+        if img_embed is None:
+            img_embed = self.img_embed
+        device, dt = self.device, self.dtype
+        rgb = input_rgb.to(device=device, dtype=dt)
+        B = rgb.shape[0]
+        if num_inference_steps != 1 or isinstance(noise, torch.Tensor) or noise != "zeros":
+            cls = self.class_embedding(B, domain, dt, device)
+            return self._multi_step(rgb, None if img_embed is None else img_embed.to(device=device, dtype=dt), cls, num_inference_steps, noise, generator)
+        self.scheduler.set_timesteps(1, device=device)
+        t_dev = self.scheduler.timesteps[:1]
+        sb = -self.scheduler.zero_latent_x0_scale(self.scheduler.timesteps_host[0])   # x0 = -sb * model_output (by prediction_type); host copy, no device read-back
+        ck = (B, domain, dt, str(device))
+        if getattr(self, "_cls_key", None) != ck:
+            self._cls, self._cls_key = self.class_embedding(B, domain, dt, device), ck
+        cls = self._cls
+        if img_embed is not None:
+            img_embed = img_embed.to(device=device, dtype=dt)
+        if self._graphs is None:
+            return self._device_path(rgb, img_embed, t_dev, sb, cls)
+        from . import autograd as F
+        w0 = self.unet.conv_in.weight
+        key = (tuple(rgb.shape), dt, domain, None if img_embed is None else tuple(img_embed.shape), float(sb), F.PARAM_EPOCH, w0.data_ptr(), w0._version)
+        ent = self._graphs.get(key)
+        if ent is None:
+            _evict_stale_graphs(self._graphs, key, n_weight_fields=3)
+            self._device_path(rgb, img_embed, t_dev, sb, cls)        # eager pass: fills the packed-weight caches
+            torch.cuda.synchronize()
+            s_rgb, s_emb, s_t = rgb.clone(), None if img_embed is None else img_embed.clone(), t_dev.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                s_out = self._device_path(s_rgb, s_emb, s_t, sb, cls)
+            ent = self._graphs[key] = (g, s_rgb, s_emb, s_t, s_out)
+        g, s_rgb, s_emb, s_t, s_out = ent
+        s_rgb.copy_(rgb)
+        if s_emb is not None:
+            s_emb.copy_(img_embed)
+        s_t.copy_(t_dev)
+        g.replay()
+        return s_out[0].clone(), s_out[1].clone()
+
+    # ---- geowizard_pipeline.py:88-230 ----
+    @torch.no_grad()
+    def __call__(self, input_image, denoising_steps=1, ensemble_size=1, processing_res=768, match_input_res=True, batch_size=0,
+                 domain="indoor", color_map="Spectral", show_progress_bar=False, ensemble_kwargs=None, noise="zeros"):
+        """Host orchestration of the joint prediction: resize -> [-1,1] -> `ensemble_size` passes -> depth / normal ensembling ->
+        min-max -> resize back.  Defaults are the E2E-FT setting (denoising_steps = 1, noise = "zeros": every pass identical, ensembling
+        is a no-op); the reference's own defaults for the original checkpoints are 10 steps, 10 members, gaussian noise.  Resampling runs in torch (the reference goes
+        through PIL / cv2 on the host: bicubic for depth, nearest for normals) and the colourised images are left to the caller."""
+        assert processing_res >= 0 and ensemble_size >= 1 and denoising_steps >= 1
+        if isinstance(input_image, torch.Tensor):
+            rgb = input_image.squeeze()
+        else:
+            rgb = torch.from_numpy(np.asarray(input_image.convert("RGB"))).permute(2, 0, 1)
+        assert rgb.dim() == 3 and rgb.shape[0] == 3
+        H0, W0 = rgb.shape[-2:]
+        rgb = rgb.to(self.device)
+        if processing_res > 0:
+            rgb = resize_max_res(rgb, processing_res)
+        rgb_norm = (rgb.float() / 255.0 * 2.0 - 1.0).clamp(-1.0, 1.0).to(self.dtype)
+        bs = batch_size if batch_size > 0 else 1
+        dup = torch.stack([rgb_norm] * ensemble_size)
+        depths, normals = [], []
+        for s0 in range(0, ensemble_size, bs):
+            d, n = self.single_infer(dup[s0:s0 + bs], domain=domain, num_inference_steps=denoising_steps, noise=noise)
+            depths.append(d)
+            normals.append(n)
+        depth_preds = torch.cat(depths, 0).float().squeeze(1)         # [N, H, W]
+        normal_preds = torch.cat(normals, 0).float()                  # [N, 3, H, W]
+        uncert = None
+        if ensemble_size > 1:
+            from .ensemble import ensemble_depths, ensemble_normals
+            depth_pred, uncert = ensemble_depths(depth_preds, **(ensemble_kwargs or {}))
+            normal_pred = ensemble_normals(normal_preds)[0]
+        else:
+            depth_pred, normal_pred = depth_preds[0], normal_preds[0]
+        mn, mx = depth_pred.min(), depth_pred.max()
+        depth_pred = (depth_pred - mn) / (mx - mn)
+        hwc = False
+        if match_input_res and tuple(depth_pred.shape[-2:]) != (H0, W0):
+            depth_pred = torch.nn.functional.interpolate(depth_pred[None, None], size=(H0, W0), mode="bicubic", align_corners=False)[0, 0]
+            normal_pred = torch.nn.functional.interpolate(normal_pred[None], size=(H0, W0), mode="nearest")[0]
+        if match_input_res:
+            normal_pred, hwc = normal_pred.permute(1, 2, 0), True      # the reference returns HWC normals after its cv2 resize (:205)
+        return DepthNormalPipelineOutput(depth_np=depth_pred.clamp(0, 1).cpu().numpy().astype(np.float32), depth_colored=None,
+                                         normal_np=normal_pred.clamp(-1, 1).contiguous().cpu().numpy().astype(np.float32), normal_colored=None,
+                                         uncertainty=uncert)

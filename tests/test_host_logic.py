@@ -162,3 +162,19 @@ def test_pyramid_noise_like_draws_the_reference_sequence():
         got = pyramid_noise_like(x)
         assert got.shape == want.shape and torch.allclose(got, want, rtol=1e-6, atol=1e-6), shape
         assert abs(got.std().item() - 1.0) < 1e-5
+
+
+def test_public_surface_is_importable():
+    """every name callers of the reference's modules import from their counterparts here (a CPU-side guard: the GPU suite only runs at round end)"""
+    from diffusion_e2e_ft_amd.pipeline import (MarigoldPipeline, MarigoldDepthOutput, DepthNormalEstimationPipeline, DepthNormalPipelineOutput,  # noqa: F401
+                                               resize_max_res, pyramid_noise_like, find_batch_size, colorize_depth)
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel, UNet2DConditionOutput  # noqa: F401
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL  # noqa: F401
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler  # noqa: F401
+    from diffusion_e2e_ft_amd.training import (e2e_ft_loss, geowizard_e2e_ft_loss, FlatAdamW, IterExponential, replace_unet_conv_in, train_step)  # noqa: F401
+    from diffusion_e2e_ft_amd.clip import CLIPTextModel, CLIPVisionModelWithProjection  # noqa: F401
+    import inspect
+    sig = inspect.signature(DepthNormalEstimationPipeline.single_infer)
+    assert list(sig.parameters)[:6] == ["self", "input_rgb", "num_inference_steps", "domain", "show_pbar", "noise"]   # geowizard_pipeline.py:252-258
+    sig = inspect.signature(MarigoldPipeline.single_infer)
+    assert list(sig.parameters)[:6] == ["self", "rgb_in", "num_inference_steps", "show_pbar", "noise", "normals"]     # marigold_pipeline.py:372-380
