@@ -9,7 +9,9 @@ namespace e2eft {
 // shader clock at the phase boundaries of igemm2_kernel — start, k-loop entry, k-loop exit, accumulators staged, end.
 #ifdef E2EFT_STAMPS
 static __device__ long long g_stamps[65536 * 8];
-#define E2EFT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+static __device__ long long g_stamps_rt[65536 * 2];   // the constant 100 MHz counter (s_memrealtime) at stamps 0 and 4: shader clock = cycles / ticks * 100 MHz
+#define E2EFT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) { g_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); \
+    if ((i) == 0 || (i) == 4) g_stamps_rt[blockIdx.x * 2 + ((i) >> 2)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define E2EFT_STAMP(i) do { } while (0)
 #endif

@@ -512,4 +512,7 @@ int launch_igemm_v2(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s) 
 extern "C" int e2eft_debug_read_stamps(long long* host, int nworkgroups) {   // debug builds only; not part of include/e2eft.h
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(e2eft::g_stamps), (size_t)nworkgroups * 8 * sizeof(long long));
 }
+extern "C" int e2eft_debug_read_stamps_rt(long long* host, int nworkgroups) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(e2eft::g_stamps_rt), (size_t)nworkgroups * 2 * sizeof(long long));
+}
 #endif

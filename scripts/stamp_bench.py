@@ -36,3 +36,15 @@ print("k-loop start-up: tile 0 %.0f cycles, tiles 1-2 %.0f, tiles 3-5 %.0f (loop
     (s[:, 5] - s[:, 1]).mean(), (s[:, 6] - s[:, 5]).mean(), (s[:, 7] - s[:, 6]).mean()))
 tot = s[:, 4] - s[:, 0]
 print("%-34s mean %8.0f cycles; k-tiles %d -> %.0f cycles / k-tile in the loop" % ("workgroup total", tot.mean(), k * k * Ci // 64, (s[:, 2] - s[:, 1]).mean() / (k * k * Ci // 64)))
+
+# shader clock actually delivered while this kernel ran, from the kernel's own two counters (no profiler attached): s_memtime cycles per
+# s_memrealtime tick (100 MHz) between the first and the last stamp of every workgroup
+rt = (ctypes.c_longlong * (nwg * 2))()
+lib.e2eft_debug_read_stamps_rt.restype = ctypes.c_int
+if lib.e2eft_debug_read_stamps_rt(rt, nwg) == 0:
+    r = np.frombuffer(rt, dtype=np.int64).reshape(nwg, 2)
+    ticks = (r[:, 1] - r[:, 0]).astype(np.float64)
+    ok = ticks > 0
+    mhz = tot[ok] / ticks[ok] * 100.0
+    print("shader clock during the kernel (s_memtime / s_memrealtime): mean %.0f MHz, median %.0f, p5 %.0f, p95 %.0f; workgroup wall time mean %.1f us"
+          % (mhz.mean(), np.median(mhz), np.percentile(mhz, 5), np.percentile(mhz, 95), ticks[ok].mean() / 100.0))
