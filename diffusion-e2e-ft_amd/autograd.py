@@ -467,7 +467,8 @@ class _AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, do):
-        qkv, kv = ctx.saved_tensors[:2]
+        saved = ctx.saved_tensors          # unpacked ONCE (activation recompute re-materialises saved tensors on every access)
+        qkv, kv = saved[:2]
         heads, scale, C = ctx.meta
         q, k, v = _attn_views(qkv, kv, C)
         B, N, _ = q.shape
@@ -475,8 +476,8 @@ class _AttentionFn(torch.autograd.Function):
         d = C // heads
         dt = q.dtype
         do = do.contiguous()
-        if len(ctx.saved_tensors) == 4 and FLASH_BACKWARD:      # fused backward (e2eft_attn_bwd): no N x Nk matrix in HBM
-            o, lse = ctx.saved_tensors[2:]
+        if len(saved) == 4 and FLASH_BACKWARD:      # fused backward (e2eft_attn_bwd): no N x Nk matrix in HBM
+            o, lse = saved[2:]
             if kv is None:
                 dqkv = torch.empty(qkv.shape, dtype=dt, device=qkv.device)
                 dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]

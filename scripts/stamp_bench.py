@@ -18,7 +18,8 @@ x = torch.randn((B, H, W, Ci), device=dev).half()
 w = (torch.randn((Co, k * k * Ci), device=dev) / (k * k * Ci) ** 0.5).half()
 b = torch.randn((Co,), device=dev).half()
 p = k // 2
-for _ in range(3):
+warm = int(os.environ.get("WARM", "3"))      # WARM=400: the stamps are those of a launch after ~1 s of the same kernel (clocks settled)
+for _ in range(warm):
     out = ops.conv2d(x, w, b, Co, k, k, 1, (p, p, p, p), gn_stats=os.environ.get("NOSTATS") is None)
 torch.cuda.synchronize()
 nwg = min(65536, ((B * H * W + 255) // 256) * ((Co + 127) // 128))
@@ -28,6 +29,14 @@ lib.e2eft_debug_read_stamps.restype = ctypes.c_int
 rc = lib.e2eft_debug_read_stamps(buf, nwg)
 assert rc == 0, rc
 s = np.frombuffer(buf, dtype=np.int64).reshape(nwg, 8)
+rt_reader = lib.e2eft_debug_read_stamps_rt
+if not s[:, 4].any():       # the launch went to the row-strip kernel (igemm4.hip keeps its own stamp arrays)
+    lib.e2eft_debug_read_stamps4.restype = ctypes.c_int
+    assert lib.e2eft_debug_read_stamps4(buf, nwg) == 0
+    s = np.frombuffer(buf, dtype=np.int64).reshape(nwg, 8).copy()
+    s[:, 5:8] = s[:, 1:2]
+    rt_reader = lib.e2eft_debug_read_stamps4_rt
+    print("(row-strip kernel igemm4)")
 names = ["prologue (start -> loop entry)", "main loop", "accumulators -> LDS + barrier", "epilogue stores (+GN stats)"]
 for i, n in enumerate(names):
     d = s[:, i + 1] - s[:, i]
@@ -40,8 +49,8 @@ print("%-34s mean %8.0f cycles; k-tiles %d -> %.0f cycles / k-tile in the loop" 
 # shader clock actually delivered while this kernel ran, from the kernel's own two counters (no profiler attached): s_memtime cycles per
 # s_memrealtime tick (100 MHz) between the first and the last stamp of every workgroup
 rt = (ctypes.c_longlong * (nwg * 2))()
-lib.e2eft_debug_read_stamps_rt.restype = ctypes.c_int
-if lib.e2eft_debug_read_stamps_rt(rt, nwg) == 0:
+rt_reader.restype = ctypes.c_int
+if rt_reader(rt, nwg) == 0:
     r = np.frombuffer(rt, dtype=np.int64).reshape(nwg, 2)
     ticks = (r[:, 1] - r[:, 0]).astype(np.float64)
     ok = ticks > 0
