@@ -52,16 +52,13 @@ struct IgemmParams {
 // over each thread's rows, butterfly + LDS merge over the workgroup — so that the consuming GroupNorm skips its statistics
 // pass over HBM (one of its three passes).
 template <typename T, int BM_, int BN_, int NT_>
+__device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, char* smem, int m0, int n0, int zo, int zi);
+
+template <typename T, int BM_, int BN_, int NT_>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem, floatx16 (&acc)[2][2], int wm, int wn, int l31,
                                                int h, int m0, int n0, int zo, int zi) {
-    constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int LDT = BN_ + 4;            // fp32 row stride of the staged tile (528 B for BN = 128)
-    constexpr int CPR = BN_ / 8;            // 8-column chunks per row
-    constexpr int RPP = NT_ / CPR;          // rows per pass
-    constexpr int NPASS = BM_ / RPP;        // rows per thread
-    constexpr int NWV = NT_ / 64;
     float* tile = reinterpret_cast<float*>(smem);
-    float* gst = tile + BM_ * LDT;          // [NWV][16 chunks][8 cols][2] wave partials of the GroupNorm statistics
     __syncthreads();                        // every wave is done reading the last k-tile
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -72,6 +69,21 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
                 tile[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDT + wn * 64 + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
     E2EFT_STAMP(3);
+    igemm_epilogue_rows<T, BM_, BN_, NT_>(p, smem, m0, n0, zo, zi);
+}
+
+// the row passes over a tile that is already staged in LDS as fp32 [BM_][BN_ + 4] (all threads past a barrier): bias / rowadd / alpha /
+// residual, rounding, 16-byte stores, optional GroupNorm statistics.  Kernels with other accumulator layouts stage themselves (igemm4.hip).
+template <typename T, int BM_, int BN_, int NT_>
+__device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, char* smem, int m0, int n0, int zo, int zi) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int LDT = BN_ + 4;            // fp32 row stride of the staged tile (528 B for BN = 128)
+    constexpr int CPR = BN_ / 8;            // 8-column chunks per row
+    constexpr int RPP = NT_ / CPR;          // rows per pass
+    constexpr int NPASS = BM_ / RPP;        // rows per thread
+    constexpr int NWV = NT_ / 64;
+    float* tile = reinterpret_cast<float*>(smem);
+    float* gst = tile + BM_ * LDT;          // [NWV][16 chunks][8 cols][2] wave partials of the GroupNorm statistics
 
     const T* __restrict__ bias = (const T*)p.bias;
     const T* __restrict__ rowadd = (const T*)p.rowadd;

@@ -57,3 +57,17 @@ if rt_reader(rt, nwg) == 0:
     mhz = tot[ok] / ticks[ok] * 100.0
     print("shader clock during the kernel (s_memtime / s_memrealtime): mean %.0f MHz, median %.0f, p5 %.0f, p95 %.0f; workgroup wall time mean %.1f us"
           % (mhz.mean(), np.median(mhz), np.percentile(mhz, 5), np.percentile(mhz, 95), ticks[ok].mean() / 100.0))
+
+if rt_reader is not lib.e2eft_debug_read_stamps_rt:
+    n4 = min(nwg, 4096)
+    tb = (ctypes.c_longlong * (n4 * 64))()
+    lib.e2eft_debug_read_tile4.restype = ctypes.c_int
+    if lib.e2eft_debug_read_tile4(tb, n4) == 0:
+        t = np.frombuffer(tb, dtype=np.int64).reshape(n4, 8, 8)
+        t = t[:, t[0, :, 5] != 0, :]                              # the waves the kernel has (4)
+        d = np.diff(t[:, :, :6], axis=2).astype(np.float64)      # [wg, wave, 5 phases]
+        names = ["DMA wait (s_waitcnt vmcnt)", "barrier", "first two fragment groups read (+ A DMA issue)", "first MFMA group", "remaining 3 groups + reads + DMA issue"]
+        print("inside one steady-state k-tile (tile 9), per wave, mean over waves and workgroups / mean of the per-workgroup MAX over waves:")
+        for i, n in enumerate(names):
+            print("  %-44s %7.0f / %7.0f cycles" % (n, d[:, :, i].mean(), d[:, :, i].max(axis=1).mean()))
+        print("  %-44s %7.0f cycles" % ("whole tile", (t[:, :, 5] - t[:, :, 0]).mean()))

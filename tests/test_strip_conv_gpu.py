@@ -1,7 +1,7 @@
 """igemm4.hip (3x3 / stride-1 convolutions with row-strip reuse of the A operand) against torch CPU: the shapes that stress what is new in
 it — zero padding applied to fragments (row ends and image ends inside a 256-pixel tile, every tap), strips that start before / end after
 the tensor, several images per tile, an odd number of strips, ragged N and M tiles, two-source concat with the source switch between
-64-channel chunks, the epilogue options.  The library picks the kernel by problem size; E2EFT_STRIP=2 makes it take every eligible
+64-channel chunks, the epilogue options.  The kernel is opt-in (E2EFT_STRIP=1, see igemm4.hip for the measurements); E2EFT_STRIP=2 makes it take every eligible
 convolution, so the cases run in a subprocess with that set (the variable is read once per process)."""
 import os
 import subprocess
@@ -80,5 +80,6 @@ def test_strip_kernel_forced_on_small_shapes(dev):
     _run({"E2EFT_STRIP": "2"})
 
 
-def test_same_cases_on_the_default_dispatch(dev):
+def test_same_cases_with_the_size_rule(dev):
+    """E2EFT_STRIP=1: eligible AND large problems only (the last case); the rest run on igemm2 — both dispatches give the same numbers"""
     _run({"E2EFT_STRIP": "1"})
