@@ -5,7 +5,9 @@
   prepare_batch     load.py:236-283 (Hypersim) / :342-375 (Virtual KITTI 2): what __getitem__ does to a decoded + augmented sample,
                     batched on the device: validity mask, 2 % / 98 % depth quantiles, clamp + normalise, normal renormalisation.
   hflip_sample      load.py:76-84: synchronised horizontal flip incl. the sign change of the normals' x component.
-File decoding (PNG / EXR through PIL / cv2) and resizing stay with the caller: no image library is part of this package."""
+  augment_hypersim / augment_vkitti   load.py:67-152: the synchronised transforms (h-flip, PIL-exact bilinear / nearest resize to 480 x 640,
+                    ToTensor; h-flip, ToTensor, KITTI benchmark crop 352 x 1216) on batches of DECODED images resident on the device.
+File decoding (PNG / EXR through PIL / cv2) stays with the caller: no image library is part of this package."""
 import numpy as np
 import torch
 
@@ -70,3 +72,103 @@ def prepare_batch(rgb01, depth, normal01, dataset="hypersim", near_plane=None, f
     q = ops.masked_quantiles(depth, near, far, 0.02, 0.98)
     rgb, depth3, metric, normals, mask = ops.prepare_sample(rgb01, depth, normal01, near, far, q)
     return {"rgb": rgb, "depth": depth3, "metric": metric, "normals": normals, "val_mask": mask, "domain": [DOMAIN[dataset]] * rgb.shape[0]}
+
+
+# ---- synchronised augmentation on the device (csrc/dataaug.hip) ---------------------------------------------------------------------
+_PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_coeffs(in_size, out_size):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c) for the bilinear (triangle) filter over the full input
+    range: bounds int32 [out, 2] = (first tap, tap count), coefficients int32 [out, ksize] in 22-bit fixed point.  float64 arithmetic in
+    Pillow's order, so the integer tables are the ones Pillow builds and the device resize (aug_resample_h/v kernels) is bit-exact."""
+    import math
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = np.zeros(ksize, dtype=np.float64)
+        ww = 0.0
+        for x in range(xmax):
+            v = abs((x + xmin - center + 0.5) * ss)
+            w[x] = 1.0 - v if v < 1.0 else 0.0
+            ww += w[x]
+        if ww != 0.0:
+            w[:xmax] /= ww
+        kk[xx] = [int(-0.5 + v * (1 << _PIL_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PIL_PRECISION_BITS)) for v in w]
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def pil_nearest_map(in_size, out_size):
+    """source index of every output index for Image.resize(..., NEAREST): Pillow's ImagingScaleAffine walks xo = scale / 2, xo += scale in
+    double precision and truncates — the ACCUMULATED sum, so that exact half-way positions (768 -> 480: (7 + 0.5) * 1.6 = 12) land where
+    Pillow's rounding error puts them (11)"""
+    a0 = float(in_size) / out_size
+    steps = np.full(out_size, a0, dtype=np.float64)
+    steps[0] = a0 * 0.5
+    xo = np.add.accumulate(steps)          # sequential double additions, as the C loop
+    return np.clip(xo.astype(np.int32), 0, in_size - 1)
+
+
+_TABLES = {}
+
+
+def _tables(kind, in_size, out_size, device):
+    key = (kind, in_size, out_size, str(device))
+    if key not in _TABLES:
+        if kind == "bilinear":
+            b, k = pil_bilinear_coeffs(in_size, out_size)
+            _TABLES[key] = (torch.from_numpy(b).to(device), torch.from_numpy(k).to(device))
+        elif kind == "nearest":
+            _TABLES[key] = torch.from_numpy(pil_nearest_map(in_size, out_size)).to(device)
+        else:   # ("crop", offset): in_size is the offset here
+            _TABLES[key] = (in_size + torch.arange(out_size, dtype=torch.int32)).to(device)
+    return _TABLES[key]
+
+
+def _flip_flags(flip, batch, device):
+    if flip is None:
+        return None
+    return torch.as_tensor(flip, dtype=torch.uint8).reshape(batch).to(device).contiguous()
+
+
+@torch.no_grad()
+def augment_hypersim(rgb_u8, depth, normal_u8=None, size=(480, 640), flip=None):
+    """SynchronizedTransform_Hyper (load.py:67-101) on a batch: rgb_u8 / normal_u8 uint8 [B,H0,W0,3] as decoded, depth fp32 [B,H0,W0]; flip:
+    per-image booleans (the reference draws `random.random() > 0.5` per sample).  Returns rgb01 [B,3,h,w], depth [B,1,h,w], normal01 or None
+    — the inputs of prepare_batch."""
+    dev = rgb_u8.device
+    B, H0, W0, _ = rgb_u8.shape
+    h, w = size
+    fl = _flip_flags(flip, B, dev)
+    xt, yt = _tables("bilinear", W0, w, dev), _tables("bilinear", H0, h, dev)
+    rgb01 = ops.aug_resample_bilinear_u8(rgb_u8.contiguous(), (h, w), xt, yt, flip=fl)
+    d = ops.aug_gather(depth.float().contiguous(), _tables("nearest", H0, h, dev), _tables("nearest", W0, w, dev), flip=fl)[:, None]
+    n01 = None if normal_u8 is None else ops.aug_resample_bilinear_u8(normal_u8.contiguous(), (h, w), xt, yt, flip=fl, invert_x_on_flip=True)
+    return rgb01, d, n01
+
+
+KB_CROP = (352, 1216)     # KITTI benchmark crop (load.py:112-131)
+
+
+@torch.no_grad()
+def augment_vkitti(rgb_u8, depth, normal_u8=None, flip=None):
+    """SynchronizedTransform_VKITTI (load.py:104-152): h-flip, ToTensor, crop the bottom 352 rows / centred 1216 columns"""
+    dev = rgb_u8.device
+    B, H0, W0, _ = rgb_u8.shape
+    ch, cw = KB_CROP
+    top, left = int(H0 - ch), int((W0 - cw) / 2)
+    fl = _flip_flags(flip, B, dev)
+    ym, xm = _tables("crop", top, ch, dev), _tables("crop", left, cw, dev)
+    rgb01 = ops.aug_gather(rgb_u8.contiguous(), ym, xm, flip=fl)
+    d = ops.aug_gather(depth.float().contiguous(), ym, xm, flip=fl)[:, None]
+    n01 = None if normal_u8 is None else ops.aug_gather(normal_u8.contiguous(), ym, xm, flip=fl, invert_x_on_flip=True)
+    return rgb01, d, n01

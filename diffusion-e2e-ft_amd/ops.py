@@ -967,3 +967,52 @@ def prepare_sample(rgb01, depth, normal01, near, far, quantiles):
     check(_lib.load().e2eft_prepare_sample(B, H * W, _ptr(rgb01), _ptr(depth), _ptr(normal01), near, far, _ptr(quantiles), _ptr(rgb), _ptr(depth3),
                                            _ptr(metric), _ptr(normals), _ptr(mask), _stream()))
     return rgb, depth3, metric, normals, mask.bool()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# sample augmentation (csrc/dataaug.hip) and evaluation metrics (csrc/evalmetrics.hip)
+def aug_resample_bilinear_u8(img, size, xtab, ytab, flip=None, invert_x_on_flip=False):
+    """img uint8 [B,H0,W0,3] -> fp32 [B,3,h,w] in [0,1]: PIL-exact bilinear resize + ToTensor; xtab / ytab = (bounds int32 [out,2], coef int32 [out,k])"""
+    _check_cuda(img, xtab[0], xtab[1], ytab[0], ytab[1], flip)
+    B, H0, W0, c = img.shape
+    assert c == 3 and img.dtype == torch.uint8 and img.is_contiguous()
+    h, w = size
+    mid = torch.empty((B, H0, w, 3), dtype=torch.uint8, device=img.device)
+    out = torch.empty((B, 3, h, w), dtype=torch.float32, device=img.device)
+    check(_lib.load().e2eft_aug_resample_bilinear_u8(B, H0, W0, h, w, _ptr(img), _ptr(flip), 1 if invert_x_on_flip else 0, _ptr(xtab[0]), _ptr(xtab[1]),
+                                                     xtab[1].shape[1], _ptr(ytab[0]), _ptr(ytab[1]), ytab[1].shape[1], _ptr(mid), _ptr(out), _stream()))
+    return out
+
+
+def aug_gather(img, ymap, xmap, flip=None, invert_x_on_flip=False):
+    """index-table gather (nearest resize / crop) with the synchronised flip: fp32 [B,H0,W0] -> [B,h,w], or uint8 [B,H0,W0,3] -> fp32 [B,3,h,w] / 255"""
+    _check_cuda(img, ymap, xmap, flip)
+    h, w = ymap.numel(), xmap.numel()
+    lib = _lib.load()
+    if img.dtype == torch.uint8:
+        B, H0, W0, c = img.shape
+        assert c == 3 and img.is_contiguous()
+        out = torch.empty((B, 3, h, w), dtype=torch.float32, device=img.device)
+        check(lib.e2eft_aug_gather_u8(B, H0, W0, h, w, _ptr(img), _ptr(ymap), _ptr(xmap), _ptr(flip), 1 if invert_x_on_flip else 0, _ptr(out), _stream()))
+        return out
+    B, H0, W0 = img.shape
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    out = torch.empty((B, h, w), dtype=torch.float32, device=img.device)
+    check(lib.e2eft_aug_gather_f32(B, H0, W0, h, w, _ptr(img), _ptr(ymap), _ptr(xmap), _ptr(flip), _ptr(out), _stream()))
+    return out
+
+
+def depth_eval(pred, gt, mask, disparity=False, align_max_res=0, min_depth=1e-3, max_depth=80.0, return_aligned=False):
+    """pred, gt fp32 [B,H,W], mask bool / uint8 [B,H,W] -> metrics fp32 [B,12] (see include/e2eft.h) [, aligned prediction [B,H,W]]"""
+    _check_cuda(pred, gt, mask)
+    B, H, W = pred.shape
+    pred, gt = pred.float().contiguous(), gt.float().contiguous()
+    mask = mask.to(torch.uint8).contiguous()
+    lib = _lib.load()
+    nws = lib.e2eft_depth_eval_workspace_bytes(B)
+    ws = torch.empty(((nws + 7) // 8,), dtype=torch.float64, device=pred.device)
+    out = torch.empty((B, 12), dtype=torch.float32, device=pred.device)
+    aligned = torch.empty_like(pred) if return_aligned else None
+    check(lib.e2eft_depth_eval(B, H, W, _ptr(pred), _ptr(gt), _ptr(mask), 1 if disparity else 0, int(align_max_res or 0), float(min_depth), float(max_depth),
+                               _ptr(out), _ptr(aligned), _ptr(ws), nws, _stream()))
+    return (out, aligned) if return_aligned else out

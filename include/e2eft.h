@@ -322,6 +322,32 @@ int e2eft_masked_quantiles(int32_t batch, int64_t n, const float* depth, float n
 int e2eft_prepare_sample(int32_t batch, int64_t hw, const float* rgb01, const float* depth, const float* normal01, float near_plane,
                          float far_plane, const float* quantiles, float* rgb, float* depth3, float* metric, float* normals,
                          uint8_t* val_mask, void* stream);
+/* Synchronised augmentation of decoded training samples on the device (/root/reference/training/dataloaders/load.py:67-152): horizontal flip
+ * (per-image flags; `invert_x_on_flip`: first channel -> 255 - x, the normals' x component, :80-82), PIL-exact bilinear resize of uint8 HWC
+ * images (torchvision.transforms.Resize on a PIL image = Image.resize: separable triangle filter, 22-bit fixed-point coefficients, uint8
+ * rounding after each pass; coefficient tables in Pillow's precompute_coeffs layout: bounds [out][2] = (first tap, tap count), coef
+ * [out][ksize]), ToTensor (uint8 / 255 -> planar fp32), nearest resize / KITTI benchmark crop as index tables.
+ *   e2eft_aug_resample_bilinear_u8  in [B][h0][w0][3] uint8 -> out [B][3][h][w] fp32 in [0,1]; mid: [B][h0][w][3] uint8 scratch
+ *   e2eft_aug_gather_f32            out[b][y][x] = in[b][ymap[y]][xmap[x]] (x mirrored when flip[b]): depth maps, fp32
+ *   e2eft_aug_gather_u8             the same for uint8 HWC -> planar fp32 / 255 */
+int e2eft_aug_resample_bilinear_u8(int32_t batch, int32_t h0, int32_t w0, int32_t h, int32_t w, const uint8_t* in, const uint8_t* flip,
+                                   int32_t invert_x_on_flip, const int32_t* xbounds, const int32_t* xcoef, int32_t xksize,
+                                   const int32_t* ybounds, const int32_t* ycoef, int32_t yksize, uint8_t* mid, float* out, void* stream);
+int e2eft_aug_gather_f32(int32_t batch, int32_t h0, int32_t w0, int32_t h, int32_t w, const float* in, const int32_t* ymap,
+                         const int32_t* xmap, const uint8_t* flip, float* out, void* stream);
+int e2eft_aug_gather_u8(int32_t batch, int32_t h0, int32_t w0, int32_t h, int32_t w, const uint8_t* in, const int32_t* ymap,
+                        const int32_t* xmap, const uint8_t* flip, int32_t invert_x_on_flip, float* out, void* stream);
+/* Evaluation arithmetic of the acceptance metric on the device, per image of a batch (fp32 [B][height][width], mask uint8):
+ * least-squares scale / shift of pred to gt over the valid pixels (/root/reference/Marigold/src/util/alignment.py:8-56; align_max_res > 0:
+ * on the nearest-down-sampled grid of :23-33; disparity != 0: in 1 / depth space with the validity rule and the 1e-3 disparity clip of
+ * Marigold/eval.py:180-201), clipping to [min_depth, max_depth] and >= 1e-6 (eval.py:203-209), then the ten metrics of
+ * Marigold/src/util/metric.py:34-158.  out_metrics [B][12] = abs_relative_difference, squared_relative_difference, rmse_linear, rmse_log,
+ * log10, delta1_acc, delta2_acc, delta3_acc, i_rmse, silog_rmse, scale, shift.  aligned_out (optional) receives the aligned, clipped
+ * prediction.  fp64 two-stage reductions over fixed partials: bit-reproducible. */
+size_t e2eft_depth_eval_workspace_bytes(int32_t batch);
+int e2eft_depth_eval(int32_t batch, int32_t height, int32_t width, const float* pred, const float* gt, const uint8_t* mask, int32_t disparity,
+                     int32_t align_max_res, float min_depth, float max_depth, float* out_metrics, float* aligned_out, void* workspace,
+                     size_t ws_bytes, void* stream);
 /* Test-time ensembling of the n_img (<= 32) predictions of ONE image, fp32, replacing
  *   ensemble_depths   /root/reference/Marigold/marigold/util/ensemble.py:40-132 (called from marigold_pipeline.py:293-297;
  *                     twin GeoWizard/geowizard/utils/depth_ensemble.py:21-115)

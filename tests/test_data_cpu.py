@@ -85,3 +85,46 @@ def test_oracle_edge_cases():
     assert out["val_mask"].sum() == (d < 65).sum() and out["depth"].shape == (3, H, W)
     assert float(out["depth"].min()) == -1.0 and float(out["depth"].max()) == 1.0
     assert (out["metric"][~out["val_mask"]] == out["metric"].max()).all()                       # invalid pixels sit on the far quantile
+
+
+# ---- device augmentation: the host-built tables are Pillow's (data.pil_bilinear_coeffs / pil_nearest_map) ---------------------------------
+def _emulate_resample(img_u8, size):
+    """numpy model of csrc/dataaug.hip's two passes (integer arithmetic, 22-bit coefficients, uint8 after each pass)"""
+    from diffusion_e2e_ft_amd.data import pil_bilinear_coeffs
+    H0, W0, _ = img_u8.shape
+    h, w = size
+    xb, xk = pil_bilinear_coeffs(W0, w)
+    yb, yk = pil_bilinear_coeffs(H0, h)
+    half = 1 << 21
+    mid = np.zeros((H0, w, 3), dtype=np.uint8)
+    for xo in range(w):
+        x0, n = xb[xo]
+        acc = (img_u8[:, x0:x0 + n, :].astype(np.int64) * xk[xo, :n, None].astype(np.int64)).sum(1) + half
+        mid[:, xo, :] = np.clip(acc >> 22, 0, 255)
+    out = np.zeros((h, w, 3), dtype=np.uint8)
+    for yo in range(h):
+        y0, n = yb[yo]
+        acc = (mid[y0:y0 + n].astype(np.int64) * yk[yo, :n, None, None].astype(np.int64)).sum(0) + half
+        out[yo] = np.clip(acc >> 22, 0, 255)
+    return out
+
+
+@pytest.mark.parametrize("src,dst", [((96, 128), (60, 80)), ((77, 101), (48, 64)), ((40, 56), (60, 84)), ((50, 50), (50, 50)), ((33, 47), (11, 17))])
+def test_bilinear_tables_reproduce_pillow_bit_for_bit(src, dst):
+    """transforms.Resize((H, W)) on a PIL image is Image.resize(..., BILINEAR) (training/dataloaders/load.py:69,87-90): down- and up-scaling,
+    odd sizes, identity"""
+    from PIL import Image
+    rng = np.random.default_rng(src[0] * 1000 + dst[1])
+    img = rng.integers(0, 256, size=(src[0], src[1], 3), dtype=np.uint8)
+    want = np.asarray(Image.fromarray(img).resize((dst[1], dst[0]), resample=Image.BILINEAR))
+    got = _emulate_resample(img, dst)
+    assert np.array_equal(got, want), int(np.abs(got.astype(int) - want.astype(int)).max())
+
+
+@pytest.mark.parametrize("n_in,n_out", [(768, 480), (1024, 640), (101, 64), (64, 101), (375, 352)])
+def test_nearest_map_is_pillows(n_in, n_out):
+    from PIL import Image
+    from diffusion_e2e_ft_amd.data import pil_nearest_map
+    ramp = np.arange(n_in, dtype=np.float32)[None, :].repeat(3, 0)
+    want = np.asarray(Image.fromarray(ramp, mode="F").resize((n_out, 3), resample=Image.NEAREST))[0].astype(np.int32)
+    assert np.array_equal(pil_nearest_map(n_in, n_out), want)

@@ -1,5 +1,6 @@
 """GPU parity of the sample-preparation kernels (csrc/dataprep.hip) against the CPU oracle (oracle/dataprep_ref.py, the reference's
 torch calls) and torch.quantile directly."""
+import numpy as np
 import pytest
 import torch
 
@@ -69,3 +70,68 @@ def test_prepare_batch_nothing_valid(dev):
     out = prepare_batch(rgb.to(dev), torch.zeros(1, 1, 5, 7, device=dev), nrm.to(dev))
     assert not out["val_mask"].any() and (out["depth"] == 0).all() and (out["metric"] == 0).all() and (out["normals"] == 0).all()
     assert torch.equal(out["rgb"].cpu(), rgb * 2 - 1)
+
+
+# ---- synchronised augmentation on the device (csrc/dataaug.hip) against Pillow, which is what the reference's transforms call ----------------
+def _decoded_batch(B, H0, W0, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.linspace(0, 1, H0), np.linspace(0, 1, W0), indexing="ij")
+    rgb = np.stack([np.clip((0.5 + 0.4 * np.sin(6 * xx + b) + 0.1 * rng.standard_normal((H0, W0)))[..., None] * np.array([1.0, 0.8, 0.6]) * 255, 0, 255)
+                    for b in range(B)]).astype(np.uint8)
+    nrm = rng.integers(0, 256, size=(B, H0, W0, 3), dtype=np.uint8)
+    depth = (2.0 + 8.0 * yy[None] + rng.random((B, H0, W0))).astype(np.float32)
+    return rgb, depth, nrm
+
+
+@pytest.mark.parametrize("H0,W0,size", [(96, 128, (60, 80)), (77, 101, (48, 64))])
+def test_augment_hypersim_equals_pillow_transforms(dev, H0, W0, size):
+    """SynchronizedTransform_Hyper (training/dataloaders/load.py:67-101): flip -> normals' x channel 255 - x -> Resize (PIL bilinear / nearest)
+    -> ToTensor, image by image through Pillow, against the batched device kernels: bit-exact"""
+    from PIL import Image
+    from diffusion_e2e_ft_amd.data import augment_hypersim
+    rgb, depth, nrm = _decoded_batch(3, H0, W0, 5)
+    flips = [True, False, True]
+    h, w = size
+    want_rgb, want_d, want_n = [], [], []
+    for b in range(3):
+        ri, di, ni = Image.fromarray(rgb[b]), Image.fromarray(depth[b], mode="F"), Image.fromarray(nrm[b])
+        if flips[b]:
+            ri, di, ni = (im.transpose(Image.FLIP_LEFT_RIGHT) for im in (ri, di, ni))
+            a = np.array(ni)
+            a[:, :, 0] = 255 - a[:, :, 0]
+            ni = Image.fromarray(a)
+        want_rgb.append(np.asarray(ri.resize((w, h), resample=Image.BILINEAR)).astype(np.float32).transpose(2, 0, 1) / 255.0)
+        want_n.append(np.asarray(ni.resize((w, h), resample=Image.BILINEAR)).astype(np.float32).transpose(2, 0, 1) / 255.0)
+        want_d.append(np.asarray(di.resize((w, h), resample=Image.NEAREST)))
+    r01, d, n01 = augment_hypersim(torch.from_numpy(rgb).to(dev), torch.from_numpy(depth).to(dev), torch.from_numpy(nrm).to(dev), size=size, flip=flips)
+    assert tuple(r01.shape) == (3, 3, h, w) and tuple(d.shape) == (3, 1, h, w)
+    assert np.array_equal(r01.cpu().numpy(), np.stack(want_rgb)) and np.array_equal(n01.cpu().numpy(), np.stack(want_n))
+    assert np.array_equal(d[:, 0].cpu().numpy(), np.stack(want_d))
+
+
+def test_augment_vkitti_crop_and_flip(dev):
+    """SynchronizedTransform_VKITTI (load.py:104-152): flip, ToTensor, KITTI benchmark crop (bottom 352 rows, centred 1216 columns)"""
+    from diffusion_e2e_ft_amd.data import augment_vkitti, KB_CROP
+    rgb, depth, nrm = _decoded_batch(2, 375, 1242, 7)
+    flips = [False, True]
+    r01, d, n01 = augment_vkitti(torch.from_numpy(rgb).to(dev), torch.from_numpy(depth).to(dev), torch.from_numpy(nrm).to(dev), flip=flips)
+    top, left = 375 - 352, int((1242 - 1216) / 2)
+    for b in range(2):
+        r, dd, n = rgb[b], depth[b], nrm[b].copy()
+        if flips[b]:
+            r, dd, n = r[:, ::-1], dd[:, ::-1], n[:, ::-1].copy()
+            n[:, :, 0] = 255 - n[:, :, 0]
+        sl = (slice(top, top + 352), slice(left, left + 1216))
+        assert np.array_equal(r01[b].cpu().numpy(), r[sl].astype(np.float32).transpose(2, 0, 1) / 255.0)
+        assert np.array_equal(n01[b].cpu().numpy(), n[sl].astype(np.float32).transpose(2, 0, 1) / 255.0)
+        assert np.array_equal(d[b, 0].cpu().numpy(), dd[sl])
+    assert tuple(r01.shape[-2:]) == KB_CROP
+
+
+def test_augmented_batch_feeds_prepare_batch(dev):
+    from diffusion_e2e_ft_amd.data import augment_hypersim, prepare_batch
+    rgb, depth, nrm = _decoded_batch(2, 96, 128, 9)
+    r01, d, n01 = augment_hypersim(torch.from_numpy(rgb).to(dev), torch.from_numpy(depth).to(dev), torch.from_numpy(nrm).to(dev), size=(64, 96), flip=[True, False])
+    batch = prepare_batch(r01, d, n01, "hypersim")
+    assert tuple(batch["rgb"].shape) == (2, 3, 64, 96) and batch["val_mask"].dtype == torch.bool and torch.isfinite(batch["metric"]).all()
+    assert batch["rgb"].min().item() >= -1.0 and batch["rgb"].max().item() <= 1.0
