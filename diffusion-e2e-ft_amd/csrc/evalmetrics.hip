@@ -36,7 +36,7 @@ template <int N> __device__ __forceinline__ void ev_block_store(double (&v)[N], 
 
 // pass 1: per-image sums of the (optionally nearest-down-sampled) valid pixels.  disparity != 0: the target is 1 / gt where gt > 0 and
 // only pixels with gt > 0 and pred > 0 take part (eval.py:182-190).  Down-sampling: torch.nn.Upsample(scale_factor, "nearest") reads source
-// index floor(dst * (1 / scale_factor)) (alignment.py:23-33); oh == h, ow == w means none.
+// index floor(dst * (1 / scale_factor)) (alignment.py:23-33; the host passes oh == h: see e2eft_depth_eval); oh == h, ow == w means none.
 __global__ __launch_bounds__(256) void ev_align_sums_kernel(int h, int w, int oh, int ow, float inv_scale, int disparity, const float* __restrict__ pred,
                                                             const float* __restrict__ gt, const uint8_t* __restrict__ mask, double* __restrict__ part) {
     const int b = blockIdx.y;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void ev_align_sums_kernel(int h, int w, int oh
         long src = i;
         if (ds) {
             const int oy = i / ow, ox = i - oy * ow;
-            const int sy = min((int)floorf(oy * inv_scale), h - 1), sx = min((int)floorf(ox * inv_scale), w - 1);
+            const int sy = oh == h ? oy : min((int)floorf(oy * inv_scale), h - 1), sx = min((int)floorf(ox * inv_scale), w - 1);
             src = (long)sy * w + sx;
         }
         if (!mask[img + src]) continue;
@@ -169,13 +169,14 @@ extern "C" int e2eft_depth_eval(int32_t batch, int32_t height, int32_t width, co
     float* ss = (float*)(part + (size_t)batch * EV_NBLK * EV_NMET);
     int oh = height, ow = width;
     float inv_scale = 1.0f;
-    if (align_max_res > 0) {   // alignment.py:23-24: scale = min(max_resolution / (H, W)); applied when < 1; output size floor(size * scale)
+    if (align_max_res > 0) {   // alignment.py:23-33: scale = min(max_resolution / (H, W)), applied when < 1 through torch.nn.Upsample(scale_factor,
+        // "nearest") on a [1, H, W] tensor — a 3-D input, i.e. (N, C, L): the reference down-samples the WIDTH only, rows are kept.
+        // Reproduced as is: ow = floor(W * scale), source column floor(x / scale), oh = H.
         const double sf = fmin((double)align_max_res / height, (double)align_max_res / width);
         if (sf < 1.0) {
-            oh = (int)floor(height * sf);
             ow = (int)floor(width * sf);
             inv_scale = (float)(1.0 / sf);
-            E2EFT_REQUIRE(oh > 0 && ow > 0, "depth_eval: align_max_res too small");
+            E2EFT_REQUIRE(ow > 0, "depth_eval: align_max_res too small");
         }
     }
     const int hw = height * width;

@@ -252,7 +252,13 @@ static int gn_run(const E2eftGroupNormDesc* d, const GnGeom& g, const void* x1, 
     float* rstd = ad + (size_t)d->batch * g.C * 2;
     hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(d->groups, g.batch), dim3(256), 0, s, g.C, d->c1, d->groups, d->eps, pa, nsa, pb, nsb,
                        (const T*)gamma, ad, rstd);
-    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(g.nslabs, g.batch, g.nchb), dim3(256), 0, s, g, d->silu, d->ldy, (const T*)x1, (const T*)x2, ad, (const T*)beta, (T*)y);
+    // the apply pass has its own work split: short slabs (two unrolled iterations of four 16-byte loads per thread) in many workgroups —
+    // 0.414 ms instead of 0.472 ms on 8 x 768^2 x 128 fp16, 5.8 of the ~5.8 TB/s this part copies at (scripts/stream_bench.hip,
+    // profiles/r02_stream_bench.txt); the statistics kernels keep the coarser split, their partials are per slab
+    GnGeom ga = g;
+    ga.slab = g.pl * 8;
+    ga.nslabs = (d->hw + ga.slab - 1) / ga.slab;
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(ga.nslabs, ga.batch, ga.nchb), dim3(256), 0, s, ga, d->silu, d->ldy, (const T*)x1, (const T*)x2, ad, (const T*)beta, (T*)y);
     return check_launch("groupnorm");
 }
 

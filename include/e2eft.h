@@ -339,7 +339,7 @@ int e2eft_aug_gather_u8(int32_t batch, int32_t h0, int32_t w0, int32_t h, int32_
                         const int32_t* xmap, const uint8_t* flip, int32_t invert_x_on_flip, float* out, void* stream);
 /* Evaluation arithmetic of the acceptance metric on the device, per image of a batch (fp32 [B][height][width], mask uint8):
  * least-squares scale / shift of pred to gt over the valid pixels (/root/reference/Marigold/src/util/alignment.py:8-56; align_max_res > 0:
- * on the nearest-down-sampled grid of :23-33; disparity != 0: in 1 / depth space with the validity rule and the 1e-3 disparity clip of
+ * on the nearest-down-sampled grid of :23-33 — the reference's 3-D Upsample call shrinks the width only, reproduced as is; disparity != 0: in 1 / depth space with the validity rule and the 1e-3 disparity clip of
  * Marigold/eval.py:180-201), clipping to [min_depth, max_depth] and >= 1e-6 (eval.py:203-209), then the ten metrics of
  * Marigold/src/util/metric.py:34-158.  out_metrics [B][12] = abs_relative_difference, squared_relative_difference, rmse_linear, rmse_log,
  * log10, delta1_acc, delta2_acc, delta3_acc, i_rmse, silog_rmse, scale, shift.  aligned_out (optional) receives the aligned, clipped
