@@ -286,6 +286,8 @@ static int run_igemm(int dtype, int mode, IgemmParams& p, int nz, void* stream) 
         // independent second implementation of the same contract: E2EFT_IGEMM=1 selects it (A/B runs, cross-checks).
         static const int forced = [] { const char* e = getenv("E2EFT_IGEMM"); return e ? atoi(e) : 0; }();
         if (forced != 1) {
+            const int rc5 = launch_igemm_persistent(dtype, mode, p, nz, s);   // big problems: persistent workgroups (igemm5.hip)
+            if (rc5 >= 0) return rc5;
             const int rc4 = launch_igemm_strip(dtype, mode, p, nz, s);   // 3x3 stride-1 convs: row-strip reuse of A (igemm4.hip)
             if (rc4 >= 0) return rc4;
             return launch_igemm_v2(dtype, mode, p, nz, s);

@@ -1,0 +1,563 @@
+// igemm5.hip — PERSISTENT variant of the LDS-DMA implicit-GEMM kernel (igemm2.hip): one 8-wave workgroup per CU walks a sequence
+// of 256x128 output tiles (gfx950, fp16 / bf16, the FAST operand path only).
+//
+// Why: igemm2 pays ~18-20k shader cycles (~10 us) of fixed cost per tile — workgroup launch, index arithmetic, a cold first k-tile
+// (the first LDS-DMA of a fresh workgroup has nothing in flight in front of it), accumulators -> LDS (bound by ds_write_b32 at
+// 64 B/clk), two workgroup barriers, row passes.  At K = 1152 (conv 128->128, the most expensive shape of the path) that is 37 % of
+// the tile.  Here
+//   * the k-tile stream never stops at a tile boundary: while the last two k-tiles of tile t run, the LDS-DMA of the first two
+//     k-tiles of tile t+1 is already in flight (the ring keeps rotating; the address state of the loader is switched to the next
+//     tile after the last piece of the current one has been issued);
+//   * the epilogue has no workgroup-wide staging: every wave sends its own 64x64 accumulator block through a private 2 x 2 KB window
+//     of the ring stage that the last k-tile just released — eight 8-row slices, slice s+1 written while slice s is read back
+//     row-wise — so LDS writes, row math and 16-byte stores of different waves overlap instead of running in barrier-separated phases;
+//   * residual / bias / rowadd vectors of the first slices are requested during the last k-tile.
+// Contract, operand layouts, ring, swizzle, counted vmcnt waits: as igemm2.hip.  Eligibility is decided on the host
+// (launch_igemm_persistent returns -1 and the caller falls through to igemm2): 16-bit FAST path, M a multiple of 256, at least three
+// k-tiles, the vector epilogue, at least two tiles per workgroup.  E2EFT_PERSIST=0 disables the variant (A/B runs).
+//
+// GroupNorm statistics (p.gn_partial): per column shifted sums about a per-wave pivot (the wave's first output row), reduced over the
+// wave with three butterfly steps, deposited per wave in LDS and merged over the four row-waves of a column with Chan's formula —
+// the same (count, mean, M2) triples per 256-row slab that igemm2 emits.
+#include "igemm.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace e2eft {
+
+namespace pers {
+constexpr int BM = 256, BN = 128, NW = 8;
+constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128, STAGE = A_STAGE + B_STAGE;
+constexpr int RING = 3 * STAGE;                  // 147,456 B
+constexpr int DEP = NW * 64 * 3 * 4;             // per-wave GroupNorm deposits: (sum, sum of squares, pivot) per column
+constexpr int LDS = RING + DEP;
+constexpr unsigned int OOB = 0xF0000000u;        // byte offset beyond RECORDS: the buffer load returns zeros
+constexpr unsigned int RECORDS = 0xE0000000u;
+}  // namespace pers
+
+template <typename T> struct Mma5;
+template <> struct Mma5<f16> {
+    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma5<bf16> {
+    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bhalf8, a), __builtin_bit_cast(bhalf8, b), c, 0, 0, 0);
+    }
+};
+
+#ifdef E2EFT_STAMPS
+// instrumented build: thread 0 of every workgroup records, for its first 32 tiles, the shader clock at: k-loop entry, after the steady
+// k-tiles, after the last k-tile (= epilogue entry), epilogue exit (scripts/stamp5_bench.py)
+static __device__ long long g_stamps5[512 * 32 * 4];
+#define STAMP5(t, i) do { if (threadIdx.x == 0 && (t) < 32 && blockIdx.x < 512) g_stamps5[(blockIdx.x * 32 + (t)) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP5(t, i) do { } while (0)
+#endif
+
+typedef __attribute__((address_space(3))) void* lptr5_t;
+template <int V> using IC5 = std::integral_constant<int, V>;
+
+__device__ __forceinline__ int fast_div5(int n, int d) {   // as igemm2.hip: float estimate + one correction (quotients below 2^22)
+    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
+    const int r = n - q * d;
+    if (r < 0) --q;
+    else if (r >= d) ++q;
+    return q;
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const int total_tiles) {
+    using namespace pers;
+    __shared__ __attribute__((aligned(16))) char smem[LDS];
+    constexpr int EPC = 8;                 // elements per 16 bytes
+    constexpr int BK = 64;
+    constexpr int RSTEP = 8 * NW;          // row distance between a wave's consecutive DMA pieces
+    typedef float f2 __attribute__((ext_vector_type(2)));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nblk = p.mtiles * p.ntiles;
+    const int nk = p.K / BK;               // host: K % BK == 0, nk >= 3
+
+    // ---- this workgroup's tile sequence: the tile range is cut into eight contiguous chunks (one per XCD, so that neighbouring
+    // tiles — same A rows, other N tile; same weights — share an L2), the workgroups of an XCD walk their chunk with stride nslots
+    const int nslots = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int q8 = total_tiles >> 3, r8 = total_tiles & 7;
+    const int cbeg = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int cend = cbeg + (xcd < r8 ? q8 + 1 : q8);
+    int u_dma = cbeg + slot;               // tile the LOADER works on (it runs up to two k-tiles ahead of the MFMAs)
+    if (u_dma >= cend) return;
+
+    // ---- loader mapping (igemm2.hip): one wave-instruction fills a 1-KiB piece = 8 rows x 8 sixteen-byte chunks
+    const int lrow = 8 * wave + (lane >> 3);
+    const int jc = (lane & 7) ^ ((lrow >> 1) & 7);
+    const bool plain_taps = MODE == 1 && p.zins <= 1 && p.hl == p.hin && p.wl == p.win;
+
+    unsigned int off1[4], off2[4];          // per-row byte offsets of the current tap in x1 / x2 (OOB if padded)
+    unsigned int cur_a[4], cur_b[2];        // byte offsets of the NEXT k-tile to issue (advanced by 128 B per k-tile)
+    unsigned int base1[4], base2[4];
+    int a_iy0[4], a_ix0[4], brel[4];
+    int tile_c = 0, ky = 0, kx = 0;
+    int d_m0 = 0, d_n0 = 0, d_zo = 0, d_zi = 0;   // coordinates of the loader's tile
+    bool dma_done = false;
+    __amdgpu_buffer_rsrc_t rs1, rs2, rsw, rsa;
+
+    auto setup_dma = [&](const int u) {     // address state of tile u (uniform u)
+        const int z = u / nblk, lid = u - z * nblk;
+        const int mt = lid / p.ntiles, nt = lid - mt * p.ntiles;
+        d_m0 = mt * BM; d_n0 = nt * BN;
+        d_zo = z / p.nzi; d_zi = z - d_zo * p.nzi;
+        const T* X1 = (const T*)p.x1 + d_zo * p.sa_o + d_zi * p.sa_i;
+        const T* W = (const T*)p.w + d_zo * p.sw_o + d_zi * p.sw_i;
+        const T* b1;
+        const T* b2 = (const T*)p.x2;
+        if (MODE == 0) {
+            b1 = X1 + (long)d_m0 * p.ldx1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur_a[i] = (unsigned)((lrow + RSTEP * i) * p.ldx1 + jc * EPC) * (unsigned)sizeof(T) - 128u;
+        } else {
+            const int hw = p.hout * p.wout;
+            const int b0 = d_m0 / hw;       // first image touched by this tile (uniform)
+            b1 = X1 + (long)b0 * p.hin * p.win * p.ldx1;
+            if (b2) b2 += (long)b0 * p.hin * p.win * p.ldx2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = d_m0 + lrow + RSTEP * i;
+                const int b = fast_div5(m, hw);
+                const int rem = m - b * hw;
+                const int oy = fast_div5(rem, p.wout), ox = rem - oy * p.wout;
+                brel[i] = b - b0;
+                a_iy0[i] = oy * p.stride - p.pad_t;
+                a_ix0[i] = ox * p.stride - p.pad_l;
+                cur_a[i] = 0;
+                if (plain_taps) {
+                    const unsigned pix0 = (unsigned)((brel[i] * p.hin + a_iy0[i]) * p.win + a_ix0[i]);   // wraps for padded taps; only used when valid
+                    base1[i] = (pix0 * (unsigned)p.ldx1 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T);
+                    base2[i] = (pix0 * (unsigned)p.ldx2 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T);
+                }
+            }
+        }
+        rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, RECORDS, 0x00020000);
+        rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(b2 ? b2 : b1), 0, RECORDS, 0x00020000);
+        rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)d_n0 * p.ldw), 0, RECORDS, 0x00020000);
+        rsa = rs1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = d_n0 + lrow + RSTEP * i;
+            cur_b[i] = (n < p.N ? (unsigned)((lrow + RSTEP * i) * p.ldw + jc * EPC) * (unsigned)sizeof(T) : OOB) - 128u;
+        }
+        tile_c = 0; ky = 0; kx = 0;
+    };
+    auto retap = [&]() {   // per-row pixel offsets of the current filter tap (uniform branch, once per tap)
+        if (plain_taps) {
+            const unsigned d1 = (unsigned)((ky * p.win + kx) * p.ldx1) * (unsigned)sizeof(T);
+            const unsigned d2 = (unsigned)((ky * p.win + kx) * p.ldx2) * (unsigned)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (unsigned)(a_iy0[i] + ky) < (unsigned)p.hl && (unsigned)(a_ix0[i] + kx) < (unsigned)p.wl;
+                off1[i] = ok ? base1[i] + d1 : OOB;
+                off2[i] = ok ? base2[i] + d2 : OOB;
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+            bool ok = (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
+            int sy = iy, sx = ix;
+            if (p.zins > 1) {
+                ok = ok && (iy % p.zins == 0) && (ix % p.zins == 0);
+                sy = iy / p.zins; sx = ix / p.zins;
+            } else {
+                if (p.hl != p.hin) sy = min((int)floorf(iy * p.up_sh), p.hin - 1);
+                if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
+            }
+            const unsigned pix = (unsigned)((brel[i] * p.hin + sy) * p.win + sx);
+            off1[i] = ok ? (pix * (unsigned)p.ldx1 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T) : OOB;
+            off2[i] = ok ? (pix * (unsigned)p.ldx2 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T) : OOB;
+        }
+    };
+    auto advance = [&]() {   // offsets / descriptor of the next k-tile to issue (k-tiles of a tile are issued in order)
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur_a[i] += 128u;
+        } else {
+            if (tile_c == 0) {
+                retap();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur_a[i] = off1[i];
+                rsa = rs1;
+            } else if (tile_c == p.c1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur_a[i] = off2[i];
+                rsa = rs2;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur_a[i] += 128u;
+            }
+            tile_c += BK;
+            if (tile_c >= p.cin) {
+                tile_c = 0;
+                if (++kx == p.kw) { kx = 0; ++ky; }
+            }
+        }
+        cur_b[0] += 128u;
+        cur_b[1] += 128u;
+    };
+    // ring: three stage offsets that rotate once per k-tile (s_cur: consumed now, s_nxt: consumed next, s_dst: receives k-tile + 2)
+    int s_cur = 0, s_nxt = STAGE, s_dst = 2 * STAGE;
+    auto rotate = [&]() { const int t = s_cur; s_cur = s_nxt; s_nxt = s_dst; s_dst = t; };
+    auto fire = [&](const int stage, auto piece_c) {
+        constexpr int Q = decltype(piece_c)::value;
+        char* sa = smem + stage + wave * 1024;
+        if constexpr (Q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lptr5_t)(sa + Q * (RSTEP * 128)), 16, cur_a[Q], 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr5_t)(sa + A_STAGE + (Q - 4) * (RSTEP * 128)), 16, cur_b[Q - 4], 0, 0, 0);
+    };
+    auto fire_all = [&](const int stage) {
+        fire(stage, IC5<0>{}); fire(stage, IC5<1>{}); fire(stage, IC5<2>{}); fire(stage, IC5<3>{});
+        fire(stage, IC5<4>{}); fire(stage, IC5<5>{});
+    };
+
+    floatx16 acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    // fragment byte offsets inside a stage (read-side swizzle as igemm2.hip)
+    const int sw = (l31 >> 1) & 7;
+    int aofs[4], bofs[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int chunk = g * 2 + h;
+        aofs[g] = (wm * 64 + l31) * 128 + ((chunk ^ sw) * 16);
+        bofs[g] = A_STAGE + (wn * 64 + l31) * 128 + ((chunk ^ sw) * 16);
+    }
+    auto mma_group = [&](const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1) {
+        acc[0][0] = Mma5<T>::run(a0, b0, acc[0][0]);
+        acc[0][1] = Mma5<T>::run(a0, b1, acc[0][1]);
+        acc[1][0] = Mma5<T>::run(a1, b0, acc[1][0]);
+        acc[1][1] = Mma5<T>::run(a1, b1, acc[1][1]);
+    };
+
+    // ---- epilogue operands requested ahead of their use
+    const int er = lane >> 3, ec = lane & 7;          // row inside an 8-row slice, 8-column chunk inside the wave's 64 columns
+    const T* __restrict__ bias = (const T*)p.bias;
+    const T* __restrict__ rowadd = (const T*)p.rowadd;
+    const bool has_res = p.residual != nullptr, has_ra = rowadd != nullptr, stats = p.gn_partial != nullptr;
+    Vec16<T> pre_res[4], pre_bias, pre_ra;            // residual rows of slices 0-3, bias and rowadd chunk of this lane
+    long c_orow = 0, c_rrow = 0;                       // element offsets of this lane's first output / residual row in the MFMA-side tile
+    int c_m0 = 0, c_n0 = 0;
+    bool c_colok = false;
+
+    // one k-tile.  KIND 0: steady state (the loader's next k-tile belongs to the same tile); 1: the loader has issued every k-tile of
+    // the current tile — no DMA between the MFMA groups, afterwards the loader moves to the workgroup's next tile and issues its first
+    // k-tile; 2: last k-tile of the tile — normal interleaved issue (if there is a next tile) plus the epilogue's operand requests.
+    // The synchronisation that opens k-tile g+1 (counted DMA wait + barrier) is issued in front of the LAST TWO MFMA groups of k-tile g —
+    // every LDS read of k-tile g has been requested by then, and the barrier skew of the eight waves disappears under 8 MFMAs (igemm2's
+    // unrolled loop gets the same placement from the compiler's scheduler; a rolled loop has to spell it out).  nextwait: 0 none,
+    // 1 vmcnt(0), 2 vmcnt(6).
+    auto ktile = [&](auto kind_c, const int nextwait) {
+        constexpr int KIND = decltype(kind_c)::value;
+        const bool more = KIND == 0 ? true : (KIND == 1 ? false : !dma_done);
+        if (more) advance();
+        const int sc = s_cur, sd = s_dst;
+        u32x4 a0[3], a1[3], b0[3], b1[3];
+        auto rd = [&](auto gc, auto slotc) {
+            constexpr int g = decltype(gc)::value, slot = decltype(slotc)::value;
+            a0[slot] = *reinterpret_cast<const u32x4*>(smem + sc + aofs[g]);
+            a1[slot] = *reinterpret_cast<const u32x4*>(smem + sc + aofs[g] + 32 * 128);
+            b0[slot] = *reinterpret_cast<const u32x4*>(smem + sc + bofs[g]);
+            b1[slot] = *reinterpret_cast<const u32x4*>(smem + sc + bofs[g] + 32 * 128);
+        };
+        rd(IC5<0>{}, IC5<0>{});
+        rd(IC5<1>{}, IC5<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        rd(IC5<2>{}, IC5<2>{});
+        if (more) { fire(sd, IC5<0>{}); fire(sd, IC5<1>{}); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(a0[0], a1[0], b0[0], b1[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(IC5<3>{}, IC5<0>{});
+        if (more) { fire(sd, IC5<2>{}); fire(sd, IC5<3>{}); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(a0[1], a1[1], b0[1], b1[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) { fire(sd, IC5<4>{}); fire(sd, IC5<5>{}); }
+        if constexpr (KIND == 2) {   // the epilogue's first operands: in flight under the last MFMAs
+            if (c_colok) {
+                if (has_res) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) pre_res[s] = ld16((const T*)p.residual + c_rrow + (long)(s * 8) * p.ldr);
+                }
+                if (bias) pre_bias = ld16(bias + c_n0 + wn * 64 + ec * 8);
+                if (has_ra) pre_ra = ld16(rowadd + (long)(c_m0 / p.rows_per_img) * p.N + c_n0 + wn * 64 + ec * 8);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (nextwait == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // lgkmcnt(0): this wave's reads of the current stage
+        else if (nextwait == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // have RETURNED before others may overwrite it
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(a0[2], a1[2], b0[2], b1[2]);
+        mma_group(a0[0], a1[0], b0[0], b1[0]);
+        if constexpr (KIND == 1) {   // the loader moves on: next tile's address state, then its first k-tile (all six pieces at once)
+            __builtin_amdgcn_sched_barrier(0);
+            u_dma += nslots;
+            if (u_dma < cend) {
+                setup_dma(u_dma);
+                advance();
+                fire_all(sd);
+            } else {
+                dma_done = true;
+            }
+        }
+        asm volatile("" ::: "memory");
+        rotate();
+    };
+
+    // ---- the epilogue of the MFMA-side tile (c_m0, c_n0): out = alpha * (acc + bias + rowadd[img]) + residual, eight slices per wave
+    auto epilogue = [&](const int sfree, const long zoff_o) {
+        // (opened by the barrier embedded in the last k-tile: every wave is done reading that k-tile, its stage is scratch now)
+        float* win = reinterpret_cast<float*>(smem + sfree + wave * 4096);   // two 2-KiB slice windows
+        // window layout: 16-byte unit U = ((x >> 2) & 1) * 64 + row * 8 + (x >> 3) for logical (row, column x): the row-wise readers take
+        // units `lane` and `64 + lane` (two conflict-free contiguous kilobytes), the accumulator lanes write 2-way (free on ds_write_b32)
+        const int wofs = ((l31 >> 2) & 1) * 256 + h * 128 + (l31 >> 3) * 4 + (l31 & 3);   // in floats; + e * 32 + j * 16
+        const float al = p.alpha;
+        T* __restrict__ out = (T*)p.out + zoff_o;
+        const T* __restrict__ res = (const T*)p.residual;   // c_rrow carries the batch offset
+        f2 bva2[4], ra2[4], pv2[4], sm2[4], sq2[4];
+        const f2 al2 = {al, al};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bva2[q] = bias ? f2{to_f(pre_bias.e[2 * q]) * al, to_f(pre_bias.e[2 * q + 1]) * al} : f2{0.f, 0.f};
+            ra2[q] = has_ra ? f2{to_f(pre_ra.e[2 * q]), to_f(pre_ra.e[2 * q + 1])} : f2{0.f, 0.f};
+            pv2[q] = f2{0.f, 0.f}; sm2[q] = f2{0.f, 0.f}; sq2[q] = f2{0.f, 0.f};
+        }
+        auto wr = [&](auto sc_) {
+            constexpr int s = decltype(sc_)::value, i = s >> 2, q = s & 3;
+            float* wb = win + (s & 1) * 512 + wofs;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wb[e * 32 + j * 16] = acc[i][j][4 * q + e];
+        };
+        Vec16<T> late_res[4];
+        auto slice = [&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            if constexpr (s < 7) wr(IC5<s + 1>{});
+            if constexpr (s == 0) {
+                if (has_res && c_colok) {   // residual rows of slices 4-7: consumed four slices from now
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) late_res[t] = ld16(res + c_rrow + (long)((4 + t) * 8) * p.ldr);
+                }
+            }
+            if constexpr (s == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's first two k-tiles (issued >= 1 k-tile + 4 slices ago) have landed
+            const float* rb = win + (s & 1) * 512 + lane * 4;
+            const floatx4 t0 = *reinterpret_cast<const floatx4*>(rb);
+            const floatx4 t1 = *reinterpret_cast<const floatx4*>(rb + 256);
+            f2 x2[4] = {f2{t0[0], t0[1]}, f2{t0[2], t0[3]}, f2{t1[0], t1[1]}, f2{t1[2], t1[3]}};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x2[q] = __builtin_elementwise_fma(x2[q], al2, bva2[q]);
+            if (has_ra) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x2[q] = __builtin_elementwise_fma(ra2[q], al2, x2[q]);
+            }
+            if (has_res) {
+                const Vec16<T>& rv = s < 4 ? pre_res[s & 3] : late_res[s & 3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x2[q] += f2{to_f(rv.e[2 * q]), to_f(rv.e[2 * q + 1])};
+            }
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = from_f<T>(x2[e >> 1][e & 1]);
+            if (c_colok) st16(out + c_orow + (long)(s * 8) * p.ldo, o);
+            if (stats) {
+                if constexpr (s == 0) {   // pivot: the wave's first row, broadcast down the eight row-lanes of every chunk
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pv2[q] = f2{__shfl(x2[q][0], ec, 64), __shfl(x2[q][1], ec, 64)};
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f2 d = x2[q] - pv2[q];
+                    sm2[q] += d;
+                    sq2[q] = __builtin_elementwise_fma(d, d, sq2[q]);
+                }
+            }
+        };
+        wr(IC5<0>{});
+        slice(IC5<0>{}); slice(IC5<1>{}); slice(IC5<2>{}); slice(IC5<3>{});
+        slice(IC5<4>{}); slice(IC5<5>{}); slice(IC5<6>{}); slice(IC5<7>{});
+        if (stats) {   // uniform.  16 values (8 sums, 8 sums of squares) over the 8 row-lanes of a chunk: reduce-scatter butterfly —
+            // each step a lane hands half of its values to its partner and adds the partner's other half (14 exchanges instead of 48)
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[2 * q] = sm2[q][0]; v[2 * q + 1] = sm2[q][1]; v[8 + 2 * q] = sq2[q][0]; v[8 + 2 * q + 1] = sq2[q][1]; }
+            const bool b0 = (er & 1) != 0, b1 = (er & 2) != 0, b2 = (er & 4) != 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float keep = b0 ? v[k + 8] : v[k], send = b0 ? v[k] : v[k + 8];
+                v[k] = keep + __shfl_xor(send, 8, 64);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float keep = b1 ? v[k + 4] : v[k], send = b1 ? v[k] : v[k + 4];
+                v[k] = keep + __shfl_xor(send, 16, 64);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float keep = b2 ? v[k + 2] : v[k], send = b2 ? v[k] : v[k + 2];
+                v[k] = keep + __shfl_xor(send, 32, 64);
+            }
+            // this lane now holds statistic (er & 1) of columns e0, e0 + 1 of its chunk, e0 = 4 * bit1 + 2 * bit2
+            const int e0 = ((er >> 1) & 1) * 4 + (er >> 2) * 2;
+            float pva[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pva[e] = pv2[e >> 1][e & 1];
+            const float pe0 = b1 ? (b2 ? pva[6] : pva[4]) : (b2 ? pva[2] : pva[0]);
+            const float pe1 = b1 ? (b2 ? pva[7] : pva[5]) : (b2 ? pva[3] : pva[1]);
+            float* d3 = reinterpret_cast<float*>(smem + RING) + (wave * 64 + ec * 8 + e0) * 3;
+            d3[(int)b0] = v[0];
+            d3[3 + (int)b0] = v[1];
+            if (!b0) { d3[2] = pe0; d3[5] = pe1; }
+        }
+    };
+    // merge of the four row-waves' deposits of tile (m0, n0), one thread per column (after a barrier that follows the deposits)
+    auto combine = [&](const int m0, const int n0) {
+        if (tid < BN && n0 + tid < p.N) {
+            const float* dep = reinterpret_cast<const float*>(smem + RING);
+            const int cw = tid >> 6, cc = tid & 63;
+            float mean = 0.f, m2 = 0.f, na = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                const float* d3 = dep + ((w4 * 2 + cw) * 64 + cc) * 3;
+                const float s1 = d3[0], s2 = d3[1], pv = d3[2];
+                const float mb = pv + s1 * (1.0f / 64.0f);
+                const float m2b = fmaxf(s2 - s1 * s1 * (1.0f / 64.0f), 0.f);
+                if (w4 == 0) { mean = mb; m2 = m2b; na = 64.f; }
+                else {
+                    const float nt = na + 64.f, dl = mb - mean;
+                    mean += dl * (64.f / nt);
+                    m2 += m2b + dl * dl * (na * 64.f / nt);
+                    na = nt;
+                }
+            }
+            const int img = m0 / p.rows_per_img;
+            const int slab = (m0 - img * p.rows_per_img) / BM;
+            float* o = p.gn_partial + (((long)img * p.gn_nslabs + slab) * p.N + n0 + tid) * 3;
+            o[0] = na; o[1] = mean; o[2] = m2;
+        }
+    };
+
+    // ================================ main ==========================================================================
+    setup_dma(u_dma);
+    advance(); fire_all(s_cur);
+    advance(); fire_all(s_nxt);
+    zero_acc();
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // k-tile 0 of the first tile
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bool first = true;
+    int tseq = 0;
+    (void)tseq;
+    for (;;) {
+        // the MFMA side enters the tile the loader is (still) on: nk >= 3 k-tiles, the loader is two ahead
+        c_m0 = d_m0; c_n0 = d_n0;
+        const long zoff_o = d_zo * p.so_o + d_zi * p.so_i, zoff_r = d_zo * p.sr_o + d_zi * p.sr_i;
+        c_colok = c_n0 + wn * 64 + ec * 8 < p.N;
+        {
+            const int m = c_m0 + wm * 64 + er;          // slice s adds 8 * s rows
+            const int n = c_n0 + wn * 64 + ec * 8;
+            c_orow = (long)m * p.ldo + n;
+            c_rrow = zoff_r + (long)m * p.ldr + n;
+        }
+        STAMP5(tseq, 0);
+        // embedded sync of k-tile kt opens k-tile kt + 1: after an epilogue the first two k-tiles are known to have landed
+        for (int kt = 0; kt < nk - 2; ++kt) ktile(IC5<0>{}, (!first && kt == 0) ? 0 : 2);
+        STAMP5(tseq, 1);
+        ktile(IC5<1>{}, 1);    // opens the last k-tile: nothing younger has been issued at that point
+        ktile(IC5<2>{}, 0);    // opens the epilogue: barrier only
+        STAMP5(tseq, 2);
+        // after the rotation of the last k-tile its stage is s_dst (the next DMA destination): scratch until the next barrier
+        epilogue(s_dst, zoff_o);
+        STAMP5(tseq, 3);
+        ++tseq;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // statistics deposits written; every slice window read
+        __builtin_amdgcn_s_barrier();                        // opens k-tile 0 of the next tile (its pieces landed before slice 4 of every wave)
+        asm volatile("" ::: "memory");
+        if (stats) combine(c_m0, c_n0);
+        if (dma_done) break;
+        zero_acc();
+        first = false;
+    }
+}
+
+static int g_pers_cus = 0;
+static long g_pers_launches = 0;   // debug counter (tests assert that the variant under test really ran)
+
+template <typename T, int MODE> static int launch5(IgemmParams& p, int nz, int total, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((igemm5_kernel<T, MODE>), dim3(grid), dim3(512), 0, s, p, total);
+    return check_launch("igemm5");
+}
+
+int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s) {
+    using namespace pers;
+    static const int enabled = [] { const char* e = getenv("E2EFT_PERSIST"); return e ? atoi(e) : 1; }();
+    if (!enabled) return -1;
+    if (dtype != E2EFT_F16 && dtype != E2EFT_BF16) return -1;
+    if (p.ksplit_taps > 0 || p.bias_along_m) return -1;
+    if (p.M % BM != 0 || p.K % 64 != 0 || p.K / 64 < 3) return -1;
+    if (p.N % 8 != 0 || p.ldo % 8 != 0 || (((uintptr_t)p.out) & 15) != 0) return -1;
+    if (p.residual && (p.ldr % 8 != 0 || (((uintptr_t)p.residual) & 15) != 0)) return -1;
+    if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return -1;
+    if (p.rowadd && ((((uintptr_t)p.rowadd) & 15) != 0 || (p.rows_per_img % BM != 0 && p.rows_per_img < p.M))) return -1;
+    if (nz > 1 && (p.so_o % 8 != 0 || p.so_i % 8 != 0 || p.sr_o % 8 != 0 || p.sr_i % 8 != 0)) return -1;
+    if (mode == 0) {
+        if ((long)256 * p.ldx1 * 2 >= 0x40000000L || (long)128 * p.ldw * 2 >= 0x40000000L) return -1;
+    } else {
+        const long img_bytes = (long)p.hin * p.win * (p.ldx1 > p.ldx2 ? p.ldx1 : p.ldx2) * 2;
+        const long span_imgs = 256 / ((long)p.hout * p.wout) + 2;
+        if (p.cin % 64 != 0 || p.c1 % 64 != 0 || img_bytes * span_imgs >= 0xD0000000L || (long)128 * p.ldw * 2 >= 0x40000000L) return -1;
+    }
+    if (g_pers_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return -1;
+        g_pers_cus = n & ~7;
+        if (const char* e = getenv("E2EFT_PERSIST_GRID")) {   // tests: a small grid sends small problems through the persistent kernel
+            const int g = atoi(e) & ~7;
+            if (g >= 8 && g <= g_pers_cus) g_pers_cus = g;
+        }
+    }
+    const int mtiles = p.M / BM, ntiles = cdiv(p.N, BN);
+    const long total = (long)mtiles * ntiles * nz;
+    if (total < 2L * g_pers_cus || total > 2000000000L) return -1;
+    p.mtiles = mtiles;
+    p.ntiles = ntiles;
+    if (p.gn_partial) {   // statistics need whole tiles inside one image
+        const bool ok = nz == 1 && p.rows_per_img % BM == 0 && p.M % p.rows_per_img == 0;
+        if (ok) p.gn_nslabs = p.rows_per_img / BM;
+        else p.gn_partial = nullptr;
+    }
+    ++g_pers_launches;
+    if (dtype == E2EFT_F16) return mode ? launch5<f16, 1>(p, nz, (int)total, g_pers_cus, s) : launch5<f16, 0>(p, nz, (int)total, g_pers_cus, s);
+    return mode ? launch5<bf16, 1>(p, nz, (int)total, g_pers_cus, s) : launch5<bf16, 0>(p, nz, (int)total, g_pers_cus, s);
+}
+
+}  // namespace e2eft
+
+#ifdef E2EFT_STAMPS
+extern "C" int e2eft_debug_read_stamps5(long long* host, int nworkgroups) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(e2eft::g_stamps5), (size_t)nworkgroups * 32 * 4 * sizeof(long long));
+}
+#endif
+extern "C" long e2eft_debug_persistent_launches(void) { return e2eft::g_pers_launches; }   // not part of include/e2eft.h
