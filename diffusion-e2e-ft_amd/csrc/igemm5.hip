@@ -30,7 +30,8 @@ constexpr int BM = 256, BN = 128, NW = 8;
 constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128, STAGE = A_STAGE + B_STAGE;
 constexpr int RING = 3 * STAGE;                  // 147,456 B
 constexpr int DEP = NW * 64 * 3 * 4;             // per-wave GroupNorm deposits: (sum, sum of squares, pivot) per column
-constexpr int LDS = RING + DEP;
+constexpr int ROWTAB = BM * 16;                  // (image, iy0, ix0, pixel) of the 256 output rows of the loader's NEXT tile, one thread per row
+constexpr int LDS = RING + DEP + ROWTAB;
 constexpr unsigned int OOB = 0xF0000000u;        // byte offset beyond RECORDS: the buffer load returns zeros
 constexpr unsigned int RECORDS = 0xE0000000u;
 }  // namespace pers
@@ -50,8 +51,8 @@ template <> struct Mma5<bf16> {
 #ifdef E2EFT_STAMPS
 // instrumented build: thread 0 of every workgroup records, for its first 32 tiles, the shader clock at: k-loop entry, after the steady
 // k-tiles, after the last k-tile (= epilogue entry), epilogue exit (scripts/stamp5_bench.py)
-static __device__ long long g_stamps5[512 * 32 * 4];
-#define STAMP5(t, i) do { if (threadIdx.x == 0 && (t) < 32 && blockIdx.x < 512) g_stamps5[(blockIdx.x * 32 + (t)) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
+static __device__ long long g_stamps5[512 * 32 * 8];
+#define STAMP5(t, i) do { if (threadIdx.x == 0 && (t) < 32 && blockIdx.x < 512) g_stamps5[(blockIdx.x * 32 + (t)) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP5(t, i) do { } while (0)
 #endif
@@ -107,11 +108,39 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     bool dma_done = false;
     __amdgpu_buffer_rsrc_t rs1, rs2, rsw, rsa;
 
-    auto setup_dma = [&](const int u) {     // address state of tile u (uniform u)
-        const int z = u / nblk, lid = u - z * nblk;
-        const int mt = lid / p.ntiles, nt = lid - mt * p.ntiles;
+    // Address state of the loader's next tile, in three steps so that the heavy part is not paid by every lane: (1) tile_coords —
+    // uniform; (2) fill_rowtab — ONE thread per output row (waves 0-3) splits the row index into (image, y, x) and leaves
+    // (image - b0, iy0, ix0, tap-(0,0) pixel) in LDS; (3) after a barrier finish_setup — every loader lane picks up its four rows
+    // (one ds_read_b128 each) and derives byte offsets and descriptors.  (Doing the split per loader lane cost ~4k cycles per tile:
+    // 8 float-reciprocal divisions x 8 waves beside 4 integer divisions of uniform values.)
+    int d_b0 = 0;
+    auto tile_coords = [&](const int u) {
+        int z = 0, lid = u;
+        if (nblk != total_tiles) { z = fast_div5(u, nblk); lid = u - z * nblk; }
+        int mt = lid, nt = 0;
+        if (p.ntiles > 1) { mt = fast_div5(lid, p.ntiles); nt = lid - mt * p.ntiles; }
         d_m0 = mt * BM; d_n0 = nt * BN;
-        d_zo = z / p.nzi; d_zi = z - d_zo * p.nzi;
+        d_zo = 0; d_zi = z;
+        if (p.nzi > 1 && z > 0) { d_zo = fast_div5(z, p.nzi); d_zi = z - d_zo * p.nzi; }
+        else if (p.nzi == 1) { d_zo = z; d_zi = 0; }
+        if (MODE == 1) d_b0 = fast_div5(d_m0, p.hout * p.wout);   // first image touched by this tile
+    };
+    // (the row table is written / read with inline-asm DS instructions: in front of LDS accesses it can see, the compiler drains
+    // vmcnt — it has to assume that a pending LDS-DMA may alias them — and here pieces / stores are in flight by design)
+    auto fill_rowtab = [&]() {
+        if (MODE == 1 && tid < BM) {
+            const int hw = p.hout * p.wout;
+            const int m = d_m0 + tid;
+            const int b = fast_div5(m, hw);
+            const int rem = m - b * hw;
+            const int oy = fast_div5(rem, p.wout), ox = rem - oy * p.wout;
+            const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+            const u32x4 v = {(unsigned)(b - d_b0), (unsigned)iy0, (unsigned)ix0, (unsigned)(((b - d_b0) * p.hin + iy0) * p.win + ix0)};
+            const unsigned addr = (unsigned)(RING + DEP) + (unsigned)tid * 16u;
+            asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory");
+        }
+    };
+    auto finish_setup = [&]() {
         const T* X1 = (const T*)p.x1 + d_zo * p.sa_o + d_zi * p.sa_i;
         const T* W = (const T*)p.w + d_zo * p.sw_o + d_zi * p.sw_i;
         const T* b1;
@@ -121,24 +150,22 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur_a[i] = (unsigned)((lrow + RSTEP * i) * p.ldx1 + jc * EPC) * (unsigned)sizeof(T) - 128u;
         } else {
-            const int hw = p.hout * p.wout;
-            const int b0 = d_m0 / hw;       // first image touched by this tile (uniform)
-            b1 = X1 + (long)b0 * p.hin * p.win * p.ldx1;
-            if (b2) b2 += (long)b0 * p.hin * p.win * p.ldx2;
+            b1 = X1 + (long)d_b0 * p.hin * p.win * p.ldx1;
+            if (b2) b2 += (long)d_b0 * p.hin * p.win * p.ldx2;
+            u32x4 rt[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int m = d_m0 + lrow + RSTEP * i;
-                const int b = fast_div5(m, hw);
-                const int rem = m - b * hw;
-                const int oy = fast_div5(rem, p.wout), ox = rem - oy * p.wout;
-                brel[i] = b - b0;
-                a_iy0[i] = oy * p.stride - p.pad_t;
-                a_ix0[i] = ox * p.stride - p.pad_l;
+                const unsigned addr = (unsigned)(RING + DEP) + (unsigned)(lrow + RSTEP * i) * 16u;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(rt[i]) : "v"(addr) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rt[0]), "+v"(rt[1]), "+v"(rt[2]), "+v"(rt[3]) :: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                brel[i] = (int)rt[i][0]; a_iy0[i] = (int)rt[i][1]; a_ix0[i] = (int)rt[i][2];
                 cur_a[i] = 0;
-                if (plain_taps) {
-                    const unsigned pix0 = (unsigned)((brel[i] * p.hin + a_iy0[i]) * p.win + a_ix0[i]);   // wraps for padded taps; only used when valid
-                    base1[i] = (pix0 * (unsigned)p.ldx1 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T);
-                    base2[i] = (pix0 * (unsigned)p.ldx2 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T);
+                if (plain_taps) {   // pixel index wraps for padded taps; only used when valid
+                    base1[i] = (rt[i][3] * (unsigned)p.ldx1 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T);
+                    base2[i] = (rt[i][3] * (unsigned)p.ldx2 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T);
                 }
             }
         }
@@ -223,6 +250,8 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         fire(stage, IC5<4>{}); fire(stage, IC5<5>{});
     };
 
+    int tseq = 0;
+    (void)tseq;
     floatx16 acc[2][2];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -255,20 +284,42 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     const bool has_res = p.residual != nullptr, has_ra = rowadd != nullptr, stats = p.gn_partial != nullptr;
     Vec16<T> pre_res[4], pre_bias, pre_ra;            // residual rows of slices 0-3, bias and rowadd chunk of this lane
     long c_orow = 0, c_rrow = 0;                       // element offsets of this lane's first output / residual row in the MFMA-side tile
-    int c_m0 = 0, c_n0 = 0;
+    int c_m0 = 0, c_n0 = 0, c_img = 0, c_ncl = 0;
     bool c_colok = false;
 
-    // one k-tile.  KIND 0: steady state (the loader's next k-tile belongs to the same tile); 1: the loader has issued every k-tile of
-    // the current tile — no DMA between the MFMA groups, afterwards the loader moves to the workgroup's next tile and issues its first
-    // k-tile; 2: last k-tile of the tile — normal interleaved issue (if there is a next tile) plus the epilogue's operand requests.
+    // one k-tile.  KIND 0: steady state; 1: the loader has issued every k-tile of the current tile — at the top the epilogue's first
+    // operands are requested (BEFORE the next tile's pieces: memory returns in order, and their wait must not cover the pieces) and the
+    // loader's address state moves to the workgroup's next tile (row table filled at the top of the current tile), then the k-tile
+    // runs like any other with the next tile's first k-tile as its interleaved issue; 2: last k-tile.  Every kind issues six pieces
+    // (out-of-range offsets = zeros into a stage nobody reads when the workgroup has no further tile): with an unconditional VMEM
+    // sequence the waits can count — the compiler's own s_waitcnt for the epilogue operands is vmcnt(12), not a drain.
     // The synchronisation that opens k-tile g+1 (counted DMA wait + barrier) is issued in front of the LAST TWO MFMA groups of k-tile g —
     // every LDS read of k-tile g has been requested by then, and the barrier skew of the eight waves disappears under 8 MFMAs (igemm2's
     // unrolled loop gets the same placement from the compiler's scheduler; a rolled loop has to spell it out).  nextwait: 0 none,
-    // 1 vmcnt(0), 2 vmcnt(6).
+    // 2 vmcnt(6), 3 vmcnt(6 + NPRE) with NPRE = the operand requests issued at the top of a KIND-1 k-tile.
+    const int npre = (has_res ? 4 : 0) + (bias ? 1 : 0) + (has_ra ? 1 : 0);
+    bool nxt = false;                                  // the workgroup has a tile after the current one (set at the top of a tile)
     auto ktile = [&](auto kind_c, const int nextwait) {
         constexpr int KIND = decltype(kind_c)::value;
-        const bool more = KIND == 0 ? true : (KIND == 1 ? false : !dma_done);
-        if (more) advance();
+        if constexpr (KIND == 1) {
+            // every lane requests (columns beyond N read the tile's first chunk instead: the count of VMEM instructions must not depend on exec)
+            if (has_res) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) pre_res[s] = ld16((const T*)p.residual + c_rrow + (long)(s * 8) * p.ldr);
+            }
+            if (bias) pre_bias = ld16(bias + c_ncl);
+            if (has_ra) pre_ra = ld16(rowadd + (long)c_img * p.N + c_ncl);
+            u_dma += nslots;
+            if (nxt) {
+                finish_setup();
+            } else {
+                dma_done = true;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur_a[i] = OOB;
+                cur_b[0] = cur_b[1] = OOB;
+            }
+        }
+        if (KIND == 0 || !dma_done) advance();
         const int sc = s_cur, sd = s_dst;
         u32x4 a0[3], a1[3], b0[3], b1[3];
         auto rd = [&](auto gc, auto slotc) {
@@ -282,46 +333,32 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         rd(IC5<1>{}, IC5<1>{});
         __builtin_amdgcn_sched_barrier(0);
         rd(IC5<2>{}, IC5<2>{});
-        if (more) { fire(sd, IC5<0>{}); fire(sd, IC5<1>{}); }
+        fire(sd, IC5<0>{}); fire(sd, IC5<1>{});
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[0], a1[0], b0[0], b1[0]);
         __builtin_amdgcn_sched_barrier(0);
         rd(IC5<3>{}, IC5<0>{});
-        if (more) { fire(sd, IC5<2>{}); fire(sd, IC5<3>{}); }
+        fire(sd, IC5<2>{}); fire(sd, IC5<3>{});
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[1], a1[1], b0[1], b1[1]);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) { fire(sd, IC5<4>{}); fire(sd, IC5<5>{}); }
-        if constexpr (KIND == 2) {   // the epilogue's first operands: in flight under the last MFMAs
-            if (c_colok) {
-                if (has_res) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) pre_res[s] = ld16((const T*)p.residual + c_rrow + (long)(s * 8) * p.ldr);
-                }
-                if (bias) pre_bias = ld16(bias + c_n0 + wn * 64 + ec * 8);
-                if (has_ra) pre_ra = ld16(rowadd + (long)(c_m0 / p.rows_per_img) * p.N + c_n0 + wn * 64 + ec * 8);
-            }
-        }
+        fire(sd, IC5<4>{}); fire(sd, IC5<5>{});
         __builtin_amdgcn_sched_barrier(0);
-        if (nextwait == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // lgkmcnt(0): this wave's reads of the current stage
-        else if (nextwait == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // have RETURNED before others may overwrite it
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // lgkmcnt(0): this wave's reads of the current stage have RETURNED before the barrier lets others overwrite it
+        if (nextwait == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else if (nextwait == 3) {
+            if (npre == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if (npre == 1) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+            else if (npre == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (npre == 4) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+            else if (npre == 5) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[2], a1[2], b0[2], b1[2]);
         mma_group(a0[0], a1[0], b0[0], b1[0]);
-        if constexpr (KIND == 1) {   // the loader moves on: next tile's address state, then its first k-tile (all six pieces at once)
-            __builtin_amdgcn_sched_barrier(0);
-            u_dma += nslots;
-            if (u_dma < cend) {
-                setup_dma(u_dma);
-                advance();
-                fire_all(sd);
-            } else {
-                dma_done = true;
-            }
-        }
         asm volatile("" ::: "memory");
         rotate();
     };
@@ -356,13 +393,15 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         auto slice = [&](auto sc_) {
             constexpr int s = decltype(sc_)::value;
             if constexpr (s < 7) wr(IC5<s + 1>{});
-            if constexpr (s == 0) {
-                if (has_res && c_colok) {   // residual rows of slices 4-7: consumed four slices from now
+            if constexpr (s == 1) {
+                if (has_res) {   // residual rows of slices 4-7: consumed three slices from now
 #pragma unroll
                     for (int t = 0; t < 4; ++t) late_res[t] = ld16(res + c_rrow + (long)((4 + t) * 8) * p.ldr);
                 }
             }
-            if constexpr (s == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's first two k-tiles (issued >= 1 k-tile + 4 slices ago) have landed
+            // the next tile's first two k-tiles (issued >= 1 k-tile + 4 slices ago) have landed.  The BUILTIN, not inline asm: the compiler's
+            // waitcnt pass then knows that nothing is pending and does not drain again in front of later register / LDS reuse
+            if constexpr (s == 4) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
             const float* rb = win + (s & 1) * 512 + lane * 4;
             const floatx4 t0 = *reinterpret_cast<const floatx4*>(rb);
             const floatx4 t1 = *reinterpret_cast<const floatx4*>(rb + 256);
@@ -396,7 +435,10 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
             }
         };
         wr(IC5<0>{});
-        slice(IC5<0>{}); slice(IC5<1>{}); slice(IC5<2>{}); slice(IC5<3>{});
+        slice(IC5<0>{});
+        STAMP5(tseq, 5);
+        slice(IC5<1>{}); slice(IC5<2>{}); slice(IC5<3>{});
+        STAMP5(tseq, 6);
         slice(IC5<4>{}); slice(IC5<5>{}); slice(IC5<6>{}); slice(IC5<7>{});
         if (stats) {   // uniform.  16 values (8 sums, 8 sums of squares) over the 8 row-lanes of a chunk: reduce-scatter butterfly —
             // each step a lane hands half of its values to its partner and adds the partner's other half (14 exchanges instead of 48)
@@ -460,7 +502,10 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     };
 
     // ================================ main ==========================================================================
-    setup_dma(u_dma);
+    tile_coords(u_dma);
+    fill_rowtab();
+    __syncthreads();
+    finish_setup();
     advance(); fire_all(s_cur);
     advance(); fire_all(s_nxt);
     zero_acc();
@@ -468,24 +513,30 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     bool first = true;
-    int tseq = 0;
-    (void)tseq;
     for (;;) {
         // the MFMA side enters the tile the loader is (still) on: nk >= 3 k-tiles, the loader is two ahead
         c_m0 = d_m0; c_n0 = d_n0;
         const long zoff_o = d_zo * p.so_o + d_zi * p.so_i, zoff_r = d_zo * p.sr_o + d_zi * p.sr_i;
         c_colok = c_n0 + wn * 64 + ec * 8 < p.N;
+        c_ncl = c_colok ? c_n0 + wn * 64 + ec * 8 : c_n0;
+        c_img = has_ra ? fast_div5(c_m0, p.rows_per_img) : 0;
         {
             const int m = c_m0 + wm * 64 + er;          // slice s adds 8 * s rows
-            const int n = c_n0 + wn * 64 + ec * 8;
-            c_orow = (long)m * p.ldo + n;
-            c_rrow = zoff_r + (long)m * p.ldr + n;
+            c_orow = (long)m * p.ldo + c_ncl;
+            c_rrow = zoff_r + (long)m * p.ldr + c_ncl;
+        }
+        // the workgroup's next tile: coordinates now, row table now (consumed at the top of this tile's last-but-one k-tile)
+        nxt = u_dma + nslots < cend;
+        if (nxt) {
+            tile_coords(u_dma + nslots);
+            fill_rowtab();
         }
         STAMP5(tseq, 0);
         // embedded sync of k-tile kt opens k-tile kt + 1: after an epilogue the first two k-tiles are known to have landed
         for (int kt = 0; kt < nk - 2; ++kt) ktile(IC5<0>{}, (!first && kt == 0) ? 0 : 2);
         STAMP5(tseq, 1);
-        ktile(IC5<1>{}, 1);    // opens the last k-tile: nothing younger has been issued at that point
+        ktile(IC5<1>{}, 3);    // opens the last k-tile: younger = this k-tile's operand requests + the next tile's first pieces
+        STAMP5(tseq, 4);
         ktile(IC5<2>{}, 0);    // opens the epilogue: barrier only
         STAMP5(tseq, 2);
         // after the rotation of the last k-tile its stage is s_dst (the next DMA destination): scratch until the next barrier
@@ -496,6 +547,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         __builtin_amdgcn_s_barrier();                        // opens k-tile 0 of the next tile (its pieces landed before slice 4 of every wave)
         asm volatile("" ::: "memory");
         if (stats) combine(c_m0, c_n0);
+        STAMP5(tseq - 1, 7);
         if (dma_done) break;
         zero_acc();
         first = false;
@@ -557,7 +609,7 @@ int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStre
 
 #ifdef E2EFT_STAMPS
 extern "C" int e2eft_debug_read_stamps5(long long* host, int nworkgroups) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(e2eft::g_stamps5), (size_t)nworkgroups * 32 * 4 * sizeof(long long));
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(e2eft::g_stamps5), (size_t)nworkgroups * 32 * 8 * sizeof(long long));
 }
 #endif
 extern "C" long e2eft_debug_persistent_launches(void) { return e2eft::g_pers_launches; }   // not part of include/e2eft.h

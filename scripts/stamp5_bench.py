@@ -26,18 +26,19 @@ for _ in range(int(os.environ.get("WARM", "20"))):
 torch.cuda.synchronize()
 lib = _lib.load()
 nwg = 256
-buf = (ctypes.c_longlong * (nwg * 32 * 4))()
+buf = (ctypes.c_longlong * (nwg * 32 * 8))()
 lib.e2eft_debug_read_stamps5.restype = ctypes.c_int
 assert lib.e2eft_debug_read_stamps5(buf, nwg) == 0
-s = np.frombuffer(buf, dtype=np.int64).reshape(nwg, 32, 4)
+s = np.frombuffer(buf, dtype=np.int64).reshape(nwg, 32, 8)
 ntile = ((B * H * W) // 256) * ((Co + 127) // 128)
 per = min(32, ntile // 256)
 nk = k * k * Ci // 64
 t = s[:, 1:per - 1, :]            # steady tiles (not the first, not the last)
 print("conv%dx%d B%d %dx%d %d->%d res=%d stats=%d: %d tiles, %d per workgroup, %d k-tiles" % (k, k, B, H, W, Ci, Co, res, stats, ntile, ntile // 256, nk))
 print("steady k-tiles (0 .. nk-3)        mean %8.0f cycles = %.0f / k-tile" % ((t[:, :, 1] - t[:, :, 0]).mean(), (t[:, :, 1] - t[:, :, 0]).mean() / (nk - 2)))
-print("last two k-tiles (switch + last)  mean %8.0f cycles" % (t[:, :, 2] - t[:, :, 1]).mean())
-print("epilogue                          mean %8.0f cycles" % (t[:, :, 3] - t[:, :, 2]).mean())
+print("last two k-tiles (switch + last)  mean %8.0f cycles = switch %.0f + last %.0f" % ((t[:, :, 2] - t[:, :, 1]).mean(), (t[:, :, 4] - t[:, :, 1]).mean(), (t[:, :, 2] - t[:, :, 4]).mean()))
+print("epilogue                          mean %8.0f cycles = slice 0 %.0f + slices 1-3 %.0f + slices 4-7 and statistics %.0f" % ((t[:, :, 3] - t[:, :, 2]).mean(), (t[:, :, 5] - t[:, :, 2]).mean(), (t[:, :, 6] - t[:, :, 5]).mean(), (t[:, :, 3] - t[:, :, 6]).mean()))
+print("barrier + statistics merge        mean %8.0f cycles" % (t[:, :, 7] - t[:, :, 3]).mean())
 nxt = s[:, 2:per, 0] - s[:, 1:per - 1, 3]
 print("epilogue exit -> next k-loop      mean %8.0f cycles" % nxt.mean())
 print("tile period                       mean %8.0f cycles" % (s[:, 2:per, 0] - s[:, 1:per - 1, 0]).mean())
