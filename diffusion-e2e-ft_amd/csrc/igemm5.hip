@@ -253,14 +253,6 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     int tseq = 0;
     (void)tseq;
     floatx16 acc[2][2];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    };
     // fragment byte offsets inside a stage (read-side swizzle as igemm2.hip)
     const int sw = (l31 >> 1) & 7;
     int aofs[4], bofs[4];
@@ -299,27 +291,23 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     // 2 vmcnt(6), 3 vmcnt(6 + NPRE) with NPRE = the operand requests issued at the top of a KIND-1 k-tile.
     const int npre = (has_res ? 4 : 0) + (bias ? 1 : 0) + (has_ra ? 1 : 0);
     bool nxt = false;                                  // the workgroup has a tile after the current one (set at the top of a tile)
+    long zoff_o = 0;
+    auto enter_tile = [&]() {   // the MFMA side enters the tile the loader is (still) on; then the loader's coordinates move to the workgroup's next tile
+        c_m0 = d_m0; c_n0 = d_n0;
+        zoff_o = d_zo * p.so_o + d_zi * p.so_i;
+        const long zoff_r = d_zo * p.sr_o + d_zi * p.sr_i;
+        c_colok = c_n0 + wn * 64 + ec * 8 < p.N;
+        c_ncl = c_colok ? c_n0 + wn * 64 + ec * 8 : c_n0;
+        c_img = has_ra ? fast_div5(c_m0, p.rows_per_img) : 0;
+        const int m = c_m0 + wm * 64 + er;          // slice s adds 8 * s rows
+        c_orow = (long)m * p.ldo + c_ncl;
+        c_rrow = zoff_r + (long)m * p.ldr + c_ncl;
+        nxt = u_dma + nslots < cend;
+        if (nxt) tile_coords(u_dma + nslots);
+    };
     auto ktile = [&](auto kind_c, const int nextwait) {
         constexpr int KIND = decltype(kind_c)::value;
-        if constexpr (KIND == 1) {
-            // every lane requests (columns beyond N read the tile's first chunk instead: the count of VMEM instructions must not depend on exec)
-            if (has_res) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) pre_res[s] = ld16((const T*)p.residual + c_rrow + (long)(s * 8) * p.ldr);
-            }
-            if (bias) pre_bias = ld16(bias + c_ncl);
-            if (has_ra) pre_ra = ld16(rowadd + (long)c_img * p.N + c_ncl);
-            u_dma += nslots;
-            if (nxt) {
-                finish_setup();
-            } else {
-                dma_done = true;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cur_a[i] = OOB;
-                cur_b[0] = cur_b[1] = OOB;
-            }
-        }
-        if (KIND == 0 || !dma_done) advance();
+        if (KIND == 0 || KIND == 3 || (KIND == 2 && !dma_done)) advance();
         const int sc = s_cur, sd = s_dst;
         u32x4 a0[3], a1[3], b0[3], b1[3];
         auto rd = [&](auto gc, auto slotc) {
@@ -333,16 +321,49 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         rd(IC5<1>{}, IC5<1>{});
         __builtin_amdgcn_sched_barrier(0);
         rd(IC5<2>{}, IC5<2>{});
-        fire(sd, IC5<0>{}); fire(sd, IC5<1>{});
+        if constexpr (KIND != 1) { fire(sd, IC5<0>{}); fire(sd, IC5<1>{}); }
         __builtin_amdgcn_sched_barrier(0);
-        mma_group(a0[0], a1[0], b0[0], b1[0]);
+        if constexpr (KIND == 3) {   // first k-tile of a tile: the accumulators start from the constant 0 (no 64 v_mov per tile)
+            const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[0][0] = Mma5<T>::run(a0[0], b0[0], z);
+            acc[0][1] = Mma5<T>::run(a0[0], b1[0], z);
+            acc[1][0] = Mma5<T>::run(a1[0], b0[0], z);
+            acc[1][1] = Mma5<T>::run(a1[0], b1[0], z);
+        } else {
+            mma_group(a0[0], a1[0], b0[0], b1[0]);
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KIND == 3) enter_tile();   // index arithmetic of this tile's epilogue and of the next tile: under the first MFMAs
+        if constexpr (KIND == 1) {
+            // every lane requests (columns beyond N read the tile's first chunk instead: the count of VMEM instructions must not depend on exec)
+            if (has_res) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) pre_res[s] = ld16((const T*)p.residual + c_rrow + (long)(s * 8) * p.ldr);
+            }
+            if (bias) pre_bias = ld16(bias + c_ncl);
+            if (has_ra) pre_ra = ld16(rowadd + (long)c_img * p.N + c_ncl);
+            u_dma += nslots;
+            if (nxt) {
+                finish_setup();
+                advance();
+            } else {
+                dma_done = true;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur_a[i] = OOB;
+                cur_b[0] = cur_b[1] = OOB;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fire(sd, IC5<0>{}); fire(sd, IC5<1>{});
+        }
         rd(IC5<3>{}, IC5<0>{});
         fire(sd, IC5<2>{}); fire(sd, IC5<3>{});
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[1], a1[1], b0[1], b1[1]);
         __builtin_amdgcn_sched_barrier(0);
         fire(sd, IC5<4>{}); fire(sd, IC5<5>{});
+        if constexpr (KIND == 3) {
+            if (nxt) fill_rowtab();   // consumed in this tile's last-but-one k-tile
+        }
         __builtin_amdgcn_sched_barrier(0);
         // lgkmcnt(0): this wave's reads of the current stage have RETURNED before the barrier lets others overwrite it
         if (nextwait == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
@@ -508,32 +529,15 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     finish_setup();
     advance(); fire_all(s_cur);
     advance(); fire_all(s_nxt);
-    zero_acc();
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // k-tile 0 of the first tile
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     bool first = true;
     for (;;) {
-        // the MFMA side enters the tile the loader is (still) on: nk >= 3 k-tiles, the loader is two ahead
-        c_m0 = d_m0; c_n0 = d_n0;
-        const long zoff_o = d_zo * p.so_o + d_zi * p.so_i, zoff_r = d_zo * p.sr_o + d_zi * p.sr_i;
-        c_colok = c_n0 + wn * 64 + ec * 8 < p.N;
-        c_ncl = c_colok ? c_n0 + wn * 64 + ec * 8 : c_n0;
-        c_img = has_ra ? fast_div5(c_m0, p.rows_per_img) : 0;
-        {
-            const int m = c_m0 + wm * 64 + er;          // slice s adds 8 * s rows
-            c_orow = (long)m * p.ldo + c_ncl;
-            c_rrow = zoff_r + (long)m * p.ldr + c_ncl;
-        }
-        // the workgroup's next tile: coordinates now, row table now (consumed at the top of this tile's last-but-one k-tile)
-        nxt = u_dma + nslots < cend;
-        if (nxt) {
-            tile_coords(u_dma + nslots);
-            fill_rowtab();
-        }
         STAMP5(tseq, 0);
         // embedded sync of k-tile kt opens k-tile kt + 1: after an epilogue the first two k-tiles are known to have landed
-        for (int kt = 0; kt < nk - 2; ++kt) ktile(IC5<0>{}, (!first && kt == 0) ? 0 : 2);
+        ktile(IC5<3>{}, first ? 2 : 0);
+        for (int kt = 1; kt < nk - 2; ++kt) ktile(IC5<0>{}, 2);
         STAMP5(tseq, 1);
         ktile(IC5<1>{}, 3);    // opens the last k-tile: younger = this k-tile's operand requests + the next tile's first pieces
         STAMP5(tseq, 4);
@@ -549,7 +553,6 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         if (stats) combine(c_m0, c_n0);
         STAMP5(tseq - 1, 7);
         if (dma_done) break;
-        zero_acc();
         first = false;
     }
 }

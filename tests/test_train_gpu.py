@@ -244,17 +244,22 @@ def test_gradient_checkpointing_gives_bit_equal_gradients_and_saves_memory(dev, 
         torch.cuda.reset_peak_memory_stats()
         base = torch.cuda.memory_allocated()
         loss = (training.geowizard_e2e_ft_loss(unet, vae, batch, emb, "indoor") if geo else training.e2e_ft_loss(unet, vae, batch, emb, "depth"))
+        torch.cuda.synchronize()
+        held = torch.cuda.memory_allocated() - base      # what the forward pass keeps alive for the backward pass
         loss.backward()
         torch.cuda.synchronize()
         peak = torch.cuda.max_memory_allocated() - base
-        return loss.item(), {k: p.grad.clone() for k, p in unet.named_parameters()}, peak
+        return loss.item(), {k: p.grad.clone() for k, p in unet.named_parameters()}, peak, held
 
-    l0, g0, m0 = run(False)
-    l1, g1, m1 = run(True)
+    l0, g0, m0, h0 = run(False)
+    l1, g1, m1, h1 = run(True)
     assert l0 == l1
     assert all(torch.equal(g0[k], g1[k]) for k in g0), [k for k in g0 if not torch.equal(g0[k], g1[k])][:5]
-    print("peak step memory: %.1f MB kept, %.1f MB with recompute" % (m0 / 2 ** 20, m1 / 2 ** 20))
-    assert m1 < 0.8 * m0, (m0, m1)
+    print("kept by the forward pass: %.1f MB / %.1f MB with recompute; peak of the step: %.1f MB / %.1f MB" % (h0 / 2 ** 20, h1 / 2 ** 20, m0 / 2 ** 20, m1 / 2 ** 20))
+    # the activations held between forward and backward shrink (at this toy size the PEAK is set by the backward pass's transient
+    # weight-gradient operands, which recompute does not touch: bench.py --train --grad-ckpt reports the full-size peaks, 123.7 -> 54.8 GiB)
+    assert h1 < 0.8 * h0, (h0, h1)
+    assert m1 <= m0, (m0, m1)
     # eval mode: the switch is inert (the reference checks `self.training and self.gradient_checkpointing`)
     unet, vae = _models(dev)
     unet.enable_gradient_checkpointing()
