@@ -413,13 +413,13 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         Vec16<T> late_res[4];
         auto slice = [&](auto sc_) {
             constexpr int s = decltype(sc_)::value;
-            if constexpr (s < 7) wr(IC5<s + 1>{});
-            if constexpr (s == 1) {
-                if (has_res) {   // residual rows of slices 4-7: consumed three slices from now
+            if constexpr (s == 0) {
+                if (has_res) {   // residual rows of slices 4-7: consumed four slices from now
 #pragma unroll
                     for (int t = 0; t < 4; ++t) late_res[t] = ld16(res + c_rrow + (long)((4 + t) * 8) * p.ldr);
                 }
             }
+            if constexpr (s < 7) wr(IC5<s + 1>{});
             // the next tile's first two k-tiles (issued >= 1 k-tile + 4 slices ago) have landed.  The BUILTIN, not inline asm: the compiler's
             // waitcnt pass then knows that nothing is pending and does not drain again in front of later register / LDS reuse
             if constexpr (s == 4) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
