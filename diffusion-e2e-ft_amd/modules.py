@@ -121,7 +121,9 @@ class ResnetBlock2D(nn.Module):
             h, x = self.norm1.nhwc(x, silu=True, split=True)     # x: the same tensor, routed through the norm for its gradient
         else:
             h = self.norm1.nhwc(x, x2=x2, silu=True)
-        rowadd = self.time_emb_proj(temb_act) if self.time_emb_proj is not None else None
+        rowadd = self.__dict__.pop("_rowadd_pre", None)     # inference: projected for all blocks at once (unet.py::_batch_small_gemms)
+        if rowadd is None and self.time_emb_proj is not None:
+            rowadd = self.time_emb_proj(temb_act)
         h = conv_nhwc(self.conv1, h, rowadd=rowadd)
         h = self.norm2.nhwc(h, silu=True)
         if self.conv_shortcut is not None:
@@ -225,7 +227,9 @@ class Attention(nn.Module):
                 q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
             else:
                 q = self.to_q(x)
-                kv = F.linear(ctx, (self.to_k.weight, self.to_v.weight), owner=self, name="wkv")
+                kv = self.__dict__.pop("_kv_pre", None)         # inference: keys / values of the (shared) context for all layers at once
+                if kv is None:
+                    kv = F.linear(ctx, (self.to_k.weight, self.to_v.weight), owner=self, name="wkv")
                 k, v = kv[..., :C], kv[..., C:]
             a = ops.attention(q, k, v, self.heads, self.scale, kv_nseg=2 if self.joint else 1, kv_bmod=B // 2 if self.joint else B)
         else:

@@ -1,7 +1,11 @@
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -8 > gpurun_out/r02b_gpu_tests.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -3 >> gpurun_out/r02b_gpu_tests.log
-timeout 600 python scripts/soak_determinism.py 2>&1 | tail -4 > gpurun_out/r02b_soak.log
-timeout 600 python scripts/stress_conv_stats.py 2>&1 | tail -4 >> gpurun_out/r02b_soak.log
-for pe in 1 0; do echo -n "PERSIST=$pe res " ; E2EFT_PERSIST=$pe timeout 120 python scripts/conv_bench.py 8 768 768 128 128 3 30 fp16 1 2>&1 | tail -1; done >> gpurun_out/r02b_soak.log
-cat gpurun_out/r02b_gpu_tests.log gpurun_out/r02b_soak.log
+timeout 900 python -m pytest tests/test_fullsize_parity_gpu.py tests/test_model_gpu.py -x -q -m gpu -k "batched or unet or pipeline or geowizard" 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -5 > gpurun_out/batched_test.txt
+for pe in 1 0 1 0; do
+  E2EFT_BATCHED_PROJ=$pe timeout 600 python bench.py --steps 15 --warmup 4 --no-train-leg --no-cpu-baseline > gpurun_out/bp_bench_$pe.json 2> gpurun_out/bp_bench_$pe.err
+  python - <<PY
+import json
+j = json.loads(open("gpurun_out/bp_bench_$pe.json").read().strip().splitlines()[-1])
+print("BATCHED_PROJ=$pe", round(j["value"], 2), "img/s", round(j["ms_per_step"], 2), "ms; unet stage", round(j["stages"]["ms_per_step"]["unet"], 2))
+PY
+done > gpurun_out/bp_ab.txt 2>&1
+cat gpurun_out/batched_test.txt gpurun_out/bp_ab.txt
