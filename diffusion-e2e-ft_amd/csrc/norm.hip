@@ -112,20 +112,37 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(int C, int c1, int gro
     const int na = max(0, min(cend, c1) - cbeg);          // channels of this group that live in source 1
     const int items_a = na * nsa, items = items_a + (cpg - na) * nsb;
     const int c2 = C - c1;
+    // Thread layout: consecutive threads -> consecutive channels of ONE slab (their triples are contiguous: 12 * cpg bytes), slab lanes above
+    // them; four independent triples in flight per thread.  (The first version walked slab-major per channel: every thread of a wave in a
+    // different 12 * C-byte row, one dependent round trip per item — 98 us for the 2304 slabs x 128 channels of a 768^2 layer, a third
+    // of that now; the merge order differs, the result is the same Chan merge.)
+    int P = 1;
+    while (P < cpg && P < 256) P <<= 1;
+    const int tx = tid & (P - 1), ty = tid / P, ny = 256 / P;
     Triple acc = {0.f, 0.f, 0.f};
-    for (int it = tid; it < items; it += 256) {
-        const float* o;
-        if (it < items_a) {
-            const int cc = it / nsa, sl = it - cc * nsa;
-            o = pa + (((long)b * nsa + sl) * c1 + cbeg + cc) * 3;
-        } else {
-            const int j = it - items_a;
-            const int cc = j / nsb, sl = j - cc * nsb;
-            o = pb + (((long)b * nsb + sl) * c2 + (cbeg + na + cc - c1)) * 3;
+    auto walk = [&](const float* __restrict__ base, const int ns, const int cstride, const int nch) {   // base: slab 0, first channel of the group in this source
+        for (int cc = tx; cc < nch; cc += P) {
+            const float* o = base + (long)cc * 3;
+            const long step = (long)cstride * 3;
+            int sl = ty;
+            for (; sl + 3 * ny < ns; sl += 4 * ny) {
+                const float* q0 = o + sl * step;
+                const float* q1 = q0 + ny * step;
+                const float* q2 = q1 + ny * step;
+                const float* q3 = q2 + ny * step;
+                const Triple t0 = {q0[0], q0[1], q0[2]}, t1 = {q1[0], q1[1], q1[2]}, t2 = {q2[0], q2[1], q2[2]}, t3 = {q3[0], q3[1], q3[2]};
+                acc = merge(merge(merge(merge(acc, t0), t1), t2), t3);
+            }
+            for (; sl < ns; sl += ny) {
+                const float* q0 = o + sl * step;
+                const Triple t0 = {q0[0], q0[1], q0[2]};
+                acc = merge(acc, t0);
+            }
         }
-        Triple t = {o[0], o[1], o[2]};
-        acc = merge(acc, t);
-    }
+    };
+    if (na > 0) walk(pa + ((long)b * nsa * c1 + cbeg) * 3, nsa, c1, na);
+    if (cpg - na > 0) walk(pb + ((long)b * nsb * c2 + (cbeg + na - c1)) * 3, nsb, c2, cpg - na);
+    (void)items;
     sm[tid * 3] = acc.n; sm[tid * 3 + 1] = acc.mean; sm[tid * 3 + 2] = acc.m2;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
