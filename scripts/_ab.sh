@@ -1,7 +1,16 @@
-mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py tests/test_fullsize_parity_gpu.py tests/test_bwd_gpu.py -x -q -m gpu -k "groupnorm or gn or unet or vae or pipeline or config" 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -4 > gpurun_out/gnfin_test.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_inf -o r02 -- python bench.py --no-train-leg --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/gnfin_bench.json 2>/dev/null
-grep -E "gn_finalize|gn_apply|gn_partial" $(find /tmp/prof_inf -name "*kernel_stats.csv" | head -1) | cut -c1-200 > gpurun_out/gnfin_stats.txt
-timeout 600 python bench.py --steps 15 --warmup 4 --no-train-leg --no-cpu-baseline 2>/dev/null | python -c "import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(j['value'], 2), 'img/s', round(j['ms_per_step'], 2), 'ms', j['roofline']['other_kernels']['groupnorm'])" >> gpurun_out/gnfin_stats.txt
-cat gpurun_out/gnfin_test.txt gpurun_out/gnfin_stats.txt
+O=gpurun_out
+python bench.py --steps 20 --warmup 5 --detail $O/r02c_bench_per_shape.tsv > $O/r02c_bench_default.json 2> $O/r02c_bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_inf -o r02 -- python bench.py --no-train-leg --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
+cp $(find /tmp/prof_inf -name "*kernel_stats.csv" | head -1) $O/r02c_rocprofv3_kernel_stats.csv
+python bench.py --geowizard --steps 10 --warmup 3 > $O/r02c_bench_geowizard_n1.json 2>/dev/null
+python - <<'PY'
+import json
+j = json.loads(open("gpurun_out/r02c_bench_default.json").read().strip().splitlines()[-1])
+r = j["roofline"]
+print(j["value"], j["ms_per_step"], r["achieved"], r["frac"], r["kernel_ms_per_step"], {k: round(v["ms_per_step"], 2) for k, v in r["other_kernels"].items()})
+print(j["stages"]["ms_per_step"], j["cpu_baseline"]["value"], j["cpu_baseline"]["sample"][:120], j["cpu_baseline"]["leg_seconds"])
+print(j["train_step"]["value"], j["train_step_fp32"]["value"])
+g = json.loads(open("gpurun_out/r02c_bench_geowizard_n1.json").read().strip().splitlines()[-1]); print("geo", g["value"], g["ms_per_step"])
+PY
+head -6 $O/r02c_rocprofv3_kernel_stats.csv | cut -c1-150
