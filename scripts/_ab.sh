@@ -1,16 +1,8 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out
-python bench.py --steps 20 --warmup 5 --detail $O/r02c_bench_per_shape.tsv > $O/r02c_bench_default.json 2> $O/r02c_bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_inf -o r02 -- python bench.py --no-train-leg --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
-cp $(find /tmp/prof_inf -name "*kernel_stats.csv" | head -1) $O/r02c_rocprofv3_kernel_stats.csv
-python bench.py --geowizard --steps 10 --warmup 3 > $O/r02c_bench_geowizard_n1.json 2>/dev/null
-python - <<'PY'
-import json
-j = json.loads(open("gpurun_out/r02c_bench_default.json").read().strip().splitlines()[-1])
-r = j["roofline"]
-print(j["value"], j["ms_per_step"], r["achieved"], r["frac"], r["kernel_ms_per_step"], {k: round(v["ms_per_step"], 2) for k, v in r["other_kernels"].items()})
-print(j["stages"]["ms_per_step"], j["cpu_baseline"]["value"], j["cpu_baseline"]["sample"][:120], j["cpu_baseline"]["leg_seconds"])
-print(j["train_step"]["value"], j["train_step_fp32"]["value"])
-g = json.loads(open("gpurun_out/r02c_bench_geowizard_n1.json").read().strip().splitlines()[-1]); print("geo", g["value"], g["ms_per_step"])
-PY
-head -6 $O/r02c_rocprofv3_kernel_stats.csv | cut -c1-150
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_persistent_gpu.py -x -q -m gpu 2>&1 | tail -6 > gpurun_out/swap_test.txt
+for rep in 1 2; do for sw in 0 1; do
+  for shp in "73728 320 320" "73728 2560 320" "18432 5120 640" "18432 640 640" "4608 1280 1280" "73728 512 512"; do
+    echo -n "NOSWAP=$sw " ; E2EFT_PERSIST_NOSWAP=$sw timeout 120 python scripts/gemm_bench.py $shp 2>&1 | tail -1
+  done
+done; done > gpurun_out/swap_ab.txt 2>&1
+cat gpurun_out/swap_test.txt gpurun_out/swap_ab.txt
