@@ -98,6 +98,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     const int lrow = 8 * wave + (lane >> 3);
     const int jc = (lane & 7) ^ ((lrow >> 1) & 7);
     const bool plain_taps = MODE == 1 && p.zins <= 1 && p.hl == p.hin && p.wl == p.win;
+    const bool half_res = MODE == 1 && (p.zins == 2 || (p.zins <= 1 && p.hl == 2 * p.hin && p.wl == 2 * p.win));
 
     unsigned int off1[4], off2[4];          // per-row byte offsets of the current tap in x1 / x2 (OOB if padded)
     unsigned int cur_a[4], cur_b[2];        // byte offsets of the NEXT k-tile to issue (advanced by 128 B per k-tile)
@@ -189,6 +190,18 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
                 const bool ok = (unsigned)(a_iy0[i] + ky) < (unsigned)p.hl && (unsigned)(a_ix0[i] + kx) < (unsigned)p.wl;
                 off1[i] = ok ? base1[i] + d1 : OOB;
                 off2[i] = ok ? base2[i] + d2 : OOB;
+            }
+            return;
+        }
+        if (half_res) {   // exact 2x nearest upsample (every fused upsample of the path) / stride-2 zero insertion: shifts instead of float / integer division
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                bool ok = (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
+                if (p.zins == 2) ok = ok && (((iy | ix) & 1) == 0);
+                const unsigned pix = (unsigned)((brel[i] * p.hin + (iy >> 1)) * p.win + (ix >> 1));
+                off1[i] = ok ? (pix * (unsigned)p.ldx1 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T) : OOB;
+                off2[i] = ok ? (pix * (unsigned)p.ldx2 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T) : OOB;
             }
             return;
         }
