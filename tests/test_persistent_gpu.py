@@ -141,22 +141,34 @@ for dtype in (torch.float16, torch.bfloat16):
         assert launches() - n0 == 1
 
 # ---- fused GroupNorm statistics: the consumer GroupNorm gives the same result with the producer's partials as with its own pass
-for (B, H, C1, Co, res) in [(4, 32, 64, 128, False), (1, 64, 128, 320, True), (16, 16, 64, 64, True)]:
-    g = torch.Generator().manual_seed(B + H + Co)
+# (B, H, C1, Co, residual, rowadd, alpha, stride): the last two rows add the per-image row vector + alpha and a strided producer
+for (B, H, C1, Co, res, ra, alpha, st) in [(4, 32, 64, 128, False, False, 1.0, 1), (1, 64, 128, 320, True, False, 1.0, 1), (16, 16, 64, 64, True, False, 1.0, 1),
+                                           (2, 64, 64, 128, True, True, 0.5, 1), (4, 64, 64, 256, False, True, 1.0, 2)]:
+    g = torch.Generator().manual_seed(B + H + Co + st)
     x = q(torch.randn(B, C1, H, H, generator=g) * 3.0 + 1.5, torch.float16)
     w = q(torch.randn(Co, C1, 3, 3, generator=g) / (C1 * 9) ** 0.5, torch.float16)
     bb = q(torch.randn(Co, generator=g) * 4.0, torch.float16)
-    r = nhwc(q(torch.randn(B, Co, H, H, generator=g) * 2.0 - 5.0, torch.float16), torch.float16, dev) if res else None
+    Ho = H // st
+    r = nhwc(q(torch.randn(B, Co, Ho, Ho, generator=g) * 2.0 - 5.0, torch.float16), torch.float16, dev) if res else None
+    rav = q(torch.randn(B, Co, generator=g) * 2.0, torch.float16).half().to(dev) if ra else None
     n0 = launches()
-    y = ops.conv2d(nhwc(x, torch.float16, dev), pack_conv_weight(w, torch.float16, dev), bb.half().to(dev), Co, 3, 3, 1, (1, 1, 1, 1), residual=r, gn_stats=True)
+    y = ops.conv2d(nhwc(x, torch.float16, dev), pack_conv_weight(w, torch.float16, dev), bb.half().to(dev), Co, 3, 3, st, (1, 1, 1, 1), residual=r, rowadd=rav,
+                   alpha=alpha, gn_stats=True)
     took = launches() - n0
+    yref = F.conv2d(x.double(), w.double(), bb.double(), stride=st, padding=1)
+    if ra:
+        yref = yref + rav.double().cpu()[:, :, None, None]
+    yref = yref * alpha
+    if res:
+        yref = yref + to_nchw(r).double()
+    assert rel_err(to_nchw(y), yref.float()) <= TOL[torch.float16]
     assert getattr(y, "_e2eft_gn", None) is not None, "no GroupNorm statistics emitted"
     ga, be = torch.ones(Co, device=dev).half(), torch.zeros(Co, device=dev).half()
     a = ops.groupnorm(y, ga, be, 32, 1e-5, True)
     b_ = ops.groupnorm(y.clone(), ga, be, 32, 1e-5, True)     # no statistics attached: the norm computes its own
     ref = F.silu(F.group_norm(to_nchw(y).double(), 32, eps=1e-5)).float()
     e1, e2 = rel_err(to_nchw(a), ref), rel_err(to_nchw(b_), ref)
-    print("gn stats %%s: with partials %%.2e, own pass %%.2e persistent=%%d" %% ((B, H, C1, Co, res), e1, e2, took))
+    print("gn stats %%s: with partials %%.2e, own pass %%.2e persistent=%%d" %% ((B, H, C1, Co, res, ra, alpha, st), e1, e2, took))
     assert e1 < 2e-3 and e2 < 2e-3
     if EXPECT:
         assert took == 1
