@@ -11,14 +11,29 @@
 //   * the epilogue has no workgroup-wide staging: every wave sends its own 64x64 accumulator block through a private 2 x 2 KB window
 //     of the ring stage that the last k-tile just released — eight 8-row slices, slice s+1 written while slice s is read back
 //     row-wise — so LDS writes, row math and 16-byte stores of different waves overlap instead of running in barrier-separated phases;
-//   * residual / bias / rowadd vectors of the first slices are requested during the last k-tile.
-// Contract, operand layouts, ring, swizzle, counted vmcnt waits: as igemm2.hip.  Eligibility is decided on the host
-// (launch_igemm_persistent returns -1 and the caller falls through to igemm2): 16-bit FAST path, M a multiple of 256, at least three
-// k-tiles, the vector epilogue, at least two tiles per workgroup.  E2EFT_PERSIST=0 disables the variant (A/B runs).
+//   * the barrier that opens k-tile g+1 sits in front of the LAST TWO MFMA groups of k-tile g (every LDS read of k-tile g has been
+//     requested and has returned by then): the skew of the eight waves runs under eight MFMAs — 1.45 k cycles per k-tile at K = 1152 and
+//     1.3 k at K = 4608 instead of 1.8 k with the barrier at the top of a rolled loop (igemm2's unrolled loop gets this placement from the
+//     compiler's scheduler, by accident of its freedom to move MFMAs across an asm barrier);
+//   * the loader's per-row index arithmetic for the NEXT tile is done by one thread per output row at the top of the current tile (LDS
+//     row table), the k-tile that switches the loader over only reads four table entries per lane;
+//   * residual / bias / rowadd vectors of the first slices are requested at the top of the last-but-one k-tile, BEFORE the next tile's
+//     first pieces (memory returns in order: their wait must not cover the pieces); every k-tile kind issues exactly six pieces, so all
+//     waits in the tile stream are counted (`vmcnt(6)`, `vmcnt(6 + requests)`), the compiler's own wait for the operands is `vmcnt(12)`,
+//     and the only drain per tile is one `vmcnt(0)` in the middle of the epilogue (as the builtin, so that the waitcnt pass knows);
+//   * the first k-tile of a tile multiplies into the constant 0 (no accumulator clears) and carries the tile-entry arithmetic.
+// Contract, operand layouts, ring, swizzle: as igemm2.hip.  Eligibility is decided on the host (launch_igemm_persistent returns -1 and the
+// caller falls through to igemm2): 16-bit FAST path, M a multiple of 256, at least three k-tiles, the vector epilogue, at least two tiles
+// per workgroup.  E2EFT_PERSIST=0 disables the variant (A/B runs), E2EFT_PERSIST_GRID=<n> shrinks the grid (tests).
 //
-// GroupNorm statistics (p.gn_partial): per column shifted sums about a per-wave pivot (the wave's first output row), reduced over the
-// wave with three butterfly steps, deposited per wave in LDS and merged over the four row-waves of a column with Chan's formula —
-// the same (count, mean, M2) triples per 256-row slab that igemm2 emits.
+// GroupNorm statistics (p.gn_partial): per column shifted sums about a per-wave pivot (the wave's first output row), a 14-exchange
+// reduce-scatter over the eight row-lanes of a chunk, per-wave deposits in LDS merged over the four row-waves of a column with Chan's
+// formula after the barrier that opens the next tile — the same (count, mean, M2) triples per 256-row slab that igemm2 emits.
+//
+// Measured (profiles/r02b_igemm5_phase_clocks_and_ab.txt, r02d_*): 34.5 k cycles per 256x128x1152 tile against 41.7 k in igemm2; at the
+// 1400 W package power cap that is +6 % wall time on conv 128->128 @768^2, +14 % with a residual, +1-3 % at K >= 2304.  Tried and not
+// kept: a 4th fragment slot requested across the barrier, row-table reads one MFMA group early, statistics merge under the next tile's
+// MFMAs, a register-only (operand-swapped) epilogue for GEMM tiles, tap offsets after the fragment requests.
 #include "igemm.h"
 #include <stdlib.h>
 #include <type_traits>
