@@ -102,7 +102,95 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const NarrowParams 
     }
 }
 
+// MFMA form of the same kernel (cin a multiple of 32): the 16 pixels of one tile row are the M rows of v_mfma_f32_16x16x32, the (<= 4, padded
+// to 16) output channels its N columns, 32 input channels of one tap its K; A fragments are the same 16-byte halo reads as above (lane =
+// pixel, lane >> 4 = 8-channel group), the weight fragments of a 64-channel chunk (9 taps x 2 slabs, zero rows beyond cout) sit in 72
+// registers.  The dot-product form issues 864 v_dot2 per thread and chunk (~7k VALU cycles per wave) and streams the weights through the
+// scalar cache; here a wave issues 72 MFMAs (1.2k matrix-pipe cycles) per chunk and the kernel is bound by the halo traffic.
+template <typename T> struct Mma16;
+template <> struct Mma16<f16> {
+    __device__ static __forceinline__ floatx4 run(const u32x4& a, const u32x4& b, floatx4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<bf16> {
+    __device__ static __forceinline__ floatx4 run(const u32x4& a, const u32x4& b, floatx4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bhalf8, a), __builtin_bit_cast(bhalf8, b), c, 0, 0, 0);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv3x3_narrow_mfma_kernel(const NarrowParams p, const T* __restrict__ wg) {
+    __shared__ __attribute__((aligned(16))) char halo[NR_H * NR_H * NR_PIX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;      // A: pixel (tile column) / 8-channel group; B: output channel / 8-channel group; D: column = output channel, rows 4 kq + r
+    const int tile = blockIdx.x;
+    const int oy0 = (tile / p.tiles_x) * NR_T, ox0 = (tile % p.tiles_x) * NR_T;
+    const T* xb = (const T*)p.x + (long)blockIdx.y * p.H * p.W * p.ldx;
+    floatx4 acc[4];                                // tile rows 4 wave + rb
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) acc[rb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const bool wrow = m < p.cout;
+
+    for (int c0 = 0; c0 < p.cin; c0 += NR_CH) {
+        const int nch = min(NR_CH, p.cin - c0);      // multiple of 32
+        const int ngr = nch >> 3;
+        // weight fragments of this chunk (requested before the halo is staged: both latencies overlap)
+        u32x4 bf[9][2];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const bool ok = wrow && sl * 32 < nch;
+                bf[tap][sl] = ok ? *reinterpret_cast<const u32x4*>(wg + (long)m * p.ldw + (long)tap * p.cin + c0 + sl * 32 + kq * 8) : u32x4{0u, 0u, 0u, 0u};
+            }
+        __syncthreads();                              // the previous chunk is consumed
+        for (int i = tid; i < NR_H * NR_H * 8; i += 256) {
+            const int g = i & 7, pix = i >> 3;
+            if (g >= ngr) continue;
+            const int hy = pix / NR_H, hx = pix - hy * NR_H;
+            const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const u32x4*>(xb + ((long)iy * p.W + ix) * p.ldx + c0 + g * 8);
+            *reinterpret_cast<u32x4*>(halo + pix * NR_PIX + g * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int ty = 4 * wave + rb;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const char* px = halo + ((ty + ky) * NR_H + m + kx) * NR_PIX + kq * 16;
+                    acc[rb] = Mma16<T>::run(*reinterpret_cast<const u32x4*>(px), bf[ky * 3 + kx][0], acc[rb]);
+                    if (nch > 32) acc[rb] = Mma16<T>::run(*reinterpret_cast<const u32x4*>(px + 64), bf[ky * 3 + kx][1], acc[rb]);
+                }
+        }
+    }
+    if (wrow) {
+        const T* bias = (const T*)p.bias;
+        const float bv = bias ? to_f(bias[m]) : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const int oy = oy0 + 4 * wave + rb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = ox0 + 4 * kq + r;
+                if (oy < p.H && ox < p.W)
+                    ((T*)p.out)[(((long)blockIdx.y * p.H + oy) * p.W + ox) * p.ldo + m] = from_f<T>(p.alpha * (acc[rb][r] + bv));
+            }
+        }
+    }
+}
+
 template <typename T> static void launch_narrow_t(const NarrowParams& p, dim3 grid, hipStream_t s) {
+    static const int mfma = [] { const char* e = getenv("E2EFT_NARROW_MFMA"); return e ? atoi(e) : 1; }();
+    if (mfma && p.cin % 32 == 0) {
+        hipLaunchKernelGGL((conv3x3_narrow_mfma_kernel<T>), grid, dim3(256), 0, s, p, (const T*)p.w);
+        return;
+    }
     const T* w = (const T*)p.w;
     switch (p.cout) {
         case 1: hipLaunchKernelGGL((conv3x3_narrow_kernel<T, 1>), grid, dim3(256), 0, s, p, w); break;

@@ -105,14 +105,17 @@ def test_conv3x3_basic(ops, dev, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_conv3x3_narrow_output(ops, dev, dtype):
-    """<= 4 output channels on >= 16k pixels take the LDS-halo dot-product kernel (csrc/narrow.hip): decoder conv_out 128 -> 3,
-    UNet conv_out 320 -> 4; ragged tiles, channel counts that end in a partial 64-channel chunk, alpha, one output channel"""
+    """<= 4 output channels on >= 16k pixels take the LDS-halo kernels (csrc/narrow.hip; MFMA 16x16x32 form when Cin % 32 == 0, packed
+    dot products otherwise): decoder conv_out 128 -> 3, UNet conv_out 320 -> 4; ragged tiles, channel counts that end in a partial
+    64-channel chunk, alpha, one output channel"""
     _conv_case(ops, dev, dtype, 2, 128, 3, 96, 96, 3, 1, (1, 1, 1, 1))
     _conv_case(ops, dev, dtype, 2, 128, 4, 100, 90, 3, 1, (1, 1, 1, 1), alpha=0.7)
     _conv_case(ops, dev, dtype, 2, 320, 4, 100, 90, 3, 1, (1, 1, 1, 1), alpha=0.7)   # Cin > 128 stays on the MFMA kernel
     _conv_case(ops, dev, dtype, 1, 72, 1, 131, 127, 3, 1, (1, 1, 1, 1))
     _conv_case(ops, dev, dtype, 3, 64, 2, 80, 80, 3, 1, (1, 1, 1, 1))
     _conv_case(ops, dev, dtype, 1, 8, 3, 128, 130, 3, 1, (1, 1, 1, 1))
+    _conv_case(ops, dev, dtype, 2, 96, 3, 64, 130, 3, 1, (1, 1, 1, 1))     # MFMA form (Cin % 32 == 0): a 64- and a 32-channel chunk
+    _conv_case(ops, dev, dtype, 1, 32, 4, 128, 128, 3, 1, (1, 1, 1, 1), alpha=1.3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
