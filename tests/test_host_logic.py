@@ -178,3 +178,26 @@ def test_public_surface_is_importable():
     assert list(sig.parameters)[:6] == ["self", "input_rgb", "num_inference_steps", "domain", "show_pbar", "noise"]   # geowizard_pipeline.py:252-258
     sig = inspect.signature(MarigoldPipeline.single_infer)
     assert list(sig.parameters)[:6] == ["self", "rgb_in", "num_inference_steps", "show_pbar", "noise", "normals"]     # marigold_pipeline.py:372-380
+
+
+def test_small_gemm_families_of_the_sd2_unet():
+    """unet.py::_batch_small_gemms (inference): the SD-v2 UNet has 22 ResnetBlock2D time projections (all reading the 1280-wide embedding) and
+    16 cross-attention key / value pairs (all reading the 1024-wide context); the two concatenated GEMMs are 20160 and 24960 columns wide.
+    Built on the meta device: no memory, no GPU."""
+    import torch
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.modules import ResnetBlock2D, Attention
+    with torch.device("meta"):
+        m = UNet2DConditionModel(in_channels=8)
+    res = [x for x in m.modules() if isinstance(x, ResnetBlock2D) and x.time_emb_proj is not None]
+    att = [x for x in m.modules() if isinstance(x, Attention) and x.to_k.in_features != x.to_q.in_features and x.to_k.bias is None
+           and x.to_q.in_features // x.heads == 64]
+    assert len(res) == 22 and all(r.time_emb_proj.in_features == 1280 for r in res)
+    assert len(att) == 16 and all(a.to_k.in_features == 1024 for a in att)
+    assert sum(r.time_emb_proj.out_features for r in res) == 20160
+    assert sum(2 * a.to_k.out_features for a in att) == 24960
+    # the consumers pick their slices up through these two attribute names
+    import inspect
+    from diffusion_e2e_ft_amd import modules, unet
+    assert "_rowadd_pre" in inspect.getsource(modules.ResnetBlock2D.nhwc) and "_kv_pre" in inspect.getsource(modules.Attention.forward)
+    assert "_rowadd_pre" in inspect.getsource(unet.UNet2DConditionModel._batch_small_gemms)
