@@ -354,7 +354,6 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, char* 
 
 // v2: 256x128 tile, 8 waves, LDS-DMA (global_load_lds) 3-stage ring — igemm2.hip
 int launch_igemm_v2(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
-// v3: same tile, 32-wide k-tiles, two workgroups per CU (16-bit FAST-path problems; returns -1 when not applicable) — igemm3.hip
 // igemm4.hip: 3x3 / stride-1 convolutions with row-strip reuse of the A operand; returns -1 when the problem is not eligible
 int launch_igemm_strip(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 // igemm5.hip: persistent workgroups walking a tile sequence (16-bit FAST path, M % 256 == 0, >= 2 tiles per CU); -1 when not eligible
