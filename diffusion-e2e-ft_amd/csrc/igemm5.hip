@@ -623,7 +623,7 @@ int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStre
     }
     const int mtiles = p.M / BM, ntiles = cdiv(p.N, BN);
     const long total = (long)mtiles * ntiles * nz;
-    if (total < 2L * g_pers_cus || total > 2000000000L) return -1;
+    if (total < 2L * g_pers_cus || total > 2000000000L || mtiles >= (1 << 22)) return -1;   // (tile / row splits use a float reciprocal: quotients below 2^22)
     p.mtiles = mtiles;
     p.ntiles = ntiles;
     if (p.gn_partial) {   // statistics need whole tiles inside one image
