@@ -21,7 +21,9 @@
 //     first pieces (memory returns in order: their wait must not cover the pieces); every k-tile kind issues exactly six pieces, so all
 //     waits in the tile stream are counted (`vmcnt(6)`, `vmcnt(6 + requests)`), the compiler's own wait for the operands is `vmcnt(12)`,
 //     and the only drain per tile is one `vmcnt(0)` in the middle of the epilogue (as the builtin, so that the waitcnt pass knows);
-//   * the first k-tile of a tile multiplies into the constant 0 (no accumulator clears) and carries the tile-entry arithmetic.
+//   * the first k-tile of a tile multiplies into the constant 0 (no accumulator clears) and carries the tile-entry arithmetic;
+//   * launches WITHOUT a residual (template flag RES = false) use the packed epilogue: alpha / bias / row vector / statistics in the accumulator
+//     layout (a lane owns two columns), values rounded there, two rows per dword through LDS — half the staging bytes, readers only store.
 // Contract, operand layouts, ring, swizzle: as igemm2.hip.  Eligibility is decided on the host (launch_igemm_persistent returns -1 and the
 // caller falls through to igemm2): 16-bit FAST path, M a multiple of 256, at least three k-tiles, the vector epilogue, at least two tiles
 // per workgroup.  E2EFT_PERSIST=0 disables the variant (A/B runs), E2EFT_PERSIST_GRID=<n> shrinks the grid (tests).
@@ -83,7 +85,8 @@ __device__ __forceinline__ int fast_div5(int n, int d) {   // as igemm2.hip: flo
     return q;
 }
 
-template <typename T, int MODE>
+// RES: the launch has a residual operand (fp32 sliced epilogue); otherwise the packed epilogue — one of the two per instantiation, for the register budget
+template <typename T, int MODE, bool RES>
 __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const int total_tiles) {
     using namespace pers;
     __shared__ __attribute__((aligned(16))) char smem[LDS];
@@ -301,8 +304,10 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     const int er = lane >> 3, ec = lane & 7;          // row inside an 8-row slice, 8-column chunk inside the wave's 64 columns
     const T* __restrict__ bias = (const T*)p.bias;
     const T* __restrict__ rowadd = (const T*)p.rowadd;
-    const bool has_res = p.residual != nullptr, has_ra = rowadd != nullptr, stats = p.gn_partial != nullptr;
+    constexpr bool has_res = RES;
+    const bool has_ra = rowadd != nullptr, stats = p.gn_partial != nullptr;
     Vec16<T> pre_res[4], pre_bias, pre_ra;            // residual rows of slices 0-3, bias and rowadd chunk of this lane
+    T col_bias[2], col_ra[2];                          // packed epilogue (no residual): bias / rowadd of the two COLUMNS this lane owns in the accumulator layout
     long c_orow = 0, c_rrow = 0;                       // element offsets of this lane's first output / residual row in the MFMA-side tile
     int c_m0 = 0, c_n0 = 0, c_img = 0, c_ncl = 0;
     bool c_colok = false;
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     // every LDS read of k-tile g has been requested by then, and the barrier skew of the eight waves disappears under 8 MFMAs (igemm2's
     // unrolled loop gets the same placement from the compiler's scheduler; a rolled loop has to spell it out).  nextwait: 0 none,
     // 2 vmcnt(6), 3 vmcnt(6 + NPRE) with NPRE = the operand requests issued at the top of a KIND-1 k-tile.
-    const int npre = (has_res ? 4 : 0) + (bias ? 1 : 0) + (has_ra ? 1 : 0);
+    const int npre = has_res ? 4 + (bias ? 1 : 0) + (has_ra ? 1 : 0) : 2 * ((bias ? 1 : 0) + (has_ra ? 1 : 0));
     bool nxt = false;                                  // the workgroup has a tile after the current one (set at the top of a tile)
     long zoff_o = 0;
     auto enter_tile = [&]() {   // the MFMA side enters the tile the loader is (still) on; then the loader's coordinates move to the workgroup's next tile
@@ -367,9 +372,14 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
             if (has_res) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) pre_res[s] = ld16((const T*)p.residual + c_rrow + (long)(s * 8) * p.ldr);
+                if (bias) pre_bias = ld16(bias + c_ncl);
+                if (has_ra) pre_ra = ld16(rowadd + (long)c_img * p.N + c_ncl);
+            } else {   // packed epilogue: two column scalars per operand (columns beyond N read the tile's first column: unused, but the count stays)
+                const int cA = c_n0 + wn * 64 + l31, cB = cA + 32;
+                const int nA = cA < p.N ? cA : c_n0, nB = cB < p.N ? cB : c_n0;
+                if (bias) { col_bias[0] = bias[nA]; col_bias[1] = bias[nB]; }
+                if (has_ra) { col_ra[0] = rowadd[(long)c_img * p.N + nA]; col_ra[1] = rowadd[(long)c_img * p.N + nB]; }
             }
-            if (bias) pre_bias = ld16(bias + c_ncl);
-            if (has_ra) pre_ra = ld16(rowadd + (long)c_img * p.N + c_ncl);
             u_dma += nslots;
             if (nxt) {
                 finish_setup();
@@ -413,6 +423,91 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     };
 
     // ---- the epilogue of the MFMA-side tile (c_m0, c_n0): out = alpha * (acc + bias + rowadd[img]) + residual, eight slices per wave
+    // Tiles WITHOUT a residual: everything that is per column (alpha, bias, row vector, GroupNorm statistics) is done in the accumulator layout,
+    // where a lane owns two columns; the values are rounded to T there and two rows of a column share a dword, so the LDS transpose moves half
+    // the bytes (the ds_write_b32 rate of 64 B/clk is what bounds the epilogue) and the row-wise readers only un-interleave and store.
+    // Rounds of 16 rows: window = 8 row pairs x 64 columns of packed dwords (2 KiB as one fp32 slice), two windows in flight.
+    auto epilogue_packed = [&](const int sfree, const long zoff_o) {
+        unsigned* win = reinterpret_cast<unsigned*>(smem + sfree + wave * 4096);
+        const float al = p.alpha;
+        T* __restrict__ out = (T*)p.out + zoff_o;
+        const f2 al2 = {al, al};
+        f2 bva[2], rav[2], pv[2], sm[2], sq[2];   // per owned column j: bias * alpha, row vector, pivot, shifted sums (pairs = two rows at a time)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bj = bias ? to_f(col_bias[j]) * al : 0.f, rj = has_ra ? to_f(col_ra[j]) : 0.f;
+            bva[j] = f2{bj, bj}; rav[j] = f2{rj, rj};
+            pv[j] = f2{0.f, 0.f}; sm[j] = f2{0.f, 0.f}; sq[j] = f2{0.f, 0.f};
+        }
+        // physical dword of (row pair rp8, column x) inside a window: ((x >> 2) & 1) * 256 + rp8 * 32 + (x >> 3) * 4 + (x & 3): readers take the
+        // 16-byte units `lane` and `64 + lane`
+        const int wofs = ((l31 >> 2) & 1) * 256 + h * 64 + (l31 >> 3) * 4 + (l31 & 3);   // + qq * 128 + t * 32 + j * 16
+        auto wr = [&](auto rc_) {
+            constexpr int r = decltype(rc_)::value, i = r >> 1;
+            unsigned* wb = win + (r & 1) * 512 + wofs;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                constexpr int dummy = 0; (void)dummy;
+                const int q = 2 * (r & 1) + qq;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        f2 x = {acc[i][j][4 * q + 2 * t], acc[i][j][4 * q + 2 * t + 1]};
+                        x = __builtin_elementwise_fma(x, al2, bva[j]);
+                        if (has_ra) x = __builtin_elementwise_fma(rav[j], al2, x);
+                        if (stats) {
+                            if (r == 0 && qq == 0 && t == 0) {   // pivot of a column: its first value in the wave (held by the h = 0 lane)
+                                const float p0 = __shfl(x[0], l31, 64);
+                                pv[j] = f2{p0, p0};
+                            }
+                            const f2 d = x - pv[j];
+                            sm[j] += d;
+                            sq[j] = __builtin_elementwise_fma(d, d, sq[j]);
+                        }
+                        T e2[2] = {from_f<T>(x[0]), from_f<T>(x[1])};
+                        unsigned u;
+                        __builtin_memcpy(&u, e2, 4);
+                        wb[qq * 128 + t * 32 + j * 16] = u;
+                    }
+            }
+        };
+        const int rp8 = lane >> 3;                                   // reader: row pair of the round, chunk ec
+        auto round = [&](auto rc_) {
+            constexpr int r = decltype(rc_)::value;
+            if constexpr (r < 3) wr(IC5<r + 1>{});
+            if constexpr (r == 2) __builtin_amdgcn_s_waitcnt(0x0F70);   // the next tile's first two k-tiles have landed (as slice 4 of the fp32 epilogue)
+            const unsigned* rb = win + (r & 1) * 512 + lane * 4;
+            const u32x4 t0 = *reinterpret_cast<const u32x4*>(rb);       // columns 8 ec .. +3, rows (2 rp8, 2 rp8 + 1) interleaved
+            const u32x4 t1 = *reinterpret_cast<const u32x4*>(rb + 256); // columns 8 ec + 4 .. +7
+            u32x4 lo, hi;
+            lo[0] = __builtin_amdgcn_perm(t0[1], t0[0], 0x05040100u); hi[0] = __builtin_amdgcn_perm(t0[1], t0[0], 0x07060302u);
+            lo[1] = __builtin_amdgcn_perm(t0[3], t0[2], 0x05040100u); hi[1] = __builtin_amdgcn_perm(t0[3], t0[2], 0x07060302u);
+            lo[2] = __builtin_amdgcn_perm(t1[1], t1[0], 0x05040100u); hi[2] = __builtin_amdgcn_perm(t1[1], t1[0], 0x07060302u);
+            lo[3] = __builtin_amdgcn_perm(t1[3], t1[2], 0x05040100u); hi[3] = __builtin_amdgcn_perm(t1[3], t1[2], 0x07060302u);
+            if (c_colok) {
+                T* o = out + c_orow + (long)(16 * r + rp8) * p.ldo;   // c_orow is row `rp8` of the wave's block: + rp8 more rows = row 2 rp8 of round r
+                *reinterpret_cast<u32x4*>(o) = lo;
+                *reinterpret_cast<u32x4*>(o + p.ldo) = hi;
+            }
+        };
+        wr(IC5<0>{});
+        round(IC5<0>{}); round(IC5<1>{}); round(IC5<2>{}); round(IC5<3>{});
+        if (stats) {   // uniform: per column totals = both halves of the pair accumulators + the other half-wave; h = 0 lanes deposit their two columns
+            float* dep = reinterpret_cast<float*>(smem + RING);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float su = sm[j][0] + sm[j][1], s2 = sq[j][0] + sq[j][1];
+                su += __shfl_xor(su, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (h == 0) {
+                    float* d3 = dep + (wave * 64 + 32 * j + l31) * 3;
+                    d3[0] = su; d3[1] = s2; d3[2] = pv[j][0];
+                }
+            }
+        }
+    };
+
     auto epilogue = [&](const int sfree, const long zoff_o) {
         // (opened by the barrier embedded in the last k-tile: every wave is done reading that k-tile, its stage is scratch now)
         float* win = reinterpret_cast<float*>(smem + sfree + wave * 4096);   // two 2-KiB slice windows
@@ -572,7 +667,8 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         ktile(IC5<2>{}, 0);    // opens the epilogue: barrier only
         STAMP5(tseq, 2);
         // after the rotation of the last k-tile its stage is s_dst (the next DMA destination): scratch until the next barrier
-        epilogue(s_dst, zoff_o);
+        if constexpr (RES) epilogue(s_dst, zoff_o);
+        else epilogue_packed(s_dst, zoff_o);
         STAMP5(tseq, 3);
         ++tseq;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // statistics deposits written; every slice window read
@@ -589,7 +685,8 @@ static int g_pers_cus = 0;
 static long g_pers_launches = 0;   // debug counter (tests assert that the variant under test really ran)
 
 template <typename T, int MODE> static int launch5(IgemmParams& p, int nz, int total, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((igemm5_kernel<T, MODE>), dim3(grid), dim3(512), 0, s, p, total);
+    if (p.residual) hipLaunchKernelGGL((igemm5_kernel<T, MODE, true>), dim3(grid), dim3(512), 0, s, p, total);
+    else hipLaunchKernelGGL((igemm5_kernel<T, MODE, false>), dim3(grid), dim3(512), 0, s, p, total);
     return check_launch("igemm5");
 }
 
