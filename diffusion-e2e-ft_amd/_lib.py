@@ -42,6 +42,9 @@ class AttnDesc(C.Structure):
                                           "ldo")] + [("scale", C.c_float)]
 
 
+# e2eft_set_option keys (include/e2eft.h)
+OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES = range(6)
+
 _P = C.c_void_p
 _I = C.c_int32
 _L = C.c_int64
@@ -52,6 +55,8 @@ _Z = C.c_size_t
 SIGNATURES = {
     "e2eft_version": (_I, []),
     "e2eft_last_error": (C.c_char_p, []),
+    "e2eft_set_option": (_I, [_I, _I]),
+    "e2eft_get_option": (_I, [_I]),
     "e2eft_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "e2eft_gemm": (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P]),
     "e2eft_conv2d_fwd_gnstats": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int32), _P]),
@@ -67,6 +72,7 @@ SIGNATURES = {
     "e2eft_softmax_rows_causal": (_I, [_I, _L, _I, _L, _F, _I, _P, _P]),
     "e2eft_attn_fwd": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
     "e2eft_attn_fwd_lse": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P]),
+    "e2eft_attn512_fwd": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
     "e2eft_attn_bwd_workspace_bytes": (_Z, [C.POINTER(AttnDesc)]),
     "e2eft_attn_bwd": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
     "e2eft_nchw_to_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
@@ -102,6 +108,7 @@ SIGNATURES = {
     "e2eft_angular_loss_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "e2eft_sumsq": (_I, [_L, _P, _P, _P]),
     "e2eft_adamw_step": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _F, _F, _P]),
+    "e2eft_adamw_step_guarded": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _F, _F, _P]),
     "e2eft_cast": (_I, [_I, _I, _L, _F, _I, _P, _P, _P]),
     "e2eft_activation": (_I, [_I, _I, _L, _P, _P, _P]),
     "e2eft_masked_quantiles_workspace_bytes": (_Z, [_I]),
@@ -143,10 +150,30 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.e2eft_version() < 111:
+    if lib.e2eft_version() < 112:
         raise RuntimeError("libe2eft.so is stale (version %d)" % lib.e2eft_version())
     _LIB = lib
     return lib
+
+
+def set_option(key, value):
+    check(load().e2eft_set_option(key, value))
+
+
+class option:
+    """`with _lib.option(_lib.OPT_PERSISTENT, 0): ...` — scoped e2eft_set_option (A/B runs, tests)"""
+
+    def __init__(self, key, value):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        self.old = load().e2eft_get_option(self.key)
+        set_option(self.key, self.value)
+        return self
+
+    def __exit__(self, *a):
+        set_option(self.key, self.old)
+        return False
 
 
 def check(rc):

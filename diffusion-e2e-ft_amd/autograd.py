@@ -186,9 +186,13 @@ class _Conv2dFn(torch.autograd.Function):
             dyT = ops.transpose(ops._as_rows(dyp), rows_pad=nsplit * kc)        # [cop, Pp]
             col, _, _ = ops.im2col_t(xp, x2, kh, kw, stride, pad, up_to, Pp=nsplit * kc)   # [kh*kw*cin, Pp]
             dwp = ops.gemm_splitk(dyT[:Co], col, nsplit, kc, alpha=alpha)       # [Co, kh*kw*cin] = OHWI
-            dw = dwp.view(Co, kh, kw, c1 + c2)[..., :Ci].permute(0, 3, 1, 2)
-            if dw.dtype != weight.dtype:
-                dw = dw.to(weight.dtype)
+            # the gradient is handed to autograd in the PARAMETER's stride order (OIHW contiguous): AccumulateGrad then adds / stores it
+            # without a strided pass, and a DistributedDataParallel wrap finds "grad strides == bucket view strides"
+            if kh == 1 and kw == 1:
+                dw = dwp[:, :Ci].reshape(Co, Ci, 1, 1)
+                dw = dw if dw.dtype == weight.dtype else dw.to(weight.dtype)
+            else:
+                dw = dwp.view(Co, kh, kw, c1 + c2)[..., :Ci].permute(0, 3, 1, 2).to(dtype=weight.dtype, memory_format=torch.contiguous_format)
         return dx, dx2, dw, dbias, drow, dres, None, None, None, None, None, None
 
 

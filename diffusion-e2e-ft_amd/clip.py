@@ -168,6 +168,7 @@ class CLIPVisionModelWithProjection(_HubIO, nn.Module):
         return super().load_state_dict(sd, strict=strict, **kw)
 
     @torch.no_grad()
+    @ops.device_scoped
     def forward(self, pixel_values, **unused):
         last, pooled = self.vision_model(pixel_values.to(self.device))
         return _Out(self.visual_projection(pooled), last)
@@ -272,6 +273,7 @@ class CLIPTextModel(_HubIO, nn.Module):
         return super().load_state_dict(sd, strict=strict, **kw)
 
     @torch.no_grad()
+    @ops.device_scoped
     def forward(self, input_ids, return_dict=True, **unused):
         out = self.text_model(input_ids.to(self.device))
         return _TextOut(out) if return_dict else (out,)

@@ -1,5 +1,6 @@
 // api.hip — error plumbing and version for libe2eft.
 #include "common.h"
+#include <atomic>
 
 namespace e2eft {
 
@@ -21,7 +22,23 @@ int check_launch(const char* what) {
     return E2EFT_OK;
 }
 
+static std::atomic<int> g_opt[E2EFT_OPT_COUNT] = {{1}, {0}, {1}, {1}, {0}, {0}};
+
+int option(int key) { return g_opt[key].load(std::memory_order_relaxed); }
+
 }  // namespace e2eft
+
+extern "C" int e2eft_set_option(int32_t key, int32_t value) {
+    using namespace e2eft;
+    E2EFT_REQUIRE(key >= 0 && key < E2EFT_OPT_COUNT, "set_option: unknown key %d", key);
+    bool ok = value == 0 || value == 1;
+    if (key == E2EFT_OPT_PERSISTENT_GRID) ok = value == 0 || (value >= 8 && value % 8 == 0 && value <= 4096);
+    if (key == E2EFT_OPT_IGEMM2_WAVES) ok = value == 0 || value == 4 || value == 8;
+    E2EFT_REQUIRE(ok, "set_option: value %d out of range for key %d", value, key);
+    g_opt[key].store(value, std::memory_order_relaxed);
+    return E2EFT_OK;
+}
+extern "C" int e2eft_get_option(int32_t key) { return key >= 0 && key < E2EFT_OPT_COUNT ? e2eft::option(key) : -1; }
 
 extern "C" int e2eft_version(void) { return E2EFT_VERSION; }
 extern "C" const char* e2eft_last_error(void) { return e2eft::err_buf(); }

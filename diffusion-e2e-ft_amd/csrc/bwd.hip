@@ -358,6 +358,47 @@ __global__ __launch_bounds__(256) void adamw_kernel(long n, float* __restrict__ 
     }
 }
 
+// Guarded form with the step counter ON THE DEVICE (e2eft_adamw_step_guarded).  state[0] = number of APPLIED steps (the `step` of
+// torch.optim.AdamW's bias correction), state[1] = number of SKIPPED steps.  adamw_prepare_kernel (one thread) looks at the gradient's
+// sum of squares: finite -> state[0] += 1, coef = {clip factor, 1 - beta1^step, sqrt(1 - beta2^step), 1}; not finite (overflow in a 16-bit
+// forward, NaN input) -> state[1] += 1, coef[3] = 0 and adamw_guarded_kernel leaves parameters AND moments alone.  So a skipped step does not
+// advance the bias correction, the skip is visible to the caller (state[1]), and the host never waits for the device.
+__global__ void adamw_prepare_kernel(long long* __restrict__ state, float* __restrict__ coef, const double* __restrict__ sumsq, float b1, float b2,
+                                     float gscale, float max_norm) {
+    const double ss = sumsq[0];
+    if (!isfinite(ss)) {
+        state[1] += 1;
+        coef[0] = 0.f; coef[1] = 1.f; coef[2] = 1.f; coef[3] = 0.f;
+        return;
+    }
+    const long long step = state[0] + 1;
+    state[0] = step;
+    float clip = gscale;
+    if (max_norm > 0.f) clip *= fminf(1.f, max_norm / ((float)sqrt(ss) * gscale + 1e-6f));
+    coef[0] = clip;
+    coef[1] = (float)(1.0 - pow((double)b1, (double)step));
+    coef[2] = (float)sqrt(1.0 - pow((double)b2, (double)step));
+    coef[3] = 1.f;
+}
+
+__global__ __launch_bounds__(256) void adamw_guarded_kernel(long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                            float* __restrict__ v, float lr, float b1, float b2, float eps, float wd,
+                                                            const float* __restrict__ coef) {
+    if (coef[3] == 0.f) return;
+    const float clip = coef[0], bc1 = coef[1], bc2_sqrt = coef[2];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * clip;
+        float pi = p[i];
+        pi -= lr * wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void cast_kernel(long n, float mul, int accumulate, const TI* __restrict__ x, TO* __restrict__ y) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -535,6 +576,17 @@ extern "C" int e2eft_adamw_step(int64_t n, float* param, const float* grad, floa
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, s, (long)n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1,
                        bc2s, grad_sumsq, grad_scale, max_norm);
     return check_launch("adamw");
+}
+
+extern "C" int e2eft_adamw_step_guarded(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                                        float eps, float weight_decay, int64_t* state, float* coef, const double* grad_sumsq, float grad_scale,
+                                        float max_norm, void* stream) {
+    E2EFT_REQUIRE(param && grad && exp_avg && exp_avg_sq && state && coef && grad_sumsq && n > 0, "adamw_guarded: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(1), 0, s, (long long*)state, coef, grad_sumsq, beta1, beta2, grad_scale, max_norm);
+    hipLaunchKernelGGL(adamw_guarded_kernel, dim3(grid_for(n)), dim3(256), 0, s, (long)n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
+                       weight_decay, (const float*)coef);
+    return check_launch("adamw_guarded");
 }
 
 extern "C" int e2eft_cast(int32_t dt_in, int32_t dt_out, int64_t n, float mul, int32_t accumulate, const void* x, void* y, void* stream) {

@@ -12,6 +12,7 @@ namespace e2eft {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
+int option(int key);   // process-wide tuning options (e2eft_set_option), api.hip
 
 #define E2EFT_REQUIRE(cond, ...)                                     \
     do {                                                             \

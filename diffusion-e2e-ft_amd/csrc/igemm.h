@@ -73,7 +73,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, char* smem,
 }
 
 // the row passes over a tile that is already staged in LDS as fp32 [BM_][BN_ + 4] (all threads past a barrier): bias / rowadd / alpha /
-// residual, rounding, 16-byte stores, optional GroupNorm statistics.  Kernels with other accumulator layouts stage themselves (igemm4.hip).
+// residual, rounding, 16-byte stores, optional GroupNorm statistics.  
 template <typename T, int BM_, int BN_, int NT_>
 __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, char* smem, int m0, int n0, int zo, int zi) {
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -354,8 +354,6 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, char* 
 
 // v2: 256x128 tile, 8 waves, LDS-DMA (global_load_lds) 3-stage ring — igemm2.hip
 int launch_igemm_v2(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
-// igemm4.hip: 3x3 / stride-1 convolutions with row-strip reuse of the A operand; returns -1 when the problem is not eligible
-int launch_igemm_strip(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 // igemm5.hip: persistent workgroups walking a tile sequence (16-bit FAST path, M % 256 == 0, >= 2 tiles per CU); -1 when not eligible
 int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 

@@ -1,220 +1,19 @@
-// igemm.hip — implicit-GEMM convolution / NT-GEMM on MFMA for gfx950 (MI355X).
+// igemm.hip — host side of the implicit-GEMM convolution / NT-GEMM family for gfx950 (MI355X): argument checks, the split-K plan and its
+// finish kernel, kernel choice.
 //
 //   out[m, n] = alpha * ( sum_k A[m, k] * W[n, k] + bias + rowadd[img(m), n] ) + residual[m, n]
 //
-// One kernel family serves every dense contraction of the path: conv3x3 (s1/s2, symmetric or
-// VAE-asymmetric padding, fused nearest upsample, fused channel concat of two sources), conv1x1, nn.Linear and
-// the batched attention matmuls of the unfused path.
-//
-// Design (CDNA4): 128x128 output tile per 256-thread workgroup (4 waves, 2x2, each wave 64x64 = 2x2 MFMA 32x32
-// tiles, fp32 accumulators in registers).  One k-tile is 128 BYTES of K per row (64 halves / 32 floats), staged
-// global -> registers -> LDS (16-byte vector loads, the im2col gather and the zero padding happen in the load),
-// LDS rows padded 128 -> 144 bytes so that ds_read_b128 fragment reads are bank-conflict free, two LDS buffers
-// with the next tile's global loads in flight under the current tile's MFMAs (one barrier per k-tile).
-// MFMA: v_mfma_f32_32x32x16_{f16,bf16} for 16-bit data; v_mfma_f32_32x32x2_f32 (exact fp32) for the strict-fp32
-// parity path.  blockIdx -> tile mapping is XCD-aware (bijective remap) so that the N-tiles sharing one A panel
-// run on the same XCD's L2.
+// One kernel family serves every dense contraction of the path: conv3x3 (s1/s2, symmetric or VAE-asymmetric padding,
+// fused nearest upsample, fused channel concat of two sources), conv1x1, nn.Linear and the batched attention matmuls of the unfused
+// path.  The kernels live in igemm5.hip (persistent workgroups, the big 16-bit launches) and igemm2.hip (everything else, incl. exact
+// fp32 on v_mfma_f32_32x32x2_f32).  (Round 1's register-staged 128x128 kernel and round 2's row-strip kernel igemm4 were retired in
+// round 3: neither was on any production path; their text is kept in scripts/experiments/.)
 #include "common.h"
 #include "igemm.h"
-#include <stdlib.h>
 
 namespace e2eft {
 
-constexpr int BM = 128, BN = 128;
-constexpr int ROWB = 128;        // data bytes per LDS row = one k-tile
-constexpr int ROWS = ROWB + 16;  // padded LDS row stride (bytes)
-constexpr int TILE_BYTES = 128 * ROWS;
-
-
-
-template <typename T> struct Mma;
-template <> struct Mma<f16> {
-    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mma<bf16> {
-    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bhalf8, a), __builtin_bit_cast(bhalf8, b), c, 0, 0, 0);
-    }
-};
-
-// MODE 0: A rows are plain (GEMM / 1x1 conv); MODE 1: im2col gather.
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
-    constexpr int EPC = 16 / (int)sizeof(T);    // elements per 16-byte chunk
-    constexpr int BK = ROWB / (int)sizeof(T);   // k elements per tile
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, h = lane >> 5;
-
-    // ---- XCD-aware tile mapping (bijective) ----
-    const int nblk = p.mtiles * p.ntiles;
-    int lid;
-    {
-        const int bid = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int mt = lid / p.ntiles, nt = lid - mt * p.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int z = blockIdx.y;
-    const int zo = z / p.nzi, zi = z - zo * p.nzi;
-
-    const T* __restrict__ X1 = (const T*)p.x1 + zo * p.sa_o + zi * p.sa_i;
-    const T* __restrict__ X2 = (const T*)p.x2;
-    const T* __restrict__ W = (const T*)p.w + zo * p.sw_o + zi * p.sw_i;
-
-    // ---- per-thread loader state: 4 rows (r0 + 32 i), one 16-byte k-chunk column kc ----
-    const int kc = tid & 7;
-    const int r0 = tid >> 3;
-    long a_base[4];      // MODE 0: element offset of the row; MODE 1: image index b
-    int a_iy0[4], a_ix0[4];
-    bool a_ok[4];
-    long w_base[4];
-    bool w_ok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + r0 + 32 * i;
-        a_ok[i] = m < p.M;
-        if (MODE == 0) {
-            a_base[i] = (long)m * p.ldx1;
-            a_iy0[i] = a_ix0[i] = 0;
-        } else {
-            const int hw = p.hout * p.wout;
-            const int mm = a_ok[i] ? m : 0;
-            const int b = mm / hw;
-            const int rem = mm - b * hw;
-            const int oy = rem / p.wout, ox = rem - oy * p.wout;
-            a_base[i] = b;
-            a_iy0[i] = oy * p.stride - p.pad_t;
-            a_ix0[i] = ox * p.stride - p.pad_l;
-        }
-        const int n = n0 + r0 + 32 * i;
-        w_ok[i] = n < p.N;
-        w_base[i] = (long)n * p.ldw;
-    }
-
-    u32x4 ra[4], rb[4];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + kc * EPC;
-        const bool kok = k < p.K;
-        if (MODE == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                ra[i] = (kok && a_ok[i]) ? *reinterpret_cast<const u32x4*>(X1 + a_base[i] + k) : zero4;
-        } else {
-            const int kpos = k / p.cin;
-            const int c = k - kpos * p.cin;
-            const int ky = kpos / p.kw, kx = kpos - ky * p.kw;
-            const bool second = c >= p.c1;
-            const T* src = second ? X2 : X1;
-            const int ld = second ? p.ldx2 : p.ldx1;
-            const int cc = second ? c - p.c1 : c;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-                bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.hl && (unsigned)ix < (unsigned)p.wl;
-                int sy = iy, sx = ix;
-                if (p.zins > 1) {
-                    ok = ok && (iy % p.zins == 0) && (ix % p.zins == 0);
-                    sy = iy / p.zins; sx = ix / p.zins;
-                } else {
-                    if (p.hl != p.hin) sy = min((int)floorf(iy * p.up_sh), p.hin - 1);
-                    if (p.wl != p.win) sx = min((int)floorf(ix * p.up_sw), p.win - 1);
-                }
-                const long pix = (a_base[i] * p.hin + sy) * p.win + sx;
-                ra[i] = ok ? *reinterpret_cast<const u32x4*>(src + pix * ld + cc) : zero4;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            rb[i] = (kok && w_ok[i]) ? *reinterpret_cast<const u32x4*>(W + w_base[i] + k) : zero4;
-    };
-    auto store_tile = [&](int buf) {
-        char* sa = smem + buf * 2 * TILE_BYTES;
-        char* sb = sa + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = (r0 + 32 * i) * ROWS + kc * 16;
-            *reinterpret_cast<u32x4*>(sa + off) = ra[i];
-            *reinterpret_cast<u32x4*>(sb + off) = rb[i];
-        }
-    };
-
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto compute = [&](int buf) {
-        const char* sa = smem + buf * 2 * TILE_BYTES + (wm * 64 + l31) * ROWS;
-        const char* sb = smem + buf * 2 * TILE_BYTES + TILE_BYTES + (wn * 64 + l31) * ROWS;
-        if constexpr (sizeof(T) == 2) {
-            // 4 k-steps of 16; lane half h holds k = 8h..8h+7 of each step
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int off = ks * 32 + h * 16;
-                u32x4 a0 = *reinterpret_cast<const u32x4*>(sa + off);
-                u32x4 a1 = *reinterpret_cast<const u32x4*>(sa + 32 * ROWS + off);
-                u32x4 b0 = *reinterpret_cast<const u32x4*>(sb + off);
-                u32x4 b1 = *reinterpret_cast<const u32x4*>(sb + 32 * ROWS + off);
-                acc[0][0] = Mma<T>::run(a0, b0, acc[0][0]);
-                acc[0][1] = Mma<T>::run(a0, b1, acc[0][1]);
-                acc[1][0] = Mma<T>::run(a1, b0, acc[1][0]);
-                acc[1][1] = Mma<T>::run(a1, b1, acc[1][1]);
-            }
-        } else {
-            // fp32: 32 k per tile; MFMA 32x32x2 step s pairs k = s (lanes 0-31) with k = 16 + s (lanes 32-63);
-            // the same slot permutation is applied to A and W so the sum is the plain dot product.
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int off = h * 64 + qd * 16;
-                floatx4 a0 = *reinterpret_cast<const floatx4*>(sa + off);
-                floatx4 a1 = *reinterpret_cast<const floatx4*>(sa + 32 * ROWS + off);
-                floatx4 b0 = *reinterpret_cast<const floatx4*>(sb + off);
-                floatx4 b1 = *reinterpret_cast<const floatx4*>(sb + 32 * ROWS + off);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
-                }
-            }
-        }
-    };
-
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tile(kt + 1);
-        compute(cur);
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: LDS-staged, vectorised (igemm.h) ----
-    igemm_epilogue<T, BM, BN, 256>(p, smem, acc, wm, wn, l31, h, m0, n0, zo, zi);
-}
-
-template <typename T, int MODE> static int launch_igemm(const IgemmParams& p, int nz, hipStream_t s) {
-    dim3 grid(p.mtiles * p.ntiles, nz, 1);
-    hipLaunchKernelGGL((igemm_kernel<T, MODE>), grid, dim3(256), 0, s, p);
-    return check_launch("igemm");
-}
+constexpr int BM = 128, BN = 128;   // tile counts reported to the kernels' launchers (each re-derives its own tile shape)
 
 // split-K finish: out = alpha * (sum_z part[z] + bias + rowadd[img(m)]) + residual, 16-byte vectors; thread per (row, chunk)
 template <typename T>
@@ -280,24 +79,10 @@ static int run_igemm(int dtype, int mode, IgemmParams& p, int nz, void* stream) 
     if ((long)p.mtiles * p.ntiles > 2000000000L) return fail(E2EFT_ERR_BAD_ARG, "igemm: grid too large");
     if (nz > 65535) return fail(E2EFT_ERR_BAD_ARG, "igemm: batch %d > 65535", nz);
     hipStream_t s = (hipStream_t)stream;
-    {
-        // variant choice: the LDS-DMA kernel (igemm2.hip) serves everything (it picks 256- or 128-row tiles itself and beats
-        // this kernel on every shape of the path, including the 12^2 / 24^2 layers); this register-staged kernel stays as an
-        // independent second implementation of the same contract: E2EFT_IGEMM=1 selects it (A/B runs, cross-checks).
-        static const int forced = [] { const char* e = getenv("E2EFT_IGEMM"); return e ? atoi(e) : 0; }();
-        if (forced != 1) {
-            const int rc5 = launch_igemm_persistent(dtype, mode, p, nz, s);   // big problems: persistent workgroups (igemm5.hip)
-            if (rc5 >= 0) return rc5;
-            const int rc4 = launch_igemm_strip(dtype, mode, p, nz, s);   // 3x3 stride-1 convs: row-strip reuse of A (igemm4.hip)
-            if (rc4 >= 0) return rc4;
-            return launch_igemm_v2(dtype, mode, p, nz, s);
-        }
-    }
-    p.gn_partial = nullptr;   // this variant does not emit GroupNorm statistics
-    if (dtype == E2EFT_F32) return mode ? launch_igemm<float, 1>(p, nz, s) : launch_igemm<float, 0>(p, nz, s);
-    if (dtype == E2EFT_F16) return mode ? launch_igemm<f16, 1>(p, nz, s) : launch_igemm<f16, 0>(p, nz, s);
-    if (dtype == E2EFT_BF16) return mode ? launch_igemm<bf16, 1>(p, nz, s) : launch_igemm<bf16, 0>(p, nz, s);
-    return fail(E2EFT_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
+    if (dtype < 0 || dtype > 2) return fail(E2EFT_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
+    const int rc5 = launch_igemm_persistent(dtype, mode, p, nz, s);   // big 16-bit problems: persistent workgroups (igemm5.hip)
+    if (rc5 >= 0) return rc5;
+    return launch_igemm_v2(dtype, mode, p, nz, s);                    // everything else: igemm2.hip (256- or 128-row tiles)
 }
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }

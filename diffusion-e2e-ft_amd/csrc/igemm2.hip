@@ -483,7 +483,7 @@ template <typename T, int MODE, int NW> static int launch2(IgemmParams& p, int n
         const long span_imgs = 256 / ((long)p.hout * p.wout) + 2;
         fast = p.cin % BK == 0 && p.c1 % BK == 0 && img_bytes * span_imgs < 0xD0000000L && (long)128 * p.ldw * (long)sizeof(T) < 0x40000000L;
     }
-    static const bool nofast = getenv("E2EFT_IGEMM_NOFAST") != nullptr;
+    const bool nofast = option(E2EFT_OPT_IGEMM_GENERAL_OPERANDS) != 0;
     if (p.ksplit_taps > 0 && !(fast && !nofast && MODE == 1)) return fail(E2EFT_ERR_BAD_ARG, "igemm2: split-K needs the FAST conv path");
     if (fast && !nofast) hipLaunchKernelGGL((igemm2_kernel<T, MODE, true, NW>), grid, dim3(NW * 64), 0, s, p);
     else hipLaunchKernelGGL((igemm2_kernel<T, MODE, false, NW>), grid, dim3(NW * 64), 0, s, p);
@@ -491,7 +491,7 @@ template <typename T, int MODE, int NW> static int launch2(IgemmParams& p, int n
 }
 
 template <typename T> static int launch2_t(int mode, IgemmParams& p, int nz, hipStream_t s) {
-    static const int forced_nw = [] { const char* e = getenv("E2EFT_IGEMM2_NW"); return e ? atoi(e) : 0; }();
+    const int forced_nw = option(E2EFT_OPT_IGEMM2_WAVES);
     // two 128-row workgroups per CU fill the machine better on mid-size problems; 256-row tiles halve the weight traffic on big ones
     const long blocks256 = (long)cdiv(p.M, 256) * cdiv(p.N, BN2) * nz;
     const int nw = forced_nw ? forced_nw : (blocks256 < 256 ? 4 : 8);

@@ -26,7 +26,7 @@
 //     layout (a lane owns two columns), values rounded there, two rows per dword through LDS — half the staging bytes, readers only store.
 // Contract, operand layouts, ring, swizzle: as igemm2.hip.  Eligibility is decided on the host (launch_igemm_persistent returns -1 and the
 // caller falls through to igemm2): 16-bit FAST path, M a multiple of 256, at least three k-tiles, the vector epilogue, at least two tiles
-// per workgroup.  E2EFT_PERSIST=0 disables the variant (A/B runs), E2EFT_PERSIST_GRID=<n> shrinks the grid (tests).
+// per workgroup.  e2eft_set_option(E2EFT_OPT_PERSISTENT, 0) disables the variant (A/B runs), E2EFT_OPT_PERSISTENT_GRID shrinks the grid (tests).
 //
 // GroupNorm statistics (p.gn_partial): per column shifted sums about a per-wave pivot (the wave's first output row), a 14-exchange
 // reduce-scatter over the eight row-lanes of a chunk, per-wave deposits in LDS merged over the four row-waves of a column with Chan's
@@ -37,7 +37,7 @@
 // kept: a 4th fragment slot requested across the barrier, row-table reads one MFMA group early, statistics merge under the next tile's
 // MFMAs, a register-only (operand-swapped) epilogue for GEMM tiles, tap offsets after the fragment requests.
 #include "igemm.h"
-#include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 namespace e2eft {
@@ -435,6 +435,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         f2 bva[2], rav[2], pv[2], sm[2], sq[2];   // per owned column j: bias * alpha, row vector, pivot, shifted sums (pairs = two rows at a time)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            // association as in the fp32 epilogue below and igemm2's vector row pass: fma(rowadd, alpha, fma(acc, alpha, bias * alpha))
             const float bj = bias ? to_f(col_bias[j]) * al : 0.f, rj = has_ra ? to_f(col_ra[j]) : 0.f;
             bva[j] = f2{bj, bj}; rav[j] = f2{rj, rj};
             pv[j] = f2{0.f, 0.f}; sm[j] = f2{0.f, 0.f}; sq[j] = f2{0.f, 0.f};
@@ -681,8 +682,20 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     }
 }
 
-static int g_pers_cus = 0;
-static long g_pers_launches = 0;   // debug counter (tests assert that the variant under test really ran)
+static std::atomic<int> g_cus_of_device[64];     // CU count per device ordinal (0 = not queried yet): one process may drive several GPUs
+static std::atomic<long> g_pers_launches{0};      // debug counter (tests assert that the variant under test really ran)
+
+static int device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int n = g_cus_of_device[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return 0;
+        n &= ~7;
+        g_cus_of_device[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
 
 template <typename T, int MODE> static int launch5(IgemmParams& p, int nz, int total, int grid, hipStream_t s) {
     if (p.residual) hipLaunchKernelGGL((igemm5_kernel<T, MODE, true>), dim3(grid), dim3(512), 0, s, p, total);
@@ -692,8 +705,7 @@ template <typename T, int MODE> static int launch5(IgemmParams& p, int nz, int t
 
 int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s) {
     using namespace pers;
-    static const int enabled = [] { const char* e = getenv("E2EFT_PERSIST"); return e ? atoi(e) : 1; }();
-    if (!enabled) return -1;
+    if (!option(E2EFT_OPT_PERSISTENT)) return -1;
     if (dtype != E2EFT_F16 && dtype != E2EFT_BF16) return -1;
     if (p.ksplit_taps > 0 || p.bias_along_m) return -1;
     if (p.M % BM != 0 || p.K % 64 != 0 || p.K / 64 < 3) return -1;
@@ -709,26 +721,20 @@ int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStre
         const long span_imgs = 256 / ((long)p.hout * p.wout) + 2;
         if (p.cin % 64 != 0 || p.c1 % 64 != 0 || img_bytes * span_imgs >= 0xD0000000L || (long)128 * p.ldw * 2 >= 0x40000000L) return -1;
     }
-    if (g_pers_cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return -1;
-        g_pers_cus = n & ~7;
-        if (const char* e = getenv("E2EFT_PERSIST_GRID")) {   // tests: a small grid sends small problems through the persistent kernel
-            const int g = atoi(e) & ~7;
-            if (g >= 8 && g <= g_pers_cus) g_pers_cus = g;
-        }
-    }
+    int g_pers_cus = device_cus();     // CUs of the CURRENT device (the one the caller's stream belongs to)
+    if (g_pers_cus == 0) return -1;
+    const int gopt = option(E2EFT_OPT_PERSISTENT_GRID);   // tests: a small grid sends small problems through the persistent kernel
+    if (gopt >= 8 && gopt < g_pers_cus) g_pers_cus = gopt;
     const int mtiles = p.M / BM, ntiles = cdiv(p.N, BN);
     const long total = (long)mtiles * ntiles * nz;
     if (total < 2L * g_pers_cus || total > 2000000000L || mtiles >= (1 << 22)) return -1;   // (tile / row splits use a float reciprocal: quotients below 2^22)
     p.mtiles = mtiles;
     p.ntiles = ntiles;
-    if (p.gn_partial) {   // statistics need whole tiles inside one image
-        const bool ok = nz == 1 && p.rows_per_img % BM == 0 && p.M % p.rows_per_img == 0;
-        if (ok) p.gn_nslabs = p.rows_per_img / BM;
-        else p.gn_partial = nullptr;
+    if (p.gn_partial) {   // statistics need whole tiles inside one image; otherwise igemm2 may still be able to emit them (128-row slabs): fall through
+        if (!(nz == 1 && p.rows_per_img % BM == 0 && p.M % p.rows_per_img == 0)) return -1;
+        p.gn_nslabs = p.rows_per_img / BM;
     }
-    ++g_pers_launches;
+    g_pers_launches.fetch_add(1, std::memory_order_relaxed);
     if (dtype == E2EFT_F16) return mode ? launch5<f16, 1>(p, nz, (int)total, g_pers_cus, s) : launch5<f16, 0>(p, nz, (int)total, g_pers_cus, s);
     return mode ? launch5<bf16, 1>(p, nz, (int)total, g_pers_cus, s) : launch5<bf16, 0>(p, nz, (int)total, g_pers_cus, s);
 }
@@ -740,4 +746,4 @@ extern "C" int e2eft_debug_read_stamps5(long long* host, int nworkgroups) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(e2eft::g_stamps5), (size_t)nworkgroups * 32 * 8 * sizeof(long long));
 }
 #endif
-extern "C" long e2eft_debug_persistent_launches(void) { return e2eft::g_pers_launches; }   // not part of include/e2eft.h
+extern "C" long e2eft_debug_persistent_launches(void) { return e2eft::g_pers_launches.load(); }   // not part of include/e2eft.h

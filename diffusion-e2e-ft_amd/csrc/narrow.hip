@@ -186,8 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_narrow_mfma_kernel(const Narro
 }
 
 template <typename T> static void launch_narrow_t(const NarrowParams& p, dim3 grid, hipStream_t s) {
-    static const int mfma = [] { const char* e = getenv("E2EFT_NARROW_MFMA"); return e ? atoi(e) : 1; }();
-    if (mfma && p.cin % 32 == 0) {
+    if (option(E2EFT_OPT_NARROW_MFMA) && p.cin % 32 == 0) {
         hipLaunchKernelGGL((conv3x3_narrow_mfma_kernel<T>), grid, dim3(256), 0, s, p, (const T*)p.w);
         return;
     }
@@ -202,8 +201,7 @@ template <typename T> static void launch_narrow_t(const NarrowParams& p, dim3 gr
 
 // returns -1 when the problem is not this kernel's (the caller then runs the implicit-GEMM path), else the launch status
 int launch_conv3x3_narrow(const E2eftConvDesc* d, const void* x1, const void* w, const void* bias, void* out, void* stream) {
-    static const int enabled = [] { const char* e = getenv("E2EFT_NARROW"); return e ? atoi(e) : 1; }();
-    if (!enabled) return -1;
+    if (!option(E2EFT_OPT_NARROW_CONV)) return -1;
     if (d->dtype != E2EFT_F16 && d->dtype != E2EFT_BF16) return -1;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->c2 != 0) return -1;
     if (d->cout < 1 || d->cout > NR_CO || d->hl != d->hin || d->wl != d->win || d->hout != d->hin || d->wout != d->win) return -1;

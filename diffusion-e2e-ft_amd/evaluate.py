@@ -15,10 +15,17 @@ METRIC_NAMES = ("abs_relative_difference", "squared_relative_difference", "rmse_
 
 
 def _b(t):
+    """[H,W] / [B,H,W] / [B,1,H,W] -> [B,H,W]; anything else is an error (a [B,3,H,W] prediction must not spin here)"""
     t = torch.as_tensor(t)
-    while t.dim() > 3:
-        t = t.squeeze(1)
-    return t[None] if t.dim() == 2 else t
+    if t.dim() == 4:
+        if t.shape[1] != 1:
+            raise ValueError("expected a depth map [B,1,H,W], [B,H,W] or [H,W]; got shape %s" % (tuple(t.shape),))
+        t = t[:, 0]
+    if t.dim() == 2:
+        return t[None]
+    if t.dim() != 3:
+        raise ValueError("expected a depth map [B,1,H,W], [B,H,W] or [H,W]; got shape %s" % (tuple(t.shape),))
+    return t
 
 
 @torch.no_grad()

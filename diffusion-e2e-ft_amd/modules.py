@@ -64,6 +64,7 @@ def to_nchw_view(y):
 
 # ------------------------------------------------------------------------------------------------------------
 class Conv2d(nn.Conv2d):
+    @ops.device_scoped
     def forward(self, x):  # public NCHW-logical surface (vae.quant_conv(h) etc.)
         return to_nchw_view(conv_nhwc(self, to_nhwc(x)))
 
@@ -122,6 +123,8 @@ class ResnetBlock2D(nn.Module):
         else:
             h = self.norm1.nhwc(x, x2=x2, silu=True)
         rowadd = self.__dict__.pop("_rowadd_pre", None)     # inference: projected for all blocks at once (unet.py::_batch_small_gemms)
+        if torch.is_grad_enabled():
+            rowadd = None                                    # never under autograd: the slice carries no graph
         if rowadd is None and self.time_emb_proj is not None:
             rowadd = self.time_emb_proj(temb_act)
         h = conv_nhwc(self.conv1, h, rowadd=rowadd)
@@ -228,7 +231,7 @@ class Attention(nn.Module):
             else:
                 q = self.to_q(x)
                 kv = self.__dict__.pop("_kv_pre", None)         # inference: keys / values of the (shared) context for all layers at once
-                if kv is None:
+                if kv is None or torch.is_grad_enabled():
                     kv = F.linear(ctx, (self.to_k.weight, self.to_v.weight), owner=self, name="wkv")
                 k, v = kv[..., :C], kv[..., C:]
             a = ops.attention(q, k, v, self.heads, self.scale, kv_nseg=2 if self.joint else 1, kv_bmod=B // 2 if self.joint else B)
@@ -347,8 +350,15 @@ class VaeAttention(nn.Module):
             a = F.attention(qkv, None, 1, C ** -0.5)
             return out(a, residual=x.reshape(B, H * W, C)).view(B, H, W, C)
         dt = x.dtype
-        a = attention_unfused(n, n, self.to_q.weight, F._vec(self.to_q.bias, dt), self.to_k.weight, F._vec(self.to_k.bias, dt), self.to_v.weight,
-                              F._vec(self.to_v.bias, dt), 1, C ** -0.5)
+        if dt != torch.float32 and C == 512:
+            # 16-bit inference: one fused q|k|v projection, then the fused d = 512 kernel (csrc/attn512.hip) — no [B, HW, HW] score matrix
+            bias = F.cached(self, "b_qkv_%s" % dt, (self.to_q.bias, self.to_k.bias, self.to_v.bias),
+                            lambda: torch.cat([self.to_q.bias.detach().to(dt), self.to_k.bias.detach().to(dt), self.to_v.bias.detach().to(dt)]))
+            qkv = F.linear(n, (self.to_q.weight, self.to_k.weight, self.to_v.weight), bias, owner=self, name="wqkv")
+            a = ops.attention512(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], C ** -0.5)
+        else:
+            a = attention_unfused(n, n, self.to_q.weight, F._vec(self.to_q.bias, dt), self.to_k.weight, F._vec(self.to_k.bias, dt), self.to_v.weight,
+                                  F._vec(self.to_v.bias, dt), 1, C ** -0.5)
         o = out(a, residual=x.reshape(B, H * W, C), gn_rows_per_image=H * W)
         res = o.view(B, H, W, C)
         st = getattr(o, "_e2eft_gn", None)

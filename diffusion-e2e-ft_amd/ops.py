@@ -87,10 +87,11 @@ def round_up(v, m):
 
 
 def _check_cuda(*ts):
-    """Every wrapper passes its tensors through here before it launches: they must be HIP tensors of ONE device, and that device
-    becomes the calling thread's current device (the library launches on `torch.cuda.current_stream()` of the current device, so a
-    model moved with `pipe.to("cuda:1")` in a process whose current device is still 0 would otherwise launch on device 0's stream
-    with device-1 pointers).  One process drives one GPU; the switch is sticky on purpose."""
+    """Every wrapper passes its tensors through here before it launches: they must be HIP tensors of ONE device, and that device must
+    be the calling thread's current device — the library launches on `torch.cuda.current_stream()`, i.e. on a stream of the CURRENT
+    device, so device-1 pointers under a current device 0 would be launched on the wrong GPU.  The caller's current device is never
+    changed behind their back: run a model that lives on another device inside `with torch.cuda.device(model.device):` (the pipelines'
+    entry points do that themselves, `pipeline._on_device`)."""
     idx = None
     for t in ts:
         if t is None:
@@ -102,7 +103,51 @@ def _check_cuda(*ts):
         elif t.device.index != idx:
             raise RuntimeError("libe2eft ops need all tensors of a call on one device; got cuda:%d and cuda:%d" % (idx, t.device.index))
     if idx is not None and idx != torch.cuda.current_device():
-        torch.cuda.set_device(idx)
+        raise RuntimeError("libe2eft ops launch on the current device's stream: tensors live on cuda:%d but the current device is cuda:%d; "
+                           "wrap the call in `with torch.cuda.device(%d):`" % (idx, torch.cuda.current_device(), idx))
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def on_device_of(t):
+    """context manager: the device of tensor / module-parameter `t` is the current device inside (a no-op object when it already is)"""
+    dev = t.device
+    if dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+        return _NULL
+    return torch.cuda.device(dev)
+
+
+def device_scoped(fn):
+    """decorator for the entry points of the host layer (module forwards, pipeline calls): runs the call with the device of the first
+    tensor argument (or of `self`'s first parameter) as the current device and restores the caller's current device afterwards"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        t = next((a for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
+        if t is None and isinstance(self, torch.nn.Module):
+            t = next(self.parameters(), None)
+        if t is None and isinstance(getattr(type(self), "device", None), property):   # pipelines: .device of their UNet
+            dev = self.device
+            if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+                with torch.cuda.device(dev):
+                    return fn(self, *args, **kwargs)
+            return fn(self, *args, **kwargs)
+        if t is None or not t.is_cuda:
+            return fn(self, *args, **kwargs)
+        with on_device_of(t):
+            return fn(self, *args, **kwargs)
+
+    return wrapper
 
 
 def _nhwc_ld(t):
@@ -423,6 +468,25 @@ def attention(q, k, v, heads, scale, kv_nseg=1, kv_bmod=None, out=None, return_l
     with _timed("attn", 4.0 * B * heads * Nq * Nk * kv_nseg * 64, label="attn B%d h%d Nq%d Nk%d" % (B, heads, Nq, Nk * kv_nseg)):
         check(_lib.load().e2eft_attn_fwd_lse(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), _stream()))
     return (out, lse) if return_lse else out
+
+
+def attention512(q, k, v, scale, out=None):
+    """Fused attention of ONE 512-wide head (the VAE mid-block attention), fp16 / bf16.  q / k / v: [B, N, 512] views (row-strided: slices
+    of one fused q|k|v projection are fine)."""
+    _check_cuda(q, k, v, out)
+    B, Nq, Wd = q.shape
+    Nk = k.shape[1]
+    assert Wd == 512 and k.shape[2] == 512 and v.shape == k.shape and k.shape[0] == B
+    if out is None:
+        out = torch.empty((B, Nq, 512), dtype=q.dtype, device=q.device)
+    d = AttnDesc()
+    d.dtype = dtype_id(q.dtype)
+    d.batch, d.heads, d.nq, d.nk_seg, d.kv_nseg, d.kv_bmod = B, 1, Nq, Nk, 1, B
+    d.ldq, d.ldk, d.ldv, d.ldo = _ld3(q), _ld3(k), _ld3(v), _ld3(out)
+    d.scale = scale
+    with _timed("attn512", 4.0 * B * Nq * Nk * 512, label="attn512 B%d Nq%d Nk%d" % (B, Nq, Nk)):
+        check(_lib.load().e2eft_attn512_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _stream()))
+    return out
 
 
 def attention_bwd(q, k, v, out, dout, lse, heads, scale, dq, dk, dv):
@@ -866,6 +930,17 @@ def adamw_step_(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
     check(_lib.load().e2eft_adamw_step(param.numel(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), lr, beta1, beta2, eps, weight_decay, step,
                                        _ptr(grad_sumsq), grad_scale, max_norm, _stream()))
+    return param
+
+
+def adamw_step_guarded_(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, state, coef, grad_sumsq, grad_scale=1.0, max_norm=0.0):
+    """AdamW with the step counter on the device (`state` int64 [2] = applied / skipped steps) and a skip on a non-finite gradient norm"""
+    _check_cuda(param, grad, exp_avg, exp_avg_sq, state, coef, grad_sumsq)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
+    assert state.dtype == torch.int64 and state.numel() == 2 and coef.dtype == torch.float32 and coef.numel() == 4 and grad_sumsq.dtype == torch.float64
+    check(_lib.load().e2eft_adamw_step_guarded(param.numel(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), lr, beta1, beta2, eps, weight_decay,
+                                               _ptr(state), _ptr(coef), _ptr(grad_sumsq), grad_scale, max_norm, _stream()))
     return param
 
 

@@ -114,6 +114,7 @@ class MarigoldPipeline:
         self.empty_text_embed = self.text_encoder(ids)[0].to(self.dtype)
 
     # ---- marigold_pipeline.py:481-498 ----
+    @ops.device_scoped
     @torch.no_grad()
     def encode_rgb(self, rgb_in):
         h = self.vae.encoder(rgb_in)
@@ -126,6 +127,7 @@ class MarigoldPipeline:
         return self.vae.decoder(z)
 
     # ---- marigold_pipeline.py:501-519 ----
+    @ops.device_scoped
     @torch.no_grad()
     def decode_depth(self, depth_latent):
         """the channel mean of the decoded image, NOT clipped (the reference clips in single_infer, :475-477)"""
@@ -133,11 +135,13 @@ class MarigoldPipeline:
         return ops.depth_head(stacked.permute(0, 2, 3, 1), to_unit="mean")
 
     # ---- marigold_pipeline.py:522-538 ----
+    @ops.device_scoped
     @torch.no_grad()
     def decode_normal(self, normal_latent):
         return self._decode(normal_latent)
 
     # ---- marigold_pipeline.py:372-478 ----
+    @ops.device_scoped
     @torch.no_grad()
     def single_infer(self, rgb_in, num_inference_steps, show_pbar=False, noise="gaussian", normals=False, generator=None):
         device, dt = self.device, self.dtype
@@ -214,6 +218,7 @@ class MarigoldPipeline:
         mark()
         return out
 
+    @ops.device_scoped
     @torch.no_grad()
     def stage_times_ms(self, rgb_in, normals=False, repeats=3):
         """{"vae_encode", "unet", "vae_decode"}: mean milliseconds per batch of the three stages of the E2E-FT path (HIP events on the
@@ -261,6 +266,7 @@ class MarigoldPipeline:
         return s_out.clone()
 
     # ---- marigold_pipeline.py:158-353 ----
+    @ops.device_scoped
     @torch.no_grad()
     def __call__(self, input_image, denoising_steps=10, ensemble_size=10, processing_res=768, match_input_res=True,
                  resample_method="bilinear", batch_size=0, color_map="Spectral", show_progress_bar=True, ensemble_kwargs=None,
@@ -416,6 +422,7 @@ class DepthNormalEstimationPipeline:
             self._clip_key = key
         return self._clip_const
 
+    @ops.device_scoped
     @torch.no_grad()
     def encode_img_embed(self, rgb):
         """geowizard_pipeline.py:232-248 (__encode_img_embed): CLIP image embedding [B,1,X] of rgb in [-1,1]; resize + normalisation
@@ -503,6 +510,7 @@ class DepthNormalEstimationPipeline:
         normal = ops.normal_head(self._m._decode(geo[B:]).permute(0, 2, 3, 1), clamp=False, sign=-1.0)
         return depth, normal
 
+    @ops.device_scoped
     @torch.no_grad()
     def single_infer(self, input_rgb, num_inference_steps=1, domain="indoor", show_pbar=False, noise="zeros", img_embed=None, generator=None):
         """Positional order of the reference (geowizard_pipeline.py:252-258: input_rgb, num_inference_steps, domain, show_pbar, noise).
@@ -551,6 +559,7 @@ class DepthNormalEstimationPipeline:
         return s_out[0].clone(), s_out[1].clone()
 
     # ---- geowizard_pipeline.py:88-230 ----
+    @ops.device_scoped
     @torch.no_grad()
     def __call__(self, input_image, denoising_steps=1, ensemble_size=1, processing_res=768, match_input_res=True, batch_size=0,
                  domain="indoor", color_map="Spectral", show_progress_bar=False, ensemble_kwargs=None, noise="zeros"):

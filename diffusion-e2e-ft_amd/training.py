@@ -70,6 +70,12 @@ def e2e_ft_loss(unet, vae, batch, empty_encoding, modality="depth", noise_schedu
     `accelerator.prepare`, train.py:369): attributes are read from `.module`, the forward goes through the wrapper."""
     core = getattr(unet, "module", unet)
     dev = core.device
+    with ops.on_device_of(next(core.parameters())):
+        return _e2e_ft_loss(unet, core, vae, batch, empty_encoding, modality, noise_scheduler, return_estimate)
+
+
+def _e2e_ft_loss(unet, core, vae, batch, empty_encoding, modality, noise_scheduler, return_estimate):
+    dev = core.device
     dt = getattr(core, "compute_dtype", core.dtype)
     with torch.no_grad():
         rgb_latents = encode_image(vae, batch["rgb"].to(device=dev, dtype=dt)) * vae.config.scaling_factor
@@ -112,6 +118,11 @@ def geowizard_e2e_ft_loss(unet, vae, batch, imgs_embed, domain="indoor", depth_s
     embedding, the frozen decoder decodes both halves, loss = 0.5 * SSI(depth) + 1.0 * angular(normals vs -GT).
     imgs_embed: CLIP image embeddings [b,1,768] (an input here)."""
     core = getattr(unet, "module", unet)
+    with ops.on_device_of(next(core.parameters())):
+        return _geowizard_e2e_ft_loss(unet, core, vae, batch, imgs_embed, domain, depth_scale, normal_scale, return_parts)
+
+
+def _geowizard_e2e_ft_loss(unet, core, vae, batch, imgs_embed, domain, depth_scale, normal_scale, return_parts):
     dev = core.device
     dt = getattr(core, "compute_dtype", core.dtype)
     with torch.no_grad():
@@ -136,42 +147,71 @@ def geowizard_e2e_ft_loss(unet, vae, batch, imgs_embed, domain="indoor", depth_s
 
 
 # ------------------------------------------------------------------------------------------------------------
-class FlatAdamW:
-    """AdamW + gradient clipping over one flat fp32 buffer, gradient all-reduce overlapped with the backward.
+class FlatAdamW(torch.optim.Optimizer):
+    """`torch.optim.AdamW` + `clip_grad_norm_` (training/train.py:346-353,561-566) over ONE flat fp32 buffer, with the data-parallel
+    gradient all-reduce overlapped with the backward.
 
-    params: iterable of trainable Parameters (fp32, same device).  Their storage is moved into `self.flat_param`
-    (diffusers-layout views, state_dict() keeps working) and `.grad` is pre-bound to views of `self.flat_grad`, so autograd
-    accumulates straight into the exchange buffer."""
+    A real `torch.optim.Optimizer`: one `param_groups` entry whose `lr` is live (so `LambdaLR(optimizer, IterExponential(...))` of
+    train.py:356-357 drives it), `state[p] = {"step", "exp_avg", "exp_avg_sq"}` per parameter (views of the flat moment buffers and of
+    the device-side step counter), `state_dict()` / `load_state_dict()` in torch's own format (`accelerator.save_state / load_state`,
+    train.py:417-440,578-599, and checkpoints written by `torch.optim.AdamW` load here and vice versa), `zero_grad(set_to_none=...)`,
+    `step(closure=None)`.
+
+    What is flat: the storage of every trainable Parameter is moved into `self.flat_param` (diffusers-layout views: `state_dict()` of the
+    model keeps working), `.grad` is pre-bound to views of `self.flat_grad`, so autograd accumulates straight into the exchange buffer,
+    the exchange is a handful of large RCCL all-reduces over contiguous slices (no bucket copies) launched from autograd hooks while the
+    rest of the backward is still running, and clip + update are one `sumsq` and one `adamw` launch.
+
+    external_grad_sync=True: somebody else averages the gradients across ranks (a DistributedDataParallel wrap by `accelerator.prepare`,
+    train.py:369) — no hooks, no division by the world size here.
+    Non-finite gradient norm: the step is skipped on the device, the bias-correction step does not advance, `skipped_steps()` counts it
+    (e2eft_adamw_step_guarded, include/e2eft.h)."""
 
     def __init__(self, params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0, n_slices=4,
-                 process_group=None):
-        self.params = [p for p in params if p.requires_grad]
-        assert self.params, "no trainable parameters"
-        dev = self.params[0].device
-        for p in self.params:
+                 process_group=None, external_grad_sync=False):
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            if len(params) != 1:
+                raise ValueError("FlatAdamW updates one flat buffer with one set of hyper-parameters: pass a single parameter group")
+            group0 = dict(params[0])
+            plist = [p for p in group0.pop("params") if p.requires_grad]
+            lr, betas, eps, weight_decay = group0.get("lr", lr), group0.get("betas", betas), group0.get("eps", eps), group0.get("weight_decay", weight_decay)
+        else:
+            plist = [p for p in params if p.requires_grad]
+        if not plist:
+            raise ValueError("no trainable parameters")
+        dev = plist[0].device
+        for p in plist:
             if p.dtype != torch.float32:
                 raise TypeError("FlatAdamW keeps fp32 master parameters; got %s" % p.dtype)
-        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+            if p.device != dev:
+                raise ValueError("FlatAdamW: all parameters must live on one device")
+        super().__init__(plist, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.params = plist
+        self.max_grad_norm = max_grad_norm
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
             n += (p.numel() + 3) // 4 * 4                     # keep every view 16-byte aligned
         self.numel = n
-        self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
-        with torch.no_grad():
-            for p, o in zip(self.params, self.offsets):
-                view = self.flat_param[o:o + p.numel()].view(p.shape)
-                view.copy_(p.data)
-                p.data = view
-                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        with ops.on_device_of(plist[0]):
+            self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+            self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+            self._steps = torch.zeros(2, dtype=torch.int64, device=dev)      # {applied, skipped} — advanced by the update kernel itself
+            self._coef = torch.zeros(4, dtype=torch.float32, device=dev)
+            with torch.no_grad():
+                for p, o in zip(self.params, self.offsets):
+                    view = self.flat_param[o:o + p.numel()].view(p.shape)
+                    view.copy_(p.data)
+                    p.data = view
+                    p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        self._bind_state()
         F.bump_param_epoch()
-        self.step_count = 0
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.world = 1 if external_grad_sync else (dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1)
         # Slices of the flat buffer, cut by BYTES.  Parameters are stored in module order (conv_in, down, mid, up, conv_out) and the
         # backward produces gradients roughly in reverse, so the slice holding the FIRST parameters completes last and its exchange is
         # the one that cannot hide under the backward: slice sizes grow geometrically (1 : 2 : 4 : ...), the exposed one is the smallest
@@ -205,6 +245,61 @@ class FlatAdamW:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
+    # ---- torch.optim.Optimizer surface -------------------------------------------------------------------------------------------
+    def _bind_state(self):
+        """state[p]: views of the flat moment buffers; "step" is a view of the device-side applied-step counter shared by all parameters"""
+        step = self._steps[0]
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.state[p] = {"step": step, "exp_avg": self.exp_avg[o:o + n].view(p.shape), "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape)}
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, v):
+        self.param_groups[0]["lr"] = v
+
+    @property
+    def step_count(self):
+        """applied steps (host value; synchronises)"""
+        return int(self._steps[0].item())
+
+    def skipped_steps(self):
+        """optimizer steps dropped because the gradient norm was not finite (host value; synchronises)"""
+        return int(self._steps[1].item())
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for st in sd["state"].values():          # torch's format wants per-parameter tensors that survive on their own
+            st["step"] = st["step"].detach().to(torch.float32).clone()
+            st["exp_avg"] = st["exp_avg"].detach().clone()
+            st["exp_avg_sq"] = st["exp_avg_sq"].detach().clone()
+        sd["flat_adamw"] = {"skipped_steps": self.skipped_steps(), "max_grad_norm": self.max_grad_norm}
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        extra = state_dict.get("flat_adamw", {})
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != "flat_adamw"})   # group hyper-parameters (lr, betas, ...) + per-parameter copies
+        steps = set()
+        for p, o in zip(self.params, self.offsets):
+            st = self.state.get(p)
+            n = p.numel()
+            if not st:                            # parameter without saved state (fresh): zero moments
+                self.exp_avg[o:o + n].zero_()
+                self.exp_avg_sq[o:o + n].zero_()
+                continue
+            self.exp_avg[o:o + n].view(p.shape).copy_(st["exp_avg"])
+            self.exp_avg_sq[o:o + n].view(p.shape).copy_(st["exp_avg_sq"])
+            steps.add(int(torch.as_tensor(st["step"]).item()))
+        if len(steps) > 1:
+            raise ValueError("FlatAdamW.load_state_dict: parameters carry different step counts %s; one flat buffer has one bias correction" % sorted(steps))
+        self._steps[0] = steps.pop() if steps else 0
+        self._steps[1] = int(extra.get("skipped_steps", 0))
+        self._bind_state()
+
     # autograd hook: a parameter's gradient is final for this backward
     def _on_grad(self, p):
         if not self.sync_grads:
@@ -224,25 +319,49 @@ class FlatAdamW:
             sl["work"].wait()
             sl["work"], sl["ready"] = None, 0
 
+    def _adopt_grads(self):
+        """A caller may have re-bound .grad (zero_grad(set_to_none=True) of a generic training loop, then autograd created fresh tensors;
+        a DDP wrap handing out its bucket views): bring every gradient back into its slot of the flat buffer.  No-op in the normal case."""
+        base = self.flat_grad.data_ptr()
+        for p, o in zip(self.params, self.offsets):
+            g = p.grad
+            if g is not None and g.data_ptr() == base + 4 * o and g.is_contiguous():
+                continue
+            slot = self.flat_grad[o:o + p.numel()].view(p.shape)
+            if g is None:
+                slot.zero_()
+            else:
+                slot.copy_(g)
+            p.grad = slot
+
     @torch.no_grad()
-    def step(self, lr_scale=1.0, grad_scale=1.0):
-        """all-reduce(mean) -> clip_grad_norm_(max_grad_norm) -> AdamW; returns nothing (no host synchronisation)."""
-        self._finish_exchange()
-        self.step_count += 1
-        gs = grad_scale / self.world
-        sumsq = None
-        if self.max_grad_norm and self.max_grad_norm > 0:
-            sumsq = ops.sumsq(self.flat_grad, out=self._sumsq)
-        ops.adamw_step_(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr * lr_scale, self.betas[0], self.betas[1], self.eps,
-                        self.weight_decay, self.step_count, grad_sumsq=sumsq, grad_scale=gs, max_norm=self.max_grad_norm or 0.0)
+    def step(self, closure=None, lr_scale=1.0, grad_scale=1.0):
+        """all-reduce(mean) -> clip_grad_norm_(max_grad_norm) -> AdamW, no host synchronisation.  lr = param_groups[0]["lr"] * lr_scale."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        with ops.on_device_of(self.flat_param):
+            self._finish_exchange()
+            self._adopt_grads()
+            g = self.param_groups[0]
+            sumsq = ops.sumsq(self.flat_grad, out=self._sumsq)     # always: the non-finite guard needs it even without clipping
+            ops.adamw_step_guarded_(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, float(g["lr"]) * lr_scale, g["betas"][0], g["betas"][1],
+                                    g["eps"], g["weight_decay"], self._steps, self._coef, sumsq, grad_scale=grad_scale / self.world,
+                                    max_norm=float(self.max_grad_norm or 0.0))
         F.bump_param_epoch()
+        return loss
 
     def grad_norm(self):
         """global L2 norm of the (averaged) gradient — host value, synchronises"""
-        return math.sqrt(float(ops.sumsq(self.flat_grad, out=self._sumsq).item())) / self.world
+        with ops.on_device_of(self.flat_param):
+            self._adopt_grads()
+            return math.sqrt(float(ops.sumsq(self.flat_grad, out=self._sumsq).item())) / self.world
 
     @torch.no_grad()
-    def zero_grad(self):
+    def zero_grad(self, set_to_none=False):
+        """Gradients are zeroed in ONE memset of the flat buffer and stay bound to it (also with set_to_none=True: a fresh `.grad` tensor
+        per parameter would take the gradient out of the exchange buffer; `step()` would copy it back, at a price)."""
         self.flat_grad.zero_()
         for p, o in zip(self.params, self.offsets):      # autograd may have re-bound .grad (e.g. set_to_none by a caller)
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:

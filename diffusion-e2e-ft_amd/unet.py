@@ -19,6 +19,9 @@ from .modules import (Conv2d, GroupNorm, ResnetBlock2D, Transformer2DModel, Down
                       checkpointed, conv_nhwc, to_nhwc, to_nchw_view)
 
 
+BATCHED_PROJECTIONS = True   # A/B switch of UNet2DConditionModel._batch_small_gemms (inference: time / context projections as two GEMMs)
+
+
 class Config(OrderedDict):
     """dict with attribute access (diffusers FrozenDict surface: cfg.x, cfg['x'], cfg['x'] = v)."""
 
@@ -278,7 +281,7 @@ class UNet2DConditionModel(nn.Module):
         Here each family is ONE GEMM over the weights concatenated along the output dimension (the same dot products, element for
         element); the consumers pick up their slice (`ResnetBlock2D.nhwc`, `Attention.forward`)."""
         from .modules import ResnetBlock2D, Attention
-        if os.environ.get("E2EFT_BATCHED_PROJ", "1") == "0":    # A/B switch
+        if not BATCHED_PROJECTIONS:    # A/B switch
             return
         dt = temb_act.dtype
         fam = self.__dict__.get("_small_gemm_family")
@@ -307,8 +310,26 @@ class UNet2DConditionModel(nn.Module):
                 m.__dict__["_kv_pre"] = kv[..., o:o + c2]
                 o += c2
 
+    def _drop_small_gemm_slices(self):
+        """forget every pre-projected slice `_batch_small_gemms` handed to a block: a forward that aborted midway (OOM in validation)
+        must not leave pre-update, grad-less projections behind for the next forward to pick up"""
+        fam = self.__dict__.get("_small_gemm_family")
+        if fam is not None:
+            for m in fam[0]:
+                m.__dict__.pop("_rowadd_pre", None)
+            for m in fam[1]:
+                m.__dict__.pop("_kv_pre", None)
+
     # ---- forward ----
+    @ops.device_scoped
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, return_dict=True, **unused):
+        self._drop_small_gemm_slices()
+        try:
+            return self._forward(sample, timestep, encoder_hidden_states, class_labels, return_dict)
+        finally:
+            self._drop_small_gemm_slices()
+
+    def _forward(self, sample, timestep, encoder_hidden_states, class_labels, return_dict):
         cfg = self.config
         dt = self.compute_dtype
         if sample.dtype != dt:

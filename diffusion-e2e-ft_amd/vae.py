@@ -9,6 +9,7 @@ import os
 import torch
 from torch import nn
 
+from . import ops
 from .modules import (Conv2d, GroupNorm, ResnetBlock2D, Downsample2D, Upsample2D, VaeAttention, checkpointed, conv_nhwc, to_nhwc, to_nchw_view)
 from .unet import Config
 
@@ -79,6 +80,7 @@ class Encoder(nn.Module):
         h = self.conv_norm_out.nhwc(h, silu=True)
         return conv_nhwc(self.conv_out, h)
 
+    @ops.device_scoped
     def forward(self, x):
         return to_nchw_view(self.nhwc(to_nhwc(x)))
 
@@ -106,6 +108,7 @@ class Decoder(nn.Module):
         h = self.conv_norm_out.nhwc(h, silu=True)
         return conv_nhwc(self.conv_out, h)
 
+    @ops.device_scoped
     def forward(self, z):
         return to_nchw_view(self.nhwc(to_nhwc(z)))
 

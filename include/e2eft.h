@@ -19,6 +19,8 @@
  *     and softmax are always fp32.
  *   - Alignment: all base pointers 16-byte aligned; channel counts and pixel strides multiples of
  *     16 bytes / sizeof(dtype) unless a function says otherwise.
+ *   - State: the thread-local error string and the process-wide tuning options below (e2eft_set_option) are the
+ *     ONLY mutable state of the library.  The library never reads the environment.
  */
 #ifndef E2EFT_H
 #define E2EFT_H
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define E2EFT_VERSION 111 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
+#define E2EFT_VERSION 112 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
 
 enum {
     E2EFT_OK = 0,
@@ -45,9 +47,26 @@ enum { E2EFT_F32 = 0, E2EFT_F16 = 1, E2EFT_BF16 = 2 };
 int e2eft_version(void);
 const char* e2eft_last_error(void);
 
+/* Process-wide tuning options (A/B measurements and tests; the defaults are what the product path runs with).  Setting an
+ * option affects launches issued AFTER the call, on every thread.  e2eft_set_option returns E2EFT_ERR_BAD_ARG for an
+ * unknown key or an out-of-range value; e2eft_get_option returns -1 for an unknown key. */
+enum {
+    E2EFT_OPT_PERSISTENT = 0,        /* 1 (default): big 16-bit GEMM / conv launches run on the persistent kernel (igemm5); 0: never */
+    E2EFT_OPT_PERSISTENT_GRID = 1,   /* 0 (default): one workgroup per CU of the launch's device; n >= 8 (multiple of 8): at most n */
+    E2EFT_OPT_NARROW_CONV = 2,       /* 1 (default): <= 4-output-channel 3x3 convs on the LDS-halo kernel (narrow.hip); 0: MFMA tile */
+    E2EFT_OPT_NARROW_MFMA = 3,       /* 1 (default): MFMA 16x16x32 form of that kernel; 0: v_dot2 form */
+    E2EFT_OPT_IGEMM_GENERAL_OPERANDS = 4, /* 0 (default); 1: igemm2 takes its general (per-lane gather) operand path for every launch */
+    E2EFT_OPT_IGEMM2_WAVES = 5,      /* 0 (default): 8-wave 256-row tiles when >= 256 of them exist, else 4-wave 128-row; 4 / 8: forced */
+    E2EFT_OPT_COUNT = 6
+};
+int e2eft_set_option(int32_t key, int32_t value);
+int e2eft_get_option(int32_t key);
+
 /* ------------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / GEMM (MFMA).
  *   out[m, n] = alpha * ( sum_k A[m, k] * W[n, k] + bias[n] + rowadd[img(m), n] ) + residual[m, n]
+ *   (fp32 arithmetic; with alpha != 1 the vector epilogues evaluate fma(rowadd, alpha, fma(acc, alpha, bias * alpha)), the scalar
+ *   edge-tile path (acc + bias + rowadd) * alpha: the last bit of a result may depend on the tile path the shape selects)
  * conv mode (kh*kw > 1 or stride/upsample/two sources): m = (b, oy, ox), k = ((ky*kw + kx)*cin + c),
  *   A gathered on the fly from the NHWC input(s) with zero padding; weights pre-packed OHWI = W[n][k].
  * Replaces: nn.Conv2d in diffusers ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D.conv,
@@ -181,6 +200,11 @@ int e2eft_attn_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const v
 /* same, also storing lse[batch][heads][nq] (fp32): the base-2 log-sum-exp of the scaled scores of every query row, which
  * e2eft_attn_bwd needs to recompute the probabilities (lse may be NULL) */
 int e2eft_attn_fwd_lse(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, float* lse, void* stream);
+/* Fused attention forward for ONE head of width 512 (fp16 / bf16): the mid-block attention of AutoencoderKL
+ * (GeoWizard/geowizard/models/unet_2d_blocks.py:589-601 — `Attention(heads = 1, dim_head = 512)` through AttnProcessor2_0:
+ * F.scaled_dot_product_attention on [B, 1, H*W, 512]).  Descriptor as above with heads = 1, kv_nseg = 1, kv_bmod = batch;
+ * q / k / v / out rows of 512 elements (row strides ld*, so slices of one fused q|k|v projection are fine). */
+int e2eft_attn512_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, void* stream);
 /* Fused attention backward (head dim 64, fp16 / bf16, kv_nseg == 1; autograd of F.scaled_dot_product_attention /
  * xformers.memory_efficient_attention in diffusers Attention processors, attention.py:338-343,375-380): dq [B,Nq,heads*64],
  * dk / dv [B,Nk,heads*64] (row strides lddq / lddk / lddv), from q, k, v, the forward output `out` (desc ldo), its gradient
@@ -380,6 +404,16 @@ int e2eft_sumsq(int64_t n, const float* g, double* out, void* stream);
 int e2eft_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int32_t step, const double* grad_sumsq, float grad_scale,
                      float max_norm, void* stream);
+/* The same update with the step counter on the device and a guard against a non-finite gradient norm.  state: int64[2] device words
+ * {applied steps, skipped steps} (zero them once; save / restore them with the optimizer state); coef: float[4] device scratch.
+ * grad_sumsq must be given (e2eft_sumsq of `grad`).  Finite norm: state[0] += 1 and the AdamW update with the bias correction of
+ * step = state[0], gradient scaled by grad_scale * min(1, max_norm / (norm * grad_scale + 1e-6)) (max_norm <= 0: no clipping).
+ * Non-finite norm: state[1] += 1, parameters and moments untouched — the bias-correction step does NOT advance.  (The reference,
+ * training/train.py:548-566, drops a NaN loss term but still steps AdamW on whatever gradient is there; a NaN gradient would
+ * poison weights and moments for good, so this library skips and counts instead.)  No host synchronisation. */
+int e2eft_adamw_step_guarded(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t* state, float* coef, const double* grad_sumsq,
+                             float grad_scale, float max_norm, void* stream);
 /* y = (accumulate ? y : 0) + x * mul with dtype conversion (fp32 master weights -> 16-bit compute copies, 16-bit gradients
  * accumulated into the fp32 flat gradient buffer) */
 int e2eft_cast(int32_t dt_in, int32_t dt_out, int64_t n, float mul, int32_t accumulate, const void* x, void* y, void* stream);

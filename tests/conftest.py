@@ -19,4 +19,11 @@ def dev():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    # whole-suite A/B runs: E2EFT_TEST_PERSISTENT_GRID=8 sends every eligible SMALL problem of the tests through the persistent kernel,
+    # E2EFT_TEST_PERSISTENT=0 keeps everything on igemm2 (the library itself never reads the environment: e2eft_set_option)
+    from diffusion_e2e_ft_amd import _lib
+    if "E2EFT_TEST_PERSISTENT_GRID" in os.environ:
+        _lib.set_option(_lib.OPT_PERSISTENT_GRID, int(os.environ["E2EFT_TEST_PERSISTENT_GRID"]))
+    if "E2EFT_TEST_PERSISTENT" in os.environ:
+        _lib.set_option(_lib.OPT_PERSISTENT, int(os.environ["E2EFT_TEST_PERSISTENT"]))
     return torch.device("cuda:0")

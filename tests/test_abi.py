@@ -25,7 +25,25 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "libe2eft.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.e2eft_version() == 111
+    assert lib.e2eft_version() == 112
+
+
+def test_options_are_the_only_global_state_and_the_library_never_reads_the_environment():
+    """eight getenv switches inside an ABI whose contract says "no global mutable state" -> e2eft_set_option / e2eft_get_option"""
+    from diffusion_e2e_ft_amd import _lib
+    lib = _lib.load()
+    defaults = [lib.e2eft_get_option(k) for k in range(6)]
+    assert defaults == [1, 0, 1, 1, 0, 0]
+    assert lib.e2eft_set_option(_lib.OPT_PERSISTENT_GRID, 8) == 0 and lib.e2eft_get_option(_lib.OPT_PERSISTENT_GRID) == 8
+    assert lib.e2eft_set_option(_lib.OPT_PERSISTENT_GRID, 12) == 1 and b"out of range" in lib.e2eft_last_error()     # not a multiple of 8
+    assert lib.e2eft_set_option(99, 0) == 1 and lib.e2eft_get_option(99) == -1
+    with _lib.option(_lib.OPT_PERSISTENT, 0):
+        assert lib.e2eft_get_option(_lib.OPT_PERSISTENT) == 0
+    assert lib.e2eft_get_option(_lib.OPT_PERSISTENT) == 1
+    _lib.set_option(_lib.OPT_PERSISTENT_GRID, 0)
+    csrc = os.path.join(ROOT, "diffusion-e2e-ft_amd", "csrc")
+    for fn in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, fn)).read(), fn
 
 
 def test_struct_layouts_match_header():

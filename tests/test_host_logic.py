@@ -201,3 +201,62 @@ def test_small_gemm_families_of_the_sd2_unet():
     from diffusion_e2e_ft_amd import modules, unet
     assert "_rowadd_pre" in inspect.getsource(modules.ResnetBlock2D.nhwc) and "_kv_pre" in inspect.getsource(modules.Attention.forward)
     assert "_rowadd_pre" in inspect.getsource(unet.UNet2DConditionModel._batch_small_gemms)
+
+
+def test_flat_adamw_is_a_torch_optimizer_with_live_lr_and_torch_format_state():
+    """training/train.py:346-357 builds `torch.optim.AdamW(...)` + `LambdaLR(optimizer, IterExponential(...))`, :417-440,578-599 save / load the
+    optimizer through accelerate (= optimizer.state_dict() / load_state_dict()).  FlatAdamW must be usable in exactly those places: host-side
+    surface only here (the update itself is a HIP kernel: tests/test_train_gpu.py)."""
+    from torch.optim.lr_scheduler import LambdaLR
+    from diffusion_e2e_ft_amd.training import FlatAdamW, IterExponential
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    ref.load_state_dict(net.state_dict())
+    opt = FlatAdamW(net.parameters(), lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    assert isinstance(opt, torch.optim.Optimizer) and len(opt.param_groups) == 1
+    g = opt.param_groups[0]
+    assert (g["lr"], g["betas"], g["eps"], g["weight_decay"]) == (3e-5, (0.9, 0.999), 1e-8, 1e-2) and len(g["params"]) == 4
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))      # flattening keeps the values
+    # the reference's scheduler drives the group's lr (train.py:356-357); the step itself is not run on the CPU
+    lam = IterExponential(total_iter_length=20000, final_ratio=0.01, warmup_steps=100)
+    sched = LambdaLR(opt, lr_lambda=lam)
+    assert opt.param_groups[0]["lr"] == 0.0 and opt.lr == 0.0                                  # warm-up starts at 0
+    sched.last_epoch = 49
+    sched._step_count = 50
+    opt._opt_called = True      # (silences LambdaLR's "step order" warning: no optimizer.step() on a CPU box)
+    sched.step()
+    assert abs(opt.param_groups[0]["lr"] - 3e-5 * 0.5) < 1e-12
+    # state in torch's own format: a torch.optim.AdamW checkpoint loads, and ours loads into torch.optim.AdamW
+    ropt = torch.optim.AdamW(ref.parameters(), lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    ref(torch.randn(4, 6)).sum().backward()
+    ropt.step()
+    opt.load_state_dict(ropt.state_dict())
+    for p, rp, o in zip(opt.params, ref.parameters(), opt.offsets):
+        assert torch.equal(opt.exp_avg[o:o + p.numel()].view(p.shape), ropt.state[rp]["exp_avg"])
+        assert torch.equal(opt.state[p]["exp_avg_sq"], ropt.state[rp]["exp_avg_sq"])
+        assert opt.state[p]["exp_avg"].data_ptr() == opt.exp_avg.data_ptr() + 4 * o            # state stays a VIEW of the flat moments
+    assert opt.step_count == 1 and opt.skipped_steps() == 0
+    sd = opt.state_dict()
+    assert set(sd) == {"state", "param_groups", "flat_adamw"} and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    ropt2 = torch.optim.AdamW(ref.parameters(), lr=1.0)
+    ropt2.load_state_dict({k: v for k, v in sd.items() if k != "flat_adamw"})
+    assert ropt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"] and float(ropt2.state[next(ref.parameters())]["step"]) == 1.0
+    # zero_grad keeps .grad bound to the flat buffer, also with set_to_none=True; a re-bound .grad is adopted back
+    opt.zero_grad(set_to_none=True)
+    p0 = opt.params[0]
+    assert p0.grad is not None and p0.grad.data_ptr() == opt.flat_grad.data_ptr()
+    p0.grad = torch.ones_like(p0)
+    opt._adopt_grads()
+    assert p0.grad.data_ptr() == opt.flat_grad.data_ptr() and opt.flat_grad[:p0.numel()].eq(1).all()
+    with pytest.raises(ValueError):
+        FlatAdamW([{"params": [torch.nn.Parameter(torch.zeros(2))]}, {"params": [torch.nn.Parameter(torch.zeros(2))]}])
+
+
+def test_evaluate_rejects_multi_channel_input_instead_of_spinning():
+    from diffusion_e2e_ft_amd import evaluate
+    assert evaluate._b(torch.zeros(4, 5)).shape == (1, 4, 5) and evaluate._b(torch.zeros(2, 1, 4, 5)).shape == (2, 4, 5)
+    with pytest.raises(ValueError):
+        evaluate._b(torch.zeros(2, 3, 4, 5))
+    with pytest.raises(ValueError):
+        evaluate._b(torch.zeros(2, 4, 5, 1, 1))

@@ -178,9 +178,6 @@ def test_groupnorm(ops, dev, dtype, C, H, W, c2, silu, offset):
 def test_groupnorm_with_producer_statistics(ops, dev, dtype, H, W, Ci, Co, k, c2):
     """conv / linear epilogues emit the GroupNorm partial statistics of their output; GroupNorm fed with them must match both
     the torch reference and the stand-alone statistics pass (two sources: one with, one without producer statistics)."""
-    import os
-    if os.environ.get("E2EFT_IGEMM") == "1":
-        pytest.skip("the register-staged cross-check kernel (E2EFT_IGEMM=1) does not emit statistics by design")
     g = _g(H * 3 + Co)
     B = 3
     x = q(torch.randn(B, Ci, H, W, generator=g) + 0.5, dtype)
@@ -432,9 +429,6 @@ def test_conv_statistics_repeatable_with_coresident_workgroups(ops, dev):
     """Regression for DESIGN.md §3.6: B=3, 48x48, 640 output channels gives 270 tiles of 128x128 on 256 CUs, i.e. a few CUs hold
     two 4-wave workgroups in different phases.  The producer statistics must equal the statistics of the tensor that was written,
     launch after launch (scripts/stress_conv_stats.py is the long version)."""
-    import os
-    if os.environ.get("E2EFT_IGEMM") == "1":
-        pytest.skip("the register-staged cross-check kernel (E2EFT_IGEMM=1) does not emit statistics by design")
     import time
     torch.manual_seed(5)
     B, H, W, cin, cout = 3, 48, 48, 1920, 640

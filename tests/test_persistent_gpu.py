@@ -1,9 +1,9 @@
 """igemm5.hip (persistent workgroups walking a tile sequence, wave-private sliced epilogue) against torch CPU.  The variant takes only
-problems with at least two tiles per CU; E2EFT_PERSIST_GRID=8 shrinks the grid to eight workgroups so that SMALL problems — which the
+problems with at least two tiles per CU; e2eft_set_option(E2EFT_OPT_PERSISTENT_GRID, 8) shrinks the grid to eight workgroups so that SMALL problems — which the
 CPU reference finishes in seconds — run through it: every operand mode of the FAST path (3x3 / strided / 1x1-as-GEMM / fused upsample /
 two-source concat / zero-insertion dgrad), GEMM and batched GEMM, 3, 4, 5 and many k-tiles per tile, ragged N tiles, tile counts that
-do not divide by the grid, several images per tile, every epilogue option, the fused GroupNorm statistics.  The variable is read once
-per process, so the cases run in a subprocess; the debug counter proves the variant really ran."""
+do not divide by the grid, several images per tile, every epilogue option, the fused GroupNorm statistics.  The cases run in a
+subprocess (so that the option never leaks into other tests of the session); the debug counter proves the variant really ran."""
 import os
 import subprocess
 import sys
@@ -24,6 +24,8 @@ from diffusion_e2e_ft_amd import ops, _lib
 from util import nhwc, to_nchw, pack_conv_weight, q, rel_err, TOL
 dev = torch.device("cuda:0")
 lib = _lib.load()
+_lib.set_option(_lib.OPT_PERSISTENT_GRID, int(os.environ.get("TEST_PERSISTENT_GRID", "0")))
+_lib.set_option(_lib.OPT_PERSISTENT, int(os.environ.get("TEST_PERSISTENT", "1")))
 lib.e2eft_debug_persistent_launches.restype = ctypes.c_long
 EXPECT = int(os.environ.get("EXPECT_PERSISTENT", "1"))
 def launches():
@@ -191,9 +193,9 @@ def _run(env_extra):
 
 
 def test_persistent_kernel_on_small_shapes(dev):
-    _run({"E2EFT_PERSIST_GRID": "8", "EXPECT_PERSISTENT": "1"})
+    _run({"TEST_PERSISTENT_GRID": "8", "EXPECT_PERSISTENT": "1"})
 
 
 def test_same_cases_without_the_variant(dev):
-    """E2EFT_PERSIST=0: every case runs on igemm2 — the reference numbers of the A/B"""
-    _run({"E2EFT_PERSIST": "0", "EXPECT_PERSISTENT": "0"})
+    """E2EFT_OPT_PERSISTENT = 0: every case runs on igemm2 — the reference numbers of the A/B"""
+    _run({"TEST_PERSISTENT": "0", "EXPECT_PERSISTENT": "0"})

@@ -271,3 +271,94 @@ def test_gradient_checkpointing_gives_bit_equal_gradients_and_saves_memory(dev, 
     with torch.no_grad():
         b = unet(x.to(dev), torch.tensor(999, device=dev), ctx.to(dev)).sample
     assert torch.equal(a, b)
+
+
+def _toy(dev, seed=0):
+    torch.manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 24), torch.nn.Tanh(), torch.nn.Linear(24, 8), torch.nn.Linear(8, 1)).to(dev)
+    return net
+
+
+def test_flat_adamw_in_the_reference_training_loop_with_lambdalr_and_resume(dev):
+    """The optimizer as training/train.py uses it: `torch.optim.AdamW(...)` -> FlatAdamW, `LambdaLR(optimizer, IterExponential)` (:356-357),
+    `clip_grad_norm_` + `optimizer.step()` + `lr_scheduler.step()` + `optimizer.zero_grad()` (:561-566), `save_state` / `load_state` (:417-440,
+    578-599).  Five steps against torch.optim.AdamW on the same data; then state_dict -> fresh model + optimizer -> load -> the next step must be
+    bit-equal to the uninterrupted run."""
+    from torch.optim.lr_scheduler import LambdaLR
+    from diffusion_e2e_ft_amd.training import FlatAdamW, IterExponential
+    net, ref = _toy(dev), _toy(dev)
+    lam = IterExponential(total_iter_length=12, final_ratio=0.01, warmup_steps=3)
+    opt = FlatAdamW(net.parameters(), lr=2e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0)
+    ropt = torch.optim.AdamW(ref.parameters(), lr=2e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    sched, rsched = LambdaLR(opt, lr_lambda=lam), LambdaLR(ropt, lr_lambda=lam)
+    g = torch.Generator(device=dev).manual_seed(3)
+    xs = [torch.randn(32, 16, device=dev, generator=g) for _ in range(7)]
+
+    def one(model, optimizer, scheduler, x, clip_ref):
+        loss = (model(x) ** 2).mean() * 40.0
+        loss.backward()
+        if clip_ref:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        optimizer.step()
+        scheduler.step()
+        optimizer.zero_grad()
+        return loss
+
+    for i in range(5):
+        one(net, opt, sched, xs[i], False)
+        one(ref, ropt, rsched, xs[i], True)
+        assert abs(opt.param_groups[0]["lr"] - ropt.param_groups[0]["lr"]) < 1e-15
+        for p, rp in zip(net.parameters(), ref.parameters()):
+            assert rel_err(p, rp) < 2e-5, i
+    assert opt.step_count == 5 and opt.skipped_steps() == 0
+    # ---- checkpoint, then the uninterrupted run takes step 6
+    ckpt = {"model": {k: v.clone() for k, v in net.state_dict().items()}, "opt": opt.state_dict(), "sched": sched.state_dict()}
+    one(net, opt, sched, xs[5], False)
+    # ---- resume in fresh objects
+    net2 = _toy(dev, seed=99)
+    net2.load_state_dict(ckpt["model"])
+    opt2 = FlatAdamW(net2.parameters(), lr=123.0, max_grad_norm=1.0)          # hyper-parameters come back from the checkpoint
+    sched2 = LambdaLR(opt2, lr_lambda=lam)
+    opt2.load_state_dict(ckpt["opt"])
+    sched2.load_state_dict(ckpt["sched"])
+    assert opt2.step_count == 5 and opt2.param_groups[0]["lr"] == ckpt["opt"]["param_groups"][0]["lr"]
+    one(net2, opt2, sched2, xs[5], False)
+    for p, p2 in zip(net.parameters(), net2.parameters()):
+        assert torch.equal(p, p2)
+    assert torch.equal(opt.exp_avg, opt2.exp_avg) and torch.equal(opt.exp_avg_sq, opt2.exp_avg_sq) and opt2.step_count == 6
+    # ---- and torch.optim.AdamW resumes from OUR checkpoint to the same step (torch's own state format)
+    ref3 = _toy(dev, seed=98)
+    ref3.load_state_dict(ckpt["model"])
+    ropt3 = torch.optim.AdamW(ref3.parameters(), lr=1.0)
+    ropt3.load_state_dict({k: v for k, v in ckpt["opt"].items() if k != "flat_adamw"})
+    rsched3 = LambdaLR(ropt3, lr_lambda=lam)
+    rsched3.load_state_dict(ckpt["sched"])
+    one(ref3, ropt3, rsched3, xs[5], True)
+    for p, rp in zip(net.parameters(), ref3.parameters()):
+        assert rel_err(p, rp) < 2e-5
+
+
+def test_flat_adamw_skips_a_non_finite_gradient_on_the_device_and_counts_it(dev):
+    """a NaN / inf gradient norm must not reach the master weights or the moments; the bias-correction step does not advance; the caller can see
+    the skip.  Also with max_grad_norm = 0 (no clipping), where the old code path had no guard."""
+    from diffusion_e2e_ft_amd.training import FlatAdamW
+    for mgn in (1.0, 0.0):
+        net = _toy(dev)
+        opt = FlatAdamW(net.parameters(), lr=1e-2, max_grad_norm=mgn)
+        x = torch.randn(8, 16, device=dev)
+        net(x).sum().backward()
+        opt.step()
+        opt.zero_grad()
+        before = [p.detach().clone() for p in net.parameters()]
+        m0, v0 = opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+        net(x).sum().backward()
+        next(net.parameters()).grad[0, 0] = float("nan") if mgn else float("inf")
+        opt.step()
+        opt.zero_grad()
+        assert all(torch.equal(a, b) for a, b in zip(before, net.parameters())) and torch.equal(m0, opt.exp_avg) and torch.equal(v0, opt.exp_avg_sq)
+        assert opt.step_count == 1 and opt.skipped_steps() == 1
+        net(x).sum().backward()
+        opt.step()                                   # a clean step afterwards is step 2, not 3
+        assert opt.step_count == 2 and opt.skipped_steps() == 1
+        assert not any(torch.equal(a, b) for a, b in zip(before, net.parameters()))
+        assert all(torch.isfinite(p).all() for p in net.parameters())
