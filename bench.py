@@ -27,7 +27,9 @@ import torch  # noqa: E402
 
 # algorithmic forward work per image, GFLOP
 WORK_GF = {768: dict(unet=2140.0, enc=2613.0, dec=5763.0), 576: dict(unet=1060.0, enc=1427.0, dec=3199.0),
-           256: dict(unet=177.0, enc=273.0, dec=623.0)}
+           256: dict(unet=177.0, enc=273.0, dec=623.0), "576x768": dict(unet=1489.0, enc=1928.0, dec=4289.0)}
+# the only number the reference publishes for this path (README.md:145-158): one 576x768 image, 121 ms on an RTX 4090 (other hardware: context)
+REF_README_LATENCY_MS = 121.0
 PEAK_TF = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -38,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="images per rank per step")
-    ap.add_argument("--res", type=int, default=None, help="default 768 (inference, configs[1]) / 576 (--train, configs[2])")
+    ap.add_argument("--res", default=None, help="R or HxW; default 768 (inference, configs[1]) / 576 (--train, configs[2])")
     ap.add_argument("--dtype", default=None, choices=["fp16", "bf16", "fp32"], help="default fp16 (inference, configs[1]) / bf16 (--train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail", default=None, help="write a per-shape kernel table (TSV) to this path")
@@ -55,6 +57,7 @@ def parse():
     ap.add_argument("--no-image-encoder", action="store_true", help="--geowizard: feed a CLIP image embedding as input instead of running ViT-L/14")
     ap.add_argument("--geowizard", action="store_true", help="time GeoWizard joint depth+normals 1-step inference (BASELINE.json configs[4]: "
                     "dual-latent UNet with cross-domain attention, 2 images per GPU by default) instead of Marigold depth")
+    ap.add_argument("--no-latency-leg", action="store_true", help="inference mode at N=1: skip the one-image 576x768 latency measurement (`latency_b1_576x768`)")
     ap.add_argument("--no-train-leg", action="store_true", help="inference mode at N=1: skip the E2E-FT training-step measurements "
                     "that are appended to the JSON line as `train_step` (bf16 compute) and `train_step_fp32` (the reference recipe)")
     ap.add_argument("--plumbing-check", action="store_true", help="launcher / rendezvous / timing-reduction check without GPU work (gloo, CPU): "
@@ -62,6 +65,9 @@ def parse():
     args = ap.parse_args()
     if args.res is None:
         args.res = 576 if args.train else 768
+    hw = str(args.res).lower().split("x")
+    args.res_h, args.res_w = (int(hw[0]), int(hw[0])) if len(hw) == 1 else (int(hw[0]), int(hw[1]))
+    args.res = args.res_h if args.res_h == args.res_w else "%dx%d" % (args.res_h, args.res_w)
     if args.dtype is None:
         args.dtype = "bf16" if args.train else "fp16"
     return args
@@ -266,7 +272,7 @@ def run_train(args, rank, world, dev):
         unet.enable_gradient_checkpointing()
         vae.enable_gradient_checkpointing()
     opt = training.FlatAdamW(unet.parameters(), lr=3e-5, max_grad_norm=1.0)
-    R = args.res
+    R = args.res_h
     mb, acc = train_batching(args)
     text = 0.5 * torch.randn((1, 77, unet.config.cross_attention_dim), generator=torch.Generator(device=dev).manual_seed(0), device=dev)
     batches = [training.synthetic_batch(mb, R, R, dev, seed=1000 * rank + i, dtype=cdt) for i in range(acc)]
@@ -295,12 +301,7 @@ def run_train(args, rank, world, dev):
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
     ksum = timer.summary()
     if args.detail and rank == 0:
-        rows = sorted(timer.by_label().items(), key=lambda kv: -kv[1]["ms"])
-        with open(args.detail, "w") as f:
-            f.write("kernel\tlabel\tlaunches/step\tms/step\tTFLOP/s\tGB/s\n")
-            for (name, label), d in rows:
-                f.write("%s\t%s\t%.1f\t%.3f\t%.1f\t%.1f\n" % (name, label, d["launches"] / args.steps, d["ms"] / args.steps,
-                                                               d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] else 0, d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] else 0))
+        write_detail(args.detail, timer, args.steps)
     if rank == 0:
         n_img = mb * acc * world
         sec = elapsed / args.steps
@@ -361,7 +362,7 @@ def geowizard_main(args):
     pipe = DepthNormalEstimationPipeline(unet.eval(), vae.eval(), DDIMScheduler(), image_encoder=enc)
     if args.graph:
         pipe.enable_hip_graphs()
-    B, R = (args.batch if args.batch != 8 else 2), args.res
+    B, R = (args.batch if args.batch != 8 else 2), args.res_h
     g = torch.Generator(device=dev).manual_seed(rank)
     rgb = (torch.randint(0, 256, (B, 3, R, R), generator=g, device=dev, dtype=torch.int32).float() / 255.0 * 2.0 - 1.0).to(dtype)
     emb = None if enc is not None else (0.5 * torch.randn((B, 1, 768), generator=g, device=dev)).to(dtype)
@@ -413,6 +414,79 @@ def geowizard_main(args):
         dist.destroy_process_group()
 
 
+def write_detail(path, timer, steps):
+    """per-shape kernel table: one row per (family, shape label, kernel symbol as rocprofv3 names it)"""
+    rows = sorted(timer.by_label().items(), key=lambda kv: -kv[1]["ms"])
+    with open(path, "w") as f:
+        f.write("kernel\tlabel\tsymbol\tlaunches/step\tms/step\tTFLOP/s\tGB/s\talgorithmic_GFLOP/launch\n")
+        for (name, label), d in rows:
+            lab, sym = label if isinstance(label, tuple) else (label, "")
+            f.write("%s\t%s\t%s\t%.1f\t%.3f\t%.1f\t%.1f\t%.2f\n" % (name, lab, sym, d["launches"] / steps, d["ms"] / steps,
+                                                                      d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] else 0, d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] else 0,
+                                                                      d["flops"] / max(d["launches"], 1) / 1e9))
+
+
+def by_symbol(timer, steps):
+    """{kernel symbol: launches/step, ms/step, TFLOP/s} of the igemm family: the rocprofv3 kernel-stats rows can be recomputed one by one"""
+    out = {}
+    for (name, label), d in timer.by_label().items():
+        if name != "igemm" or not isinstance(label, tuple):
+            continue
+        a = out.setdefault(label[1], dict(launches=0, ms=0.0, flops=0.0))
+        a["launches"] += d["launches"]
+        a["ms"] += d["ms"]
+        a["flops"] += d["flops"]
+    return {k: dict(launches_per_step=v["launches"] / steps, ms_per_step=v["ms"] / steps, avg_us=v["ms"] * 1e3 / max(v["launches"], 1),
+                    tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0) for k, v in sorted(out.items(), key=lambda kv: -kv[1]["ms"])}
+
+
+def pmc_traffic(launches_per_step, want):
+    """HBM bytes per launch of the dominant family from the PMC counters.  rocprofv3 --pmc cannot wrap its own process, so the counters are
+    collected offline on exactly this workload (scripts/pmc_traffic.py) and committed with the build's launch count; the figure is printed
+    only when that count equals this run's (same kernel population), else null."""
+    prof = os.path.join(ROOT, "profiles")
+    files = sorted((f for f in os.listdir(prof) if f.endswith("_pmc_hbm_traffic.json")), reverse=True) if os.path.isdir(prof) else []
+    if not want:
+        return None, None, "no PMC profile for this workload", {}
+    seen = []
+    for fn in files:
+        with open(os.path.join(prof, fn)) as f:
+            pj = json.load(f)
+        k = pj["kernels"].get("igemm")
+        lps = k.get("launches_per_step") if k else None
+        seen.append("%s: %s" % (fn, lps))
+        if lps is not None and abs(lps - launches_per_step) < 0.01:
+            others = {g: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "launches_per_step": v.get("launches_per_step")} for g, v in pj["kernels"].items() if g != "igemm"}
+            return k["hbm_bytes_per_launch"], "static: profiles/%s (PMC pass of the same build: %s igemm launches per step there and here)" % (fn, lps), pj["source"], others
+    return None, None, "no committed PMC profile has this run's %.1f igemm launches per step (%s)" % (launches_per_step, "; ".join(seen[:4])), {}
+
+
+def latency_leg(pipe, dev, dtype, warm=5, iters=30):
+    g = torch.Generator(device=dev).manual_seed(123)
+    rgb1 = (torch.randint(0, 256, (1, 3, 576, 768), generator=g, device=dev, dtype=torch.int32).float() / 255.0 * 2.0 - 1.0).to(dtype)
+    pipe.enable_hip_graphs()
+    try:
+        for _ in range(warm):
+            o = pipe.single_infer(rgb1, 1, noise="zeros", normals=False)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            o = pipe.single_infer(rgb1, 1, noise="zeros", normals=False)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+    finally:
+        pipe.enable_hip_graphs(False)
+    assert torch.isfinite(o.float()).all()
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"metric": "latency of one 576x768 image, full path (VAE encode + UNet + VAE decode), host wall clock around single_infer + synchronize",
+            "value": med, "unit": "ms", "min_ms": ts[0], "p90_ms": ts[int(0.9 * (len(ts) - 1))], "iters": iters, "launch_mode": "hipGraph replay",
+            "dtype": str(dtype).replace("torch.", ""), "algorithmic_tflop": sum(WORK_GF["576x768"].values()) / 1e3,
+            "reference_readme_ms": REF_README_LATENCY_MS, "reference_hardware": "RTX 4090 (the reference's README.md:145-158; OTHER hardware: context, not a baseline)",
+            "vs_reference_readme": REF_README_LATENCY_MS / med}
+
+
 def _mark(timeline, what):
     """leg boundaries in seconds since process start: lets a GPU-busy trace sampled around this process be read (the CPU baseline leg
     keeps the GPU idle for about a minute BEFORE any GPU work)"""
@@ -451,9 +525,9 @@ def main():
     torch.set_num_threads(min(8, os.cpu_count() or 1))
 
     pipe = build_pipeline(dev, dtype, args.tiny)
-    B, R = args.batch, args.res
+    B, R, RH, RW = args.batch, args.res, args.res_h, args.res_w
     g = torch.Generator(device=dev).manual_seed(rank)
-    img = torch.randint(0, 256, (B, 3, R, R), generator=g, device=dev, dtype=torch.int32)
+    img = torch.randint(0, 256, (B, 3, RH, RW), generator=g, device=dev, dtype=torch.int32)
     rgb = (img.float() / 255.0 * 2.0 - 1.0).to(dtype)  # resident in HBM before the timed region (marigold_pipeline.py:245)
 
     def step():
@@ -468,9 +542,12 @@ def main():
     D.barrier()
     torch.cuda.synchronize()
     _mark(timeline, "inference timed region start")
-    timer = ops.KernelTimer()
+    # HIP events on the launch stream around every launch of the DOMINANT family (implicit GEMM) inside the timed region: that is what the
+    # roofline is computed from.  The other kernels run un-instrumented here (two event records per launch cost ~2 us of stream time each:
+    # 2 x 1.1k launches per step) and are timed in `args.steps` extra, fully instrumented steps after the region.
+    timer = ops.KernelTimer(only={"igemm"})
     if not args.graph:
-        ops.TIMER = timer             # HIP events around every launch, on the launch stream, inside the timed region
+        ops.TIMER = timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -492,13 +569,15 @@ def main():
         torch.cuda.synchronize()
         ops.TIMER = None
     ksum = timer.summary()
+    full = ops.KernelTimer()          # every instrumented launch: the other kernel families, the per-shape table
+    ops.TIMER = full
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    ops.TIMER = None
+    fsum = full.summary()
     if args.detail and rank == 0:
-        rows = sorted(timer.by_label().items(), key=lambda kv: -kv[1]["ms"])
-        with open(args.detail, "w") as f:
-            f.write("kernel\tlabel\tlaunches/step\tms/step\tTFLOP/s\tGB/s\n")
-            for (name, label), d in rows:
-                f.write("%s\t%s\t%.1f\t%.3f\t%.1f\t%.1f\n" % (name, label, d["launches"] / args.steps, d["ms"] / args.steps,
-                                                               d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] else 0, d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] else 0))
+        write_detail(args.detail, full, args.steps)
 
     if rank == 0:
         n_img = B * world * args.steps
@@ -506,22 +585,24 @@ def main():
         ig = ksum.get("igemm", dict(launches=0, ms=1e-9, flops=0.0, bytes=0.0))
         achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         peak = PEAK_TF[args.dtype]
+        lps = ig["launches"] / args.steps
+        alg_bpl = ig["bytes"] / max(ig["launches"], 1)
+        traffic, traffic_source, traffic_note, pmc_other = pmc_traffic(lps, (B, R, args.dtype, args.tiny) == (8, 768, "fp16", False))
         extra = {}
-        for k in ("attn", "groupnorm"):
-            if k in ksum and ksum[k]["ms"] > 0:
-                kk = ksum[k]
+        for k in ("attn", "attn512", "groupnorm"):
+            if k in fsum and fsum[k]["ms"] > 0:
+                kk = fsum[k]
                 extra[k] = dict(launches_per_step=kk["launches"] / args.steps, ms_per_step=kk["ms"] / args.steps,
                                 tflops=kk["flops"] / (kk["ms"] * 1e-3) / 1e12, gbs=kk["bytes"] / (kk["ms"] * 1e-3) / 1e9)
-        # HBM bytes per igemm launch from the PMC counters: collected offline (rocprofv3 --pmc cannot wrap its own process) on exactly
-        # this workload and committed with its provenance; null for any other workload
-        traffic, traffic_note, traffic_source = None, "no PMC profile for this workload", None
-        pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
-        if pmcs and (B, R, args.dtype, args.tiny) == (8, 768, "fp16", False):
-            with open(os.path.join(ROOT, "profiles", pmcs[-1])) as f:
-                pj = json.load(f)
-            traffic = pj["kernels"].get("igemm", pj["kernels"]["igemm2"])["hbm_bytes_per_launch"]
-            traffic_source = "static: profiles/%s (NOT measured in this run)" % pmcs[-1]
-            traffic_note = "bytes per launch (average over the %d igemm launches of a step), %s: %s" % (ig["launches"] / args.steps, pmcs[-1], pj["source"])
+        if "attn" in extra:
+            extra["attn"]["frac_of_mfma_peak"] = extra["attn"]["tflops"] / peak
+            pa = pmc_other.get("attn_fwd")
+            if pa:   # q, k, v read + out written once = the algorithmic bytes of an attention launch
+                extra["attn"]["hbm_bytes_per_launch_pmc"] = pa["hbm_bytes_per_launch"]
+        if "attn512" in extra:
+            extra["attn512"]["frac_of_mfma_peak"] = extra["attn512"]["tflops"] / peak
+        if "groupnorm" in extra:
+            extra["groupnorm"]["frac_of_hbm_peak"] = extra["groupnorm"]["gbs"] / HBM_PEAK_GBS
         line = {
             "metric": "images/sec (768x768, 1-step UNet fwd) full path: VAE encode + SD-v2 UNet @t=999 + VAE decode",
             "value": value, "unit": "images/s", "n_gpus": world, "world": world, "ranks": ranks, "rccl_ranks": world if world > 1 else 0,
@@ -529,14 +610,18 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.dtype == "fp16" else args.dtype, "data": "synthetic",
             "config": {"workload": "marigold-e2e-ft-depth 1-step inference, batch=%d/GPU at %dx%d %s, random-init SD-v2 UNet (866M) + SD VAE (84M)%s"
-                                   % (B, R, R, args.dtype, " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
+                                   % (B, RH, RW, args.dtype, " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
                        "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world,
                        "launch_mode": "hipGraph replay (one captured graph per batch shape)" if args.graph else "host launches"},
             "roofline": {"bound": "mfma", "kernel": "igemm5_kernel (persistent) + igemm2_kernel: implicit-GEMM conv/linear, all launches of the timed region",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "traffic_source": traffic_source, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": ig["bytes"] / max(ig["launches"], 1),
-                         "launches_per_step": ig["launches"] / args.steps, "kernel_ms_per_step": ig["ms"] / args.steps,
-                         "algorithmic_gflop_per_step": ig["flops"] / args.steps / 1e9, "other_kernels": extra},
+                         "traffic_over_algorithmic": (traffic / alg_bpl) if traffic else None,
+                         "traffic_source": traffic_source, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg_bpl,
+                         "launches_per_step": lps, "kernel_ms_per_step": ig["ms"] / args.steps,
+                         "algorithmic_gflop_per_step": ig["flops"] / args.steps / 1e9,
+                         "instrumentation": "HIP events around the igemm launches only inside the timed region; `other_kernels` and `by_symbol` from %d extra, "
+                                            "fully instrumented steps right after it" % args.steps,
+                         "by_symbol": by_symbol(full, args.steps), "other_kernels": extra},
         }
         try:   # stage split ("also report UNet-only"), measured after the timed region
             st = pipe.stage_times_ms(rgb, repeats=3)
@@ -550,6 +635,14 @@ def main():
             line["effective_tflops"] = value * tot / 1e3
         if cpu_leg is not None:
             line["cpu_baseline"] = cpu_leg
+        if world == 1 and not args.tiny and not args.no_latency_leg:
+            # the one figure the reference publishes for this path (README.md:145-158): ONE 576x768 image.  Batch 1 is launch-bound on the
+            # small UNet levels, so it is replayed from a captured hipGraph (bit-equal to the eager launches)
+            try:
+                _mark(timeline, "latency leg start")
+                line["latency_b1_576x768"] = latency_leg(pipe, dev, dtype)
+            except Exception as e:
+                line["latency_b1_576x768"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_train_leg and not args.tiny:
             # second part of BASELINE.json's metric ("...; E2E-FT step time"): configs[2], batch 32 at 576x576, one GPU - in the reference
             # recipe's precision (`--mixed_precision no`, training/scripts/train_marigold_e2e_ft_depth.sh:15) AND with bf16 compute over
@@ -562,6 +655,7 @@ def main():
                     _mark(timeline, "%s leg start" % key)
                     targs = argparse.Namespace(**vars(args))
                     targs.dtype, targs.res, targs.steps, targs.warmup, targs.detail, targs.micro_batch, targs.accum = tdt, 576, tsteps, 1, None, None, None
+                    targs.res_h = targs.res_w = 576
                     t = run_train(targs, 0, 1, dev)
                     line[key] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "images_per_s", "dtype", "steps", "warmup", "peak_mem_gib")}
                     line[key]["workload"] = t["config"]["workload"]

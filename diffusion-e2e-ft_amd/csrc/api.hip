@@ -22,6 +22,15 @@ int check_launch(const char* what) {
     return E2EFT_OK;
 }
 
+static thread_local char g_tag[96] = "";
+void tag_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_tag, sizeof(g_tag), fmt, ap);
+    va_end(ap);
+}
+const char* last_tag() { return g_tag; }
+
 static std::atomic<int> g_opt[E2EFT_OPT_COUNT] = {{1}, {0}, {1}, {1}, {0}, {0}};
 
 int option(int key) { return g_opt[key].load(std::memory_order_relaxed); }
@@ -39,6 +48,10 @@ extern "C" int e2eft_set_option(int32_t key, int32_t value) {
     return E2EFT_OK;
 }
 extern "C" int e2eft_get_option(int32_t key) { return key >= 0 && key < E2EFT_OPT_COUNT ? e2eft::option(key) : -1; }
+
+// debugging / measurement aid, not part of include/e2eft.h: the symbol (as rocprofv3 prints it, template arguments included) of the kernel the
+// calling thread's last implicit-GEMM launch went to
+extern "C" const char* e2eft_debug_last_kernel(void) { return e2eft::last_tag(); }
 
 extern "C" int e2eft_version(void) { return E2EFT_VERSION; }
 extern "C" const char* e2eft_last_error(void) { return e2eft::err_buf(); }

@@ -13,6 +13,7 @@ char* err_buf();
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
 int option(int key);   // process-wide tuning options (e2eft_set_option), api.hip
+void tag_kernel(const char* fmt, ...);   // thread-local name of the kernel a launcher just enqueued (e2eft_debug_last_kernel: bench.py --detail)
 
 #define E2EFT_REQUIRE(cond, ...)                                     \
     do {                                                             \

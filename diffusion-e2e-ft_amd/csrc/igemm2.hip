@@ -17,7 +17,6 @@
 // Two geometries (NW = waves per workgroup, wave tile always 64x64 = 2x2 MFMA 32x32, BN = 128):
 //   NW = 8: 256x128 tile, 3-stage ring, one workgroup per CU;   NW = 4: 128x128 tile, 2 stages, two workgroups per CU.
 #include "igemm.h"
-#include <stdlib.h>
 #include <type_traits>
 
 namespace e2eft {
@@ -487,6 +486,7 @@ template <typename T, int MODE, int NW> static int launch2(IgemmParams& p, int n
     if (p.ksplit_taps > 0 && !(fast && !nofast && MODE == 1)) return fail(E2EFT_ERR_BAD_ARG, "igemm2: split-K needs the FAST conv path");
     if (fast && !nofast) hipLaunchKernelGGL((igemm2_kernel<T, MODE, true, NW>), grid, dim3(NW * 64), 0, s, p);
     else hipLaunchKernelGGL((igemm2_kernel<T, MODE, false, NW>), grid, dim3(NW * 64), 0, s, p);
+    tag_kernel("igemm2_kernel<%s, %d, %s, %d>", sizeof(T) == 4 ? "float" : (std::is_same<T, f16>::value ? "_Float16" : "__bf16"), MODE, (fast && !nofast) ? "true" : "false", NW);
     return check_launch("igemm2");
 }
 

@@ -700,6 +700,7 @@ static int device_cus() {
 template <typename T, int MODE> static int launch5(IgemmParams& p, int nz, int total, int grid, hipStream_t s) {
     if (p.residual) hipLaunchKernelGGL((igemm5_kernel<T, MODE, true>), dim3(grid), dim3(512), 0, s, p, total);
     else hipLaunchKernelGGL((igemm5_kernel<T, MODE, false>), dim3(grid), dim3(512), 0, s, p, total);
+    tag_kernel("igemm5_kernel<%s, %d, %s>", std::is_same<T, f16>::value ? "_Float16" : "__bf16", MODE, p.residual ? "true" : "false");
     return check_launch("igemm5");
 }
 

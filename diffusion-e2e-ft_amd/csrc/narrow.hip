@@ -217,6 +217,7 @@ int launch_conv3x3_narrow(const E2eftConvDesc* d, const void* x1, const void* w,
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)d->batch);
     if (d->dtype == E2EFT_F16) launch_narrow_t<f16>(p, grid, s);
     else launch_narrow_t<bf16>(p, grid, s);
+    tag_kernel("conv3x3_narrow%s_kernel", (option(E2EFT_OPT_NARROW_MFMA) && p.cin % 32 == 0) ? "_mfma" : "");
     return check_launch("conv3x3_narrow");
 }
 

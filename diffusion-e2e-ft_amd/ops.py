@@ -16,8 +16,9 @@ class KernelTimer:
     """Optional per-launch timing with HIP events on the launch stream (torch's current stream): bench.py uses it to
     compute achieved TFLOP/s / GB/s per kernel family over the timed region.  Inactive (zero overhead) by default."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.rec = {}
+        self.only = only      # None: every instrumented launch; else a set of family names ("igemm", ...): the others run un-instrumented
 
     def add(self, name, start, end, flops, nbytes, label=None):
         self.rec.setdefault(name, []).append((start, end, flops, nbytes, label))
@@ -52,17 +53,28 @@ class _timed:
         self.name, self.flops, self.nbytes, self.label = name, flops, nbytes, label
 
     def __enter__(self):
-        if TIMER is not None:
+        self.on = TIMER is not None and (TIMER.only is None or self.name in TIMER.only)
+        if self.on:
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
             self.s.record()
         return self
 
     def __exit__(self, *a):
-        if TIMER is not None:
+        if self.on:
             self.e.record()
-            TIMER.add(self.name, self.s, self.e, self.flops, self.nbytes, self.label)
+            label = self.label
+            if self.name == "igemm":     # which kernel symbol the library's dispatch picked for this launch (debug entry, not in e2eft.h)
+                label = (label, _last_kernel())
+            TIMER.add(self.name, self.s, self.e, self.flops, self.nbytes, label)
         return False
+
+
+def _last_kernel():
+    lib = _lib.load()
+    fn = lib.e2eft_debug_last_kernel
+    fn.restype = C.c_char_p
+    return fn().decode()
 
 
 def _stream():

@@ -6,7 +6,10 @@ Collect (on the GPU box; counters in their OWN runs, --kernel-trace only, as gpu
       rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -o p -- \\
           python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train-leg
     done
-    python scripts/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE profiles/r01_pmc_hbm_traffic.json
+    python scripts/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE profiles/r01_pmc_hbm_traffic.json [steps_profiled]
+steps_profiled = the number of inference steps inside one profiled process (default 8 = 1 warm-up + 1 timed + 1 fully instrumented + 3 stage-timing steps
++ ... : bench.py prints it as `steps_in_process` on stderr); every group also gets `launches_per_step`, which bench.py matches against its own launch count
+before it prints the figure (a profile of another build — another launch population — is not printed).
 Units and corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide
 coalesced read -> doubled.  The correction is re-checked on every collection with gn_apply, whose read and write volumes are equal by
 construction (raw FETCH / WRITE must come out at 0.50)."""
@@ -18,7 +21,7 @@ import sys
 
 # "igemm" = the two kernels of the dominant family together (the persistent igemm5 takes the big launches, igemm2 the rest); "igemm2" / "igemm5" separately
 GROUPS = {"igemm": ("igemm2_kernel", "igemm5_kernel"), "igemm5": ("igemm5_kernel",), "igemm2": ("igemm2_kernel",), "gn_apply": ("gn_apply_kernel",),
-          "attn_fwd": ("attn_fwd_kernel",), "conv3x3_narrow": ("conv3x3_narrow_kernel",)}
+          "attn_fwd": ("attn_fwd_kernel",), "attn512_fwd": ("attn512_fwd_kernel",), "conv3x3_narrow": ("conv3x3_narrow",)}
 
 
 def load(d, counter):
@@ -39,8 +42,9 @@ def load(d, counter):
 
 def main():
     fd, wd, out = sys.argv[1:4]
+    steps = float(sys.argv[4]) if len(sys.argv) > 4 else 8.0
     fetch, write = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python bench.py --steps 1 --warmup 1 "
+    res = {"steps_profiled": steps, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python bench.py --steps 1 --warmup 1 "
                      "--no-cpu-baseline --no-train-leg` (B=8, 768x768, fp16), aggregated by scripts/pmc_traffic.py; counter unit KiB; FETCH_SIZE doubled "
                      "per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads) - re-checked on gn_apply, whose read and write volumes are "
                      "equal by construction (raw FETCH / WRITE ratio recorded below)", "kernels": {}}
@@ -49,7 +53,7 @@ def main():
             continue
         n = fetch[g][0]
         rf, rw = fetch[g][1] / n, write[g][1] / write[g][0]
-        res["kernels"][g] = {"launches": n, "fetch_bytes_per_launch_corrected": 2 * rf * 1024, "write_bytes_per_launch": rw * 1024,
+        res["kernels"][g] = {"launches": n, "launches_per_step": n / steps, "fetch_bytes_per_launch_corrected": 2 * rf * 1024, "write_bytes_per_launch": rw * 1024,
                              "hbm_bytes_per_launch": (2 * rf + rw) * 1024, "raw_fetch_kib_per_launch": rf, "raw_write_kib_per_launch": rw}
     if "gn_apply" in res["kernels"]:
         k = res["kernels"]["gn_apply"]
