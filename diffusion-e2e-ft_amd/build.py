@@ -21,8 +21,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # gfx950 that form sporadically read 0.0 in lanes 48-63 while a wave of ANOTHER workgroup on the same SIMD was inside its
 # MFMA / LDS-DMA k-loop (two 4-wave workgroups per CU).  Found as one GroupNorm-statistics row in ~1e-5 tiles using pivot 0;
 # plain v_sub_f32 / v_add_f32 never showed it (scripts/stress_conv_stats.py).
-# attn512.hip: packed fp32 adds beside MFMAs cost more than the scalar ones they replace (the kernel is one wave per SIMD, every issue slot counts)
-EXTRA_FLAGS = {"attn512.hip": ["-fno-slp-vectorize"], "igemm.hip": ["-fno-slp-vectorize"], "igemm2.hip": ["-fno-slp-vectorize"], "igemm5.hip": ["-fno-slp-vectorize"]}
+# attn.hip / attn512.hip: packed fp32 adds beside MFMAs cost more than the scalar ones they replace (the kernel is one wave per SIMD, every issue slot counts)
+EXTRA_FLAGS = {"attn.hip": ["-fno-slp-vectorize"], "attn512.hip": ["-fno-slp-vectorize"], "igemm.hip": ["-fno-slp-vectorize"], "igemm2.hip": ["-fno-slp-vectorize"], "igemm5.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

@@ -265,8 +265,8 @@ def test_config2_576_fp32_micro_step_gradients(dev, models, oracle_576):
 def test_config2_576_bf16_compute_micro_step_gradients(dev, models, oracle_576):
     """The training leg bench.py reports first (`train_step`: bf16 compute over fp32 master weights, bf16 frozen VAE) at the configs[2]
     resolution against the SAME fp32 oracle.  bf16 carries 8 mantissa bits through ~150 layers forward and back, so the bar is stated as
-    what a bf16 run can hold: loss within 5e-2, every sampled gradient within 0.35 of the reference in relative L2 norm AND cosine
-    similarity >= 0.94 (measured values are printed; the fp32 test above holds 2-4e-5 on the same tensors)."""
+    what a bf16 run can hold: loss within 1e-2, every sampled gradient within 0.10 of the reference in relative L2 norm AND cosine
+    similarity >= 0.995 (measured: loss 1.3e-5, L2 3.5e-2 .. 4.4e-2, cosine 0.9994 .. 0.9997; the fp32 test above holds 4-9e-5 on the same tensors)."""
     import copy
     from diffusion_e2e_ft_amd import training
     unet, vae, _, _, _ = models
@@ -287,6 +287,6 @@ def test_config2_576_bf16_compute_micro_step_gradients(dev, models, oracle_576):
     short = lambda k: k.split(".")[0] + ".." + k.split(".")[-2]
     print("576^2 bf16-compute micro-step: loss rel err %.3e; gradient rel L2 errs %s; cosines %s"
           % (el, {short(k): "%.2e" % e for k, e in l2.items()}, {short(k): "%.4f" % c for k, c in cos.items()}))
-    assert el <= 5e-2, el
-    assert max(l2.values()) <= 0.35, l2
-    assert min(cos.values()) >= 0.94, cos
+    assert el <= 1e-2, el
+    assert max(l2.values()) <= 0.10, l2
+    assert min(cos.values()) >= 0.995, cos

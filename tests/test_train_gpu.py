@@ -330,8 +330,8 @@ def test_flat_adamw_in_the_reference_training_loop_with_lambdalr_and_resume(dev)
     ref3 = _toy(dev, seed=98)
     ref3.load_state_dict(ckpt["model"])
     ropt3 = torch.optim.AdamW(ref3.parameters(), lr=1.0)
-    ropt3.load_state_dict({k: v for k, v in ckpt["opt"].items() if k != "flat_adamw"})
-    rsched3 = LambdaLR(ropt3, lr_lambda=lam)
+    rsched3 = LambdaLR(ropt3, lr_lambda=lam)          # objects first, then their states (what accelerator.load_state does): a scheduler
+    ropt3.load_state_dict({k: v for k, v in ckpt["opt"].items() if k != "flat_adamw"})   # built AFTER the load would reset the group's lr
     rsched3.load_state_dict(ckpt["sched"])
     one(ref3, ropt3, rsched3, xs[5], True)
     for p, rp in zip(net.parameters(), ref3.parameters()):

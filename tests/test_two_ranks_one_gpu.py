@@ -1,0 +1,128 @@
+"""Data-parallel E2E-FT step with TWO ranks on ONE MI355X (the driver had no 8-GPU box, so the N > 1 training path had only
+run on CPU tensors).  Both ranks use cuda:0; the collective is gloo over DEVICE tensors (RCCL refuses two ranks on one device), so what is exercised
+on real HIP streams is everything the exchange touches in the product: FlatAdamW's per-slice `register_post_accumulate_grad_hook` launching an async
+all-reduce on a slice of the flat gradient buffer while the libe2eft backward kernels of the remaining layers are still being enqueued, `step()`
+waiting for the slices, `e2eft_sumsq` + the guarded `e2eft_adamw_step` on the exchanged buffer, gradient accumulation with `sync_grads` only on the
+last micro-step.  Checked: (i) after the exchange every rank holds the SUM of the two ranks' gradients (compared with gradients computed in this
+process for both shards), (ii) the updated parameters are identical on both ranks and equal a single-process step over both shards as two
+accumulated micro-batches (training/train.py:470,559-566 semantics: mean over micro-batches = mean over ranks)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _models(dev):
+    from oracle import config
+    import golden_cases as gc
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    unet = UNet2DConditionModel(**config.TINY_UNET)
+    unet.load_state_dict(gc.tiny_unet_sd())
+    vae = AutoencoderKL(**config.TINY_VAE)
+    vae.load_state_dict(gc.tiny_vae_sd())
+    return unet.to(dev).train(), vae.to(dev).eval().requires_grad_(False)
+
+
+def _shards():
+    import golden_cases as gc
+    batch, text = gc.train_batch()
+    n = batch["rgb"].shape[0]
+    assert n >= 2
+    return [{k: v[i:i + 1] for k, v in batch.items()} for i in range(2)], text
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, HERE)
+        sys.path.insert(0, os.path.join(HERE, ".."))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        import torch.distributed as dist
+        from diffusion_e2e_ft_amd import training
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        probe = torch.ones(4, device=dev) * (rank + 1)
+        try:
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+        except Exception as e:      # a torch build whose gloo has no device-tensor support
+            q.put(("skip", rank, repr(e)))
+            dist.destroy_process_group()
+            return
+        assert probe.tolist() == [3.0] * 4
+        unet, vae = _models(dev)
+        shards, text = _shards()
+        opt = training.FlatAdamW(unet.parameters(), lr=1e-3, max_grad_norm=1.0, n_slices=3)
+        assert opt.world == 2 and len(opt._hooks) == len(opt.params)
+        # two accumulation micro-steps on this rank's shard (the same shard twice, halved): only the second one exchanges
+        opt.sync_grads = False
+        (training.e2e_ft_loss(unet, vae, shards[rank], text, "depth") * 0.5).backward()
+        assert all(sl["work"] is None for sl in opt.slices)
+        opt.sync_grads = True
+        (training.e2e_ft_loss(unet, vae, shards[rank], text, "depth") * 0.5).backward()
+        assert all(sl["work"] is not None for sl in opt.slices)          # every slice's all-reduce was launched from a hook, during the backward
+        opt._finish_exchange()
+        torch.cuda.synchronize()
+        summed = opt.flat_grad.detach().clone().cpu()
+        opt.step()
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        q.put(("ok", rank, summed, opt.flat_param.detach().clone().cpu(), opt.step_count, opt.skipped_steps()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))
+        raise
+
+
+def test_two_ranks_share_one_gpu_hooks_exchange_and_update(dev):
+    from diffusion_e2e_ft_amd import training
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+    if any(r[0] == "skip" for r in res):
+        pytest.skip("gloo has no device-tensor all_reduce in this torch build: %s" % [r[2] for r in res if r[0] == "skip"])
+    assert all(r[0] == "ok" for r in res), [r[2] for r in res if r[0] != "ok"]
+    res.sort(key=lambda r: r[1])
+    # ---- reference in this process: per-shard gradients, then ONE step over the two shards as accumulated micro-batches
+    sys.path.insert(0, HERE)
+    unet, vae = _models(dev)
+    shards, text = _shards()
+    ref_opt = training.FlatAdamW(unet.parameters(), lr=1e-3, max_grad_norm=1.0)
+    grads = []
+    for sh in shards:
+        training.e2e_ft_loss(unet, vae, sh, text, "depth").backward()
+        grads.append(ref_opt.flat_grad.detach().clone().cpu())
+        ref_opt.zero_grad()
+    want_sum = grads[0] + grads[1]
+    for r in res:
+        err = (r[2] - want_sum).abs().max().item() / want_sum.abs().max().item()
+        assert err < 1e-5, ("exchanged gradient != sum over ranks", r[1], err)
+        assert r[4] == 1 and r[5] == 0
+    assert torch.equal(res[0][3], res[1][3]), "ranks diverged"
+    training.train_step(unet, vae, ref_opt, shards, text, "depth")
+    torch.cuda.synchronize()
+    perr = (res[0][3] - ref_opt.flat_param.cpu()).abs().max().item()
+    assert perr < 2e-6, perr       # lr 1e-3: a wrong gradient scale (sum instead of mean) moves parameters by ~1e-3
