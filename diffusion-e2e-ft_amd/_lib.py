@@ -72,7 +72,8 @@ SIGNATURES = {
     "e2eft_softmax_rows_causal": (_I, [_I, _L, _I, _L, _F, _I, _P, _P]),
     "e2eft_attn_fwd": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
     "e2eft_attn_fwd_lse": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _P]),
-    "e2eft_attn512_fwd": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
+    "e2eft_attn512_workspace_bytes": (_Z, [C.POINTER(AttnDesc)]),
+    "e2eft_attn512_fwd": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _Z, _P]),
     "e2eft_attn_bwd_workspace_bytes": (_Z, [C.POINTER(AttnDesc)]),
     "e2eft_attn_bwd": (_I, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
     "e2eft_nchw_to_nhwc": (_I, [_I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),

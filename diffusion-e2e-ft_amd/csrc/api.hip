@@ -22,6 +22,20 @@ int check_launch(const char* what) {
     return E2EFT_OK;
 }
 
+// CU count of the CURRENT device, cached per device ordinal (one process may drive several GPUs); 0 on failure.  Rounded down to a multiple of 8 (XCDs).
+static std::atomic<int> g_cus_of_device[64];
+int device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int n = g_cus_of_device[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return 0;
+        n &= ~7;
+        g_cus_of_device[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 static thread_local char g_tag[96] = "";
 void tag_kernel(const char* fmt, ...) {
     va_list ap;

@@ -52,6 +52,11 @@ struct Attn5Params {
     int batch, nq, nk;
     int ldq, ldk, ldv, ldo;
     float c;  // scale * log2(e)
+    // key-split tail (see the launcher): workgroups [0, n_main) own one 128-query block each over all keys and write the result;
+    // workgroups n_main + S r + j own query block n_main + r over keys [j kchunk, (j + 1) kchunk) and write an unnormalised partial
+    int nqb, n_main, nsplit, kchunk;
+    float* part_o;    // [n_split blocks][128][512] fp32: O^T in the block's own reference frame
+    float* part_ml;   // [n_split blocks][128][2]: (reference maximum in the exponent domain, row sum)
 };
 
 template <typename T> struct Mma512;
@@ -138,8 +143,17 @@ __global__ __launch_bounds__(256) void attn512_fwd_kernel(const Attn5Params p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    int blk = blockIdx.x, part = -1, k_begin = 0, k_end = p.nk;
+    if (blk >= p.n_main) {
+        const int r = blk - p.n_main;
+        const int rq = r / p.nsplit;
+        part = r - rq * p.nsplit;
+        blk = p.n_main + rq;
+        k_begin = part * p.kchunk;
+        k_end = min(p.nk, k_begin + p.kchunk);
+    }
+    const int b = blk / p.nqb;
+    const int q0 = (blk - b * p.nqb) * 128 + wave * 32;
 
     // ---- Q^T fragments (B operand of S^T = K Q^T): lane (q = l31, hh) holds Q[q][16 ds + 8 hh .. + 7], ds = 0 .. 31 ----
     u32x4 qf[32];
@@ -163,13 +177,13 @@ __global__ __launch_bounds__(256) void attn512_fwd_kernel(const Attn5Params p) {
     const unsigned krow_b = (unsigned)(p.ldk * (int)sizeof(T)), vrow_b = (unsigned)(p.ldv * (int)sizeof(T));
     auto dma_k_row = [&](const int t, const int buf, const int i) {     // row wave + 4 i of K tile t
         const int r = wave + 4 * i;
-        const unsigned key = (unsigned)(t * KT + r);
+        const unsigned key = (unsigned)(k_begin + t * KT + r);
         const unsigned off = key < (unsigned)p.nk ? key * krow_b + lane16 : 0xFFFFFFF0u;
         dma_row512(rsk, off, lds0 + (unsigned)(buf * KTILE + r * KP));
     };
     auto dma_v_row = [&](const int t, const int buf, const int i) {
         const int r = wave + 4 * i;
-        const unsigned key = (unsigned)(t * KT + r);
+        const unsigned key = (unsigned)(k_begin + t * KT + r);
         const unsigned off = key < (unsigned)p.nk ? key * vrow_b + lane16 : 0xFFFFFFF0u;
         dma_row512(rsv, off, lds0 + (unsigned)(2 * KTILE + buf * VTILE + r * VP));
     };
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(256) void attn512_fwd_kernel(const Attn5Params p) {
     const int i16 = lane & 15, g4 = lane >> 4;
     const int vfrag = ((i16 >> 2) + 4 * hh) * VP + (16 * (g4 & 1) + 4 * (i16 & 3)) * 2;   // + (16 s2 [+ 8]) * VP + dt * 64
 
-    const int nt = (p.nk + KT - 1) / KT;
+    const int nt = (k_end - k_begin + KT - 1) / KT;     // kchunk is a multiple of KT: only the sequence's last tile can be ragged
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma_k_row(0, 0, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -259,10 +273,10 @@ __global__ __launch_bounds__(256) void attn512_fwd_kernel(const Attn5Params p) {
         // an MFMA's result registers must not be touched by a VALU for 18 wait states after issue
         asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sa), "+v"(sb));
         s = sa + sb;
-        if (t * KT + KT > p.nk) {   // last tile: keys beyond nk
+        if (k_begin + t * KT + KT > p.nk) {   // last tile: keys beyond nk
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int j = t * KT + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int j = k_begin + t * KT + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 if (j >= p.nk) s[r] = -INFINITY;
             }
         }
@@ -324,10 +338,22 @@ __global__ __launch_bounds__(256) void attn512_fwd_kernel(const Attn5Params p) {
     T* dst = (T*)p.out + ((long)b * p.nq + (qr < p.nq ? qr : 0)) * p.ldo;
     int fence = 0;
     asm volatile("s_nop 15\n\ts_nop 15\n\tv_mov_b32 %0, 0" : "=v"(fence) :: E2EFT_A256_CLOBBERS);   // the last MFMAs have retired before the first read-out
+    float* po = nullptr;
+    if (part >= 0) {   // key-split tail: unnormalised O^T (fp32), the frame it is in and the row sum go to the workspace; attn512_combine_kernel merges
+        const long slot = (long)(blockIdx.x - p.n_main) * 128 + wave * 32 + l31;
+        po = p.part_o + slot * D;
+        if (hh == 0) {
+            p.part_ml[slot * 2] = m_ref * p.c;
+            p.part_ml[slot * 2 + 1] = l_tot;
+        }
+    }
     auto store_block = [&](auto dc) {
         constexpr int dt = decltype(dc)::value;
         const floatx16 o = read_block<dt>(fence);
-        if (qr < p.nq) {
+        if (part >= 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<floatx4*>(po + dt * 32 + 8 * g + 4 * hh) = floatx4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+        } else if (qr < p.nq) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 w;
@@ -342,11 +368,81 @@ __global__ __launch_bounds__(256) void attn512_fwd_kernel(const Attn5Params p) {
     store_block(IC512<12>{}); store_block(IC512<13>{}); store_block(IC512<14>{}); store_block(IC512<15>{});
 }
 
+// merge of the key-split tail: out[q] = sum_j O_j 2^(m_j - M) / sum_j l_j 2^(m_j - M), M = max_j m_j.  One thread per (query, 8 d values).
+template <typename T>
+__global__ __launch_bounds__(256) void attn512_combine_kernel(const Attn5Params p) {
+    using namespace a5;
+    const long it = (long)blockIdx.x * 256 + threadIdx.x;
+    const int chunks = D / 8;
+    const long row = it / chunks;            // (tail query block, row inside it)
+    const int c8 = (int)(it - row * chunks) * 8;
+    const int rq = (int)(row >> 7), ri = (int)(row & 127);
+    const int nrem = (int)gridDim.x * 256 / chunks / 128;
+    if (rq >= nrem) return;
+    const int blk = p.n_main + rq;
+    const int b = blk / p.nqb;
+    const int qr = (blk - b * p.nqb) * 128 + ri;
+    if (qr >= p.nq) return;
+    float m[8], M = -INFINITY;
+    for (int j = 0; j < p.nsplit; ++j) {
+        m[j] = p.part_ml[(((long)rq * p.nsplit + j) * 128 + ri) * 2];
+        M = fmaxf(M, m[j]);
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, L = 0.f;
+    for (int j = 0; j < p.nsplit; ++j) {
+        const long slot = ((long)rq * p.nsplit + j) * 128 + ri;
+        const float w = __builtin_amdgcn_exp2f(m[j] - M);
+        L += p.part_ml[slot * 2 + 1] * w;
+        const floatx4 a0 = *reinterpret_cast<const floatx4*>(p.part_o + slot * D + c8);
+        const floatx4 a1 = *reinterpret_cast<const floatx4*>(p.part_o + slot * D + c8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += a0[e] * w; acc[4 + e] += a1[e] * w; }
+    }
+    const float inv = 1.f / L;
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.e[e] = from_f<T>(acc[e] * inv);
+    st16((T*)p.out + ((long)b * p.nq + qr) * p.ldo + c8, o);
+}
+
+// Tail balancing.  A workgroup owns 128 queries and a CU holds one workgroup, so B * ceil(nq / 128) blocks run in ceil(blocks / CUs) rounds:
+// 8 x 72 = 576 blocks on 256 CUs are 3 rounds for 2.25 rounds of work.  The blocks of the last, partial round (rem = blocks mod CUs) are cut S ways
+// along the KEYS (S = CUs / rem, at most 8, at least 512 keys per part): the last round then lasts 1 / S of a round.  The parts leave
+// unnormalised fp32 partials in the caller's workspace, a small kernel merges them.
+static void attn512_plan(const E2eftAttnDesc* d, int cus, int& nqb, int& n_main, int& nsplit, int& kchunk) {
+    nqb = cdiv(d->nq, 128);
+    const long blocks = (long)d->batch * nqb;
+    n_main = (int)blocks; nsplit = 1; kchunk = d->nk_seg;
+    if (cus <= 0) return;
+    const long rem = blocks % cus;
+    if (rem == 0) return;
+    long S = cus / rem;
+    if (S > 8) S = 8;
+    while (S > 1 && d->nk_seg / S < 512) --S;
+    if (S < 2) return;
+    kchunk = ((cdiv(d->nk_seg, (long)S) + a5::KT - 1) / a5::KT) * a5::KT;
+    nsplit = cdiv(d->nk_seg, kchunk);
+    if (nsplit < 2) { nsplit = 1; kchunk = d->nk_seg; return; }
+    n_main = (int)(blocks - rem);
+}
+
+int device_cus();   // api.hip
+
 }  // namespace e2eft
 
 using namespace e2eft;
 
-extern "C" int e2eft_attn512_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, void* stream) {
+extern "C" size_t e2eft_attn512_workspace_bytes(const E2eftAttnDesc* d) {
+    if (!d || d->batch <= 0 || d->nq <= 0 || d->nk_seg <= 0) return 0;
+    int nqb, n_main, nsplit, kchunk;
+    attn512_plan(d, device_cus(), nqb, n_main, nsplit, kchunk);
+    if (nsplit < 2) return 0;
+    const long tail = (long)d->batch * nqb - n_main;
+    return (size_t)tail * nsplit * 128 * (512 + 2) * sizeof(float);
+}
+
+extern "C" int e2eft_attn512_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, void* workspace, size_t ws_bytes,
+                                 void* stream) {
     E2EFT_REQUIRE(d && q && k && v && out, "attn512: null pointer");
     E2EFT_REQUIRE(d->dtype == E2EFT_F16 || d->dtype == E2EFT_BF16, "attn512: dtype %d unsupported (fp16 / bf16; fp32 uses the unfused path)", d->dtype);
     E2EFT_REQUIRE(d->batch > 0 && d->heads == 1 && d->nq > 0 && d->nk_seg > 0, "attn512: geometry (one head of width 512)");
@@ -354,16 +450,31 @@ extern "C" int e2eft_attn512_fwd(const E2eftAttnDesc* d, const void* q, const vo
     E2EFT_REQUIRE(d->ldq >= 512 && d->ldk >= 512 && d->ldv >= 512 && d->ldo >= 512, "attn512: row strides smaller than 512");
     E2EFT_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0, "attn512: row strides must be multiples of 8");
     E2EFT_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "attn512: alignment");
-    E2EFT_REQUIRE(d->batch <= 65535 && d->scale > 0.f, "attn512: grid / scale");
+    E2EFT_REQUIRE(d->scale > 0.f, "attn512: scale must be positive");
     E2EFT_REQUIRE((long)d->nk_seg * (d->ldk > d->ldv ? d->ldk : d->ldv) * 2 < 0xFFFF0000L, "attn512: one image's keys / values must span less than 4 GB");
     Attn5Params p;
     p.q = q; p.k = k; p.v = v; p.out = out;
     p.batch = d->batch; p.nq = d->nq; p.nk = d->nk_seg;
     p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo;
     p.c = d->scale * 1.4426950408889634f;
-    dim3 grid(cdiv(d->nq, 128), d->batch);
+    attn512_plan(d, device_cus(), p.nqb, p.n_main, p.nsplit, p.kchunk);
+    const long blocks = (long)d->batch * p.nqb;
+    const long tail = blocks - p.n_main;
+    const size_t need = (size_t)tail * p.nsplit * 128 * (512 + 2) * sizeof(float);
+    if (p.nsplit < 2 || !workspace || ws_bytes < need || ((uintptr_t)workspace & 15) != 0) {   // no (or too small a) workspace: every block runs all keys
+        p.n_main = (int)blocks; p.nsplit = 1; p.kchunk = d->nk_seg;
+    }
+    p.part_o = (float*)workspace;
+    p.part_ml = p.part_o ? p.part_o + (size_t)tail * p.nsplit * 128 * 512 : nullptr;
+    const long nwg = p.n_main + (blocks - p.n_main) * p.nsplit;
+    E2EFT_REQUIRE(nwg < 2147483647L, "attn512: grid");
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == E2EFT_F16) hipLaunchKernelGGL((attn512_fwd_kernel<f16>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn512_fwd_kernel<bf16>), grid, dim3(256), 0, s, p);
+    if (d->dtype == E2EFT_F16) hipLaunchKernelGGL((attn512_fwd_kernel<f16>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn512_fwd_kernel<bf16>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+    if (p.nsplit > 1) {
+        const unsigned cb = (unsigned)((blocks - p.n_main) * 128 * (512 / 8) / 256);
+        if (d->dtype == E2EFT_F16) hipLaunchKernelGGL((attn512_combine_kernel<f16>), dim3(cb), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((attn512_combine_kernel<bf16>), dim3(cb), dim3(256), 0, s, p);
+    }
     return check_launch("attn512_fwd");
 }

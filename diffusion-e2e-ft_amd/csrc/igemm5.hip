@@ -682,20 +682,9 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     }
 }
 
-static std::atomic<int> g_cus_of_device[64];     // CU count per device ordinal (0 = not queried yet): one process may drive several GPUs
 static std::atomic<long> g_pers_launches{0};      // debug counter (tests assert that the variant under test really ran)
 
-static int device_cus() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    int n = g_cus_of_device[dev].load(std::memory_order_relaxed);
-    if (n == 0) {
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return 0;
-        n &= ~7;
-        g_cus_of_device[dev].store(n, std::memory_order_relaxed);
-    }
-    return n;
-}
+int device_cus();   // api.hip: CU count of the current device
 
 template <typename T, int MODE> static int launch5(IgemmParams& p, int nz, int total, int grid, hipStream_t s) {
     if (p.residual) hipLaunchKernelGGL((igemm5_kernel<T, MODE, true>), dim3(grid), dim3(512), 0, s, p, total);

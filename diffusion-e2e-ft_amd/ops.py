@@ -482,6 +482,9 @@ def attention(q, k, v, heads, scale, kv_nseg=1, kv_bmod=None, out=None, return_l
     return (out, lse) if return_lse else out
 
 
+ATTN512_SPLIT_TAIL = True   # tests / A-B: without a workspace every query block runs all keys in one workgroup
+
+
 def attention512(q, k, v, scale, out=None):
     """Fused attention of ONE 512-wide head (the VAE mid-block attention), fp16 / bf16.  q / k / v: [B, N, 512] views (row-strided: slices
     of one fused q|k|v projection are fine)."""
@@ -496,8 +499,11 @@ def attention512(q, k, v, scale, out=None):
     d.batch, d.heads, d.nq, d.nk_seg, d.kv_nseg, d.kv_bmod = B, 1, Nq, Nk, 1, B
     d.ldq, d.ldk, d.ldv, d.ldo = _ld3(q), _ld3(k), _ld3(v), _ld3(out)
     d.scale = scale
+    lib = _lib.load()
+    nbytes = lib.e2eft_attn512_workspace_bytes(C.byref(d)) if ATTN512_SPLIT_TAIL else 0
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device) if nbytes else None
     with _timed("attn512", 4.0 * B * Nq * Nk * 512, label="attn512 B%d Nq%d Nk%d" % (B, Nq, Nk)):
-        check(_lib.load().e2eft_attn512_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _stream()))
+        check(lib.e2eft_attn512_fwd(C.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(ws), nbytes, _stream()))
     return out
 
 

@@ -204,8 +204,12 @@ int e2eft_attn_fwd_lse(const E2eftAttnDesc* d, const void* q, const void* k, con
 /* Fused attention forward for ONE head of width 512 (fp16 / bf16): the mid-block attention of AutoencoderKL
  * (GeoWizard/geowizard/models/unet_2d_blocks.py:589-601 — `Attention(heads = 1, dim_head = 512)` through AttnProcessor2_0:
  * F.scaled_dot_product_attention on [B, 1, H*W, 512]).  Descriptor as above with heads = 1, kv_nseg = 1, kv_bmod = batch;
- * q / k / v / out rows of 512 elements (row strides ld*, so slices of one fused q|k|v projection are fine). */
-int e2eft_attn512_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, void* stream);
+ * q / k / v / out rows of 512 elements (row strides ld*, so slices of one fused q|k|v projection are fine).
+ * workspace (optional, e2eft_attn512_workspace_bytes; 0 = not needed for this shape on this device): lets the launch cut the
+ * query blocks of its last, partially filled round of workgroups along the keys (fp32 partials + a merge kernel). */
+size_t e2eft_attn512_workspace_bytes(const E2eftAttnDesc* d);
+int e2eft_attn512_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, void* workspace, size_t ws_bytes,
+                      void* stream);
 /* Fused attention backward (head dim 64, fp16 / bf16, kv_nseg == 1; autograd of F.scaled_dot_product_attention /
  * xformers.memory_efficient_attention in diffusers Attention processors, attention.py:338-343,375-380): dq [B,Nq,heads*64],
  * dk / dv [B,Nk,heads*64] (row strides lddq / lddk / lddv), from q, k, v, the forward output `out` (desc ldo), its gradient

@@ -78,6 +78,32 @@ def test_attn512_rejects_what_it_cannot_do(dev):
     x = torch.zeros(32 * 512, dtype=torch.float16, device=dev)
     import ctypes as C
     p = C.c_void_p(x.data_ptr())
-    assert lib.e2eft_attn512_fwd(C.byref(d), p, p, p, p, None) == 1 and b"one head" in lib.e2eft_last_error()
+    assert lib.e2eft_attn512_fwd(C.byref(d), p, p, p, p, None, 0, None) == 1 and b"one head" in lib.e2eft_last_error()
     d.heads, d.dtype = 1, 0
-    assert lib.e2eft_attn512_fwd(C.byref(d), p, p, p, p, None) == 1 and b"dtype" in lib.e2eft_last_error()
+    assert lib.e2eft_attn512_fwd(C.byref(d), p, p, p, p, None, 0, None) == 1 and b"dtype" in lib.e2eft_last_error()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,N", [(1, 1536), (3, 2112), (2, 4000)])
+def test_attn512_key_split_tail_equals_the_unsplit_result(dev, dtype, B, N):
+    """fewer query blocks than CUs (or a partial last round): the tail blocks are cut along the keys and merged from fp32 partials.  Same numbers
+    as the unsplit launch to accumulation-order rounding, and right against SDPA; ragged key chunks and a ragged last query block included."""
+    from diffusion_e2e_ft_amd import ops, _lib
+    import ctypes as C
+    d = _lib.AttnDesc()
+    d.dtype, d.batch, d.heads, d.nq, d.nk_seg, d.kv_nseg, d.kv_bmod, d.ldq, d.ldk, d.ldv, d.ldo, d.scale = _lib.dtype_id(dtype), B, 1, N, N, 1, B, 512, 512, 512, 512, 0.05
+    assert _lib.load().e2eft_attn512_workspace_bytes(C.byref(d)) > 0, "this shape was meant to exercise the split"
+    g = torch.Generator().manual_seed(N)
+    q, k, v = (torch.randn(B, N, 512, generator=g).to(dtype) for _ in range(3))
+    k[0, N - 40] = 0.4 * q[0, 3]            # a dominant key in the LAST key chunk: the parts of a query end in different reference frames
+    ref = _ref(q, k, v, 512 ** -0.5)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    a = ops.attention512(qd, kd, vd, 512 ** -0.5)
+    ops.ATTN512_SPLIT_TAIL = False
+    try:
+        b = ops.attention512(qd, kd, vd, 512 ** -0.5)
+    finally:
+        ops.ATTN512_SPLIT_TAIL = True
+    torch.cuda.synchronize()
+    assert rel_err(a.float(), ref) <= TOL[dtype] and rel_err(b.float(), ref) <= TOL[dtype]
+    assert rel_err(a.float(), b.float()) <= (2e-3 if dtype == torch.float16 else 1.6e-2)
