@@ -1,21 +1,22 @@
 // attn.hip — fused attention forward for head dim 64 (fp16 / bf16), MFMA 32x32x16 + online softmax, gfx950.
 //
-// Work decomposition: one 256-thread workgroup = 128 or 256 query rows of one (image, head); each of its 4 waves owns
-// 32 or 64 query rows (template parameter QB, chosen per launch).  K/V are consumed in 64-key tiles staged in LDS (K row-major, V transposed to [d][key] while it
-// is written to LDS), double-buffered with the next tile's global loads in flight under the current tile's MFMAs.
+// Work decomposition: one 256-thread workgroup = 128 query rows of one (image, head); each of its 4 waves owns 32 query rows.  K / V are consumed in 64-key tiles
+// staged in LDS (both row-major; the V^T fragments come from the transpose read ds_read_b64_tr_b16), double-buffered with the next tile's global
+// loads in flight under the current tile's MFMAs.
 //
 // Both contractions are issued "swapped" so that the query row lives on the lane axis of every MFMA result:
 //   S^T[key, q] = K[key, :] . Q[q, :]      (A = K tile from LDS, B = Q^T fragments held in registers)
 //   O^T[d,  q] += V^T[d, key] P^T[key, q]  (A = V^T tile from LDS, B = P^T straight from the S^T registers)
 // so running max / sum / rescale are lane-local (one cross-half exchange per tile for the max), and the P
 // operand of the second MFMA is exactly the register set the first MFMA produced (no LDS round trip):
-// the key -> MFMA-k-slot permutation this implies is applied to the V^T fragment addresses instead.
+// the key -> MFMA-k-slot permutation this implies is applied to the V fragment addresses instead.
 #include "common.h"
+#include <type_traits>
 
 namespace e2eft {
 
 constexpr int KROW = 144;  // K tile LDS row stride (128 data bytes + 16)  -> conflict-free ds_read_b128
-constexpr int VROW = 136;  // V^T tile LDS row stride (128 + 8)            -> conflict-free ds_read_b64
+constexpr int VROW = 192;  // V tile (row-major [key][64 d]) LDS row stride: the four key rows of a transpose read land on four different 64-byte windows
 constexpr int KTILE = 64 * KROW;
 constexpr int VTILE = 64 * VROW;
 constexpr int KVBUF = KTILE + VTILE;
@@ -63,12 +64,17 @@ template <> struct Pk<bf16> {
 };
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return Pk<T>::pack(lo, hi); }
 
+typedef short short4va __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16: lane i of a 16-lane group supplies the address of 4 consecutive 16-bit elements (row i >> 2, columns 4 (i & 3) .. + 3 of a
+// 4 x 16 block) and receives column i of the block, rows 0 .. 3 — V stays row-major in LDS and is transposed on the way to the MFMA's A operand
+__device__ __forceinline__ u32x2 tr_read(const char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4va*)p));
+}
+
 // 1-D grid of nqb * heads * batch workgroups (nqb = ceil(nq / (128 QB))).  JOINT: keys come from kv_nseg = 2 batch-strided segments
 // (GeoWizard), which costs an integer division per loaded row; the plain case indexes keys linearly.
-// QB = query blocks of 32 rows per wave.  QB = 2 (64 rows per wave, 256 per workgroup) is the big-problem form: every K / V^T fragment read from
-// LDS, every K / V row fetched and every LDS store of the loader then serves TWO MFMAs instead of one — the d = 64 head is bound by VALU + LDS
-// issue slots, and 34 of the ~200 non-MFMA instructions of a 64-key tile are exactly those loads and stores.  QB = 1 keeps
-// small problems (cross attention over a handful of keys, CLIP's 257 tokens, the 12^2 levels) on twice as many workgroups.
+// QB = query blocks of 32 rows per wave (1).  (Round 3 measured QB = 2 — 64 rows per wave, every K / V^T fragment read and every loader store
+// serving two MFMAs: 742 against 726 TF/s at 9216 keys, +2 %: LDS / loader issue slots are not what binds; the per-score VALU work is — below.)
 // Block -> (image, head, query block): all query blocks of one (image, head) run on ONE XCD (block id mod 8 = XCD, MI355X_MICROARCH.md), so the
 // head's K / V (2.4 MB at 9216 keys) is fetched into one L2 instead of eight: PMC had 3.5x the algorithmic HBM bytes with the plain map.
 // Measured dead ends: s_setprio(1) around the MFMA phases (771 -> 697 TF/s), v_dot2c row sums on the packed probabilities (717).
@@ -112,62 +118,83 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         const T* src = Q + ((long)b * p.nq + (ok ? qr : 0)) * p.ldq + head * 64 + 8 * hh;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
-            qf[j][ds] = ok ? *reinterpret_cast<const u32x4*>(src + 16 * ds) : u32x4{0u, 0u, 0u, 0u};
+            Vec16<T> v;
+            v.raw = ok ? *reinterpret_cast<const u32x4*>(src + 16 * ds) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.e[e] = from_f<T>(to_f(v.e[e]) * p.c);     // Q' = Q * scale * log2(e): the MFMA delivers exponents
+            qf[j][ds] = v.raw;
         }
     }
 
-    // ---- loader mapping ----
-    // K: 64 keys x 8 chunks(16 B): thread -> keys (tid/8) and (tid/8 + 32), chunk tid%8
+    // ---- loader: K and V tiles are both 64 keys x 8 sixteen-byte chunks, row-major: thread -> keys (tid / 8) and (tid / 8 + 32), chunk tid % 8.
+    // Row pointers advance by a constant per tile; only a tile that reaches past the last key clamps its rows (scores masked below, p = 0).
     const int k_kc = tid & 7, k_r0 = tid >> 3;
-    // V: thread -> key pair kp (keys 2kp, 2kp+1), d-chunk vc (8 d values)
-    const int v_kp = l31, v_vc = 2 * wave + hh;
     const int kvb0 = b % p.kv_bmod;
-
     auto key_row = [&](int j) -> long {  // global row index (in rows of the [kv_batch*nk_seg] matrix) of key j
         if (!JOINT) return (long)kvb0 * p.nk_seg + j;
         const int seg = j / p.nk_seg;
         return (long)(kvb0 + seg * p.kv_bmod) * p.nk_seg + (j - seg * p.nk_seg);
     };
-
+    const T* kp[2];
+    const T* vp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        kp[i] = K + key_row(min(k_r0 + 32 * i, p.nk_total - 1)) * p.ldk + head * 64 + k_kc * 8;
+        vp[i] = V + key_row(min(k_r0 + 32 * i, p.nk_total - 1)) * p.ldv + head * 64 + k_kc * 8;
+    }
+    const long kstep = (long)64 * p.ldk, vstep = (long)64 * p.ldv;
     u32x4 rk[2], rv[2];
     auto load_tile = [&](int t) {
         const int base = t * 64;
+        if (JOINT || base + 64 > p.nk_total) {      // (joint keys change segment somewhere in the sequence: index every row)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = min(base + k_r0 + 32 * i, p.nk_total - 1);   // rows past the end: scores are masked below, p = 0
-            rk[i] = *reinterpret_cast<const u32x4*>(K + key_row(j) * p.ldk + head * 64 + k_kc * 8);
-        }
+            for (int i = 0; i < 2; ++i) {
+                const long r = key_row(min(base + k_r0 + 32 * i, p.nk_total - 1));
+                rk[i] = *reinterpret_cast<const u32x4*>(K + r * p.ldk + head * 64 + k_kc * 8);
+                rv[i] = *reinterpret_cast<const u32x4*>(V + r * p.ldv + head * 64 + k_kc * 8);
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = min(base + 2 * v_kp + i, p.nk_total - 1);
-            rv[i] = *reinterpret_cast<const u32x4*>(V + key_row(j) * p.ldv + head * 64 + v_vc * 8);
+            for (int i = 0; i < 2; ++i) {
+                rk[i] = *reinterpret_cast<const u32x4*>(kp[i] + t * kstep);
+                rv[i] = *reinterpret_cast<const u32x4*>(vp[i] + t * vstep);
+            }
         }
     };
     auto store_tile = [&](int buf) {
         char* sk = smem + buf * KVBUF;
         char* sv = sk + KTILE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(sk + (k_r0 + 32 * i) * KROW + k_kc * 16) = rk[i];
-        // transpose: V^T[8 vc + e][2 kp, 2 kp + 1]
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            // one v_perm_b32 per pair: {low halves} or {high halves} of the two keys' dwords
-            const uint32_t w = __builtin_amdgcn_perm(rv[1][e >> 1], rv[0][e >> 1], (e & 1) ? 0x07060302u : 0x05040100u);
-            *reinterpret_cast<uint32_t*>(sv + (8 * v_vc + e) * VROW + v_kp * 4) = w;
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<u32x4*>(sk + (k_r0 + 32 * i) * KROW + k_kc * 16) = rk[i];
+            *reinterpret_cast<u32x4*>(sv + (k_r0 + 32 * i) * VROW + k_kc * 16) = rv[i];
         }
     };
+    // transpose-read address of this lane inside a V tile: 16-lane group g serves d columns 16 (g & 1) .. + 15 for the k-slot half hh = g >> 1;
+    // lane i of the group supplies key (i >> 2) of a 4-key run and d offset 4 (i & 3)
+    const int i16 = lane & 15;
+    const int vfrag = ((i16 >> 2) + 4 * hh) * VROW + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;   // + first key of the run * VROW + dt * 64
 
-    floatx16 o[QB][2];
-    float m_run[QB], l_run[QB];
+    // ---- softmax state.  The kernel is bound by VALU issue (~135 VALU instructions against 16 MFMAs per 64-key tile), so two of
+    // the four per-score VALU operations are moved onto the half-idle matrix pipe:
+    //  * the scores come out of the MFMA already in the exponent domain AND relative to the reference maximum: Q is pre-multiplied by
+    //    scale * log2(e) (once per workgroup) and the accumulator chain of S^T starts from a block holding -m_ref instead of 0, so a probability is
+    //    ONE v_exp_f32 of the accumulator (no fma / subtract per score);
+    //  * the row sums come from a fifth accumulator block: l^T += ones(32 x 16) P^T, 4 extra MFMAs per tile instead of 32 v_add_f32 (and the sum is
+    //    taken over the ROUNDED probabilities, the ones that multiply V).
+    // The reference maximum only moves when a tile exceeds it by more than 2^THR (deferred rescale, as attn512.hip): then — a uniform, rare branch
+    // — the tile's scores are shifted, O^T and l^T rescaled and the -m_ref block rewritten.
+    constexpr float THR = 6.0f;
+    static_assert(QB == 1, "the VALU-light scheme keeps 2 x 16 extra accumulator registers per query block: one query block per wave");
+    const u32x4 ones = std::is_same<T, f16>::value ? u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u} : u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    floatx16 o[2], lacc, cinit;
 #pragma unroll
-    for (int j = 0; j < QB; ++j) {
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[j][dt][r] = 0.f;
-        m_run[j] = -INFINITY;
-        l_run[j] = 0.f;
-    }
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; lacc[r] = 0.f; cinit[r] = 0.f; }
+    float m_ref = 0.f;      // exponent domain; the first tile always re-references (first = true)
+    bool first = true;
+    asm volatile("" : "+v"(cinit));     // a register BLOCK of 16 equal values that stays put (not a splat re-materialised in front of every chain)
+    u32x4 ones_v = ones;
+    asm volatile("" : "+v"(ones_v));    // likewise the constant A operand of the row-sum MFMAs (else two v_mov_b64 from SGPRs in front of each)
 
     const int nt = (p.nk_total + 63) / 64;
     load_tile(0);
@@ -182,97 +209,73 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         const char* sk = smem + buf * KVBUF;
         const char* sv = sk + KTILE;
 
-        // ---- S^T = K Q^T : two 32-key sub-tiles x QB query blocks; one K fragment read feeds QB MFMAs ----
-        floatx16 s[QB][2];
+        // ---- S'^T = K Q'^T - m_ref : two 32-key sub-tiles ----
+        floatx16 s[2];
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2) {
             const char* row = sk + (kt2 * 32 + l31) * KROW + hh * 16;
+            s[kt2] = MmaA<T>::run(*reinterpret_cast<const u32x4*>(row), qf[0][0], cinit);
 #pragma unroll
-            for (int ds = 0; ds < 4; ++ds) {
-                const u32x4 kf = *reinterpret_cast<const u32x4*>(row + ds * 32);
-#pragma unroll
-                for (int j = 0; j < QB; ++j) {
-                    if (ds == 0) {
-                        const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        s[j][kt2] = MmaA<T>::run(kf, qf[j][0], z);
-                    } else {
-                        s[j][kt2] = MmaA<T>::run(kf, qf[j][ds], s[j][kt2]);
-                    }
-                }
-            }
+            for (int ds = 1; ds < 4; ++ds) s[kt2] = MmaA<T>::run(*reinterpret_cast<const u32x4*>(row + ds * 32), qf[0][ds], s[kt2]);
         }
         // ---- mask keys beyond nk_total (last tile only) ----
         if (t * 64 + 64 > p.nk_total) {
 #pragma unroll
-            for (int j = 0; j < QB; ++j)
+            for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-                for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = t * 64 + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        if (key >= p.nk_total) s[j][kt2][r] = -INFINITY;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= p.nk_total) s[kt2][r] = -INFINITY;
+                }
         }
-        // ---- online softmax (raw-score running max; exp2 with the scale folded into one fma) ----
-        uint32_t pw[QB][2][8];
-        bool resc = false;
-        float alpha[QB];
+        // ---- tile maximum relative to the reference (v_max3_f32: 16 instructions for 32 values) ----
+        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
 #pragma unroll
-        for (int j = 0; j < QB; ++j) {
-            // 32 values -> 1: v_max3_f32 halves the chain (the compiler fuses the nested fmaxf)
-            float mx = fmaxf(fmaxf(s[j][0][0], s[j][0][1]), s[j][0][2]);
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
+        mx = fmaxf(fmaxf(mx, s[0][15]), s[1][0]);
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[j][0][r]), s[j][0][r + 1]);
-            mx = fmaxf(fmaxf(mx, s[j][0][15]), s[j][1][0]);
-#pragma unroll
-            for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[j][1][r]), s[j][1][r + 1]);
-            mx = fmaxf(mx, s[j][1][15]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[j], mx);
-            alpha[j] = __builtin_amdgcn_exp2f((m_run[j] - m_new) * p.c);
-            const float mc = m_new * p.c;
-            m_run[j] = m_new;
-            // probabilities, packed straight into the B operand of the second MFMA
-            float psum = 0.f;
+        for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
+        mx = fmaxf(mx, s[1][15]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (first || __builtin_amdgcn_ballot_w64(mx > THR) != 0) {   // uniform; after the first tiles: rare
+            // per query: move the reference by delta >= 0 (first tile: to the tile maximum, whatever its sign), bring this tile's scores, O^T and
+            // l^T into the new frame, rewrite the -m_ref block
+            const float delta = first ? mx : (mx > THR ? mx : 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            m_ref += delta;
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-                for (int w = 0; w < 8; ++w) {
-                    const float e0 = __builtin_amdgcn_exp2f(fmaf(s[j][kt2][2 * w], p.c, -mc));
-                    const float e1 = __builtin_amdgcn_exp2f(fmaf(s[j][kt2][2 * w + 1], p.c, -mc));
-                    pw[j][kt2][w] = Pk<T>::pack(e0, e1);
-                    psum += e0 + e1;   // (v_dot2c on the packed word is one instruction per pair but measured slower beside the MFMAs: 717 vs 771 TF/s)
-                }
-            l_run[j] = l_run[j] * alpha[j] + psum;
-            resc = resc || (alpha[j] != 1.0f);
+                for (int r = 0; r < 16; ++r) s[kt2][r] -= delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; lacc[r] *= alpha; cinit[r] = -m_ref; }
+            asm volatile("" : "+v"(cinit));
+            first = false;
         }
-        if (__builtin_amdgcn_ballot_w64(resc) != 0) {   // the running max settles after a few tiles: skip the rescale then
+        // ---- probabilities: one v_exp_f32 per score, packed straight into the B operand of the second MFMA ----
+        uint32_t pw[2][8];
 #pragma unroll
-            for (int j = 0; j < QB; ++j)
+        for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[j][dt][r] *= alpha[j];
-        }
+            for (int w = 0; w < 8; ++w)
+                pw[kt2][w] = Pk<T>::pack(__builtin_amdgcn_exp2f(s[kt2][2 * w]), __builtin_amdgcn_exp2f(s[kt2][2 * w + 1]));
 
-        // ---- O^T += V^T P^T : one V^T fragment read feeds QB MFMAs ----
+        // ---- O^T += V^T P^T and l^T += 1 P^T ----
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int kb = (kt2 * 32 + 16 * s2 + 4 * hh) * 2;  // byte offset of the first 4-key run
+                const u32x4 pf = {pw[kt2][4 * s2], pw[kt2][4 * s2 + 1], pw[kt2][4 * s2 + 2], pw[kt2][4 * s2 + 3]};
+                // k-slots 0-3 of half hh: keys kt2 * 32 + 16 s2 + 4 hh + 0..3, k-slots 4-7: the same + 8 (the S^T register order)
+                const char* vb = sv + vfrag + (kt2 * 32 + 16 * s2) * VROW;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const char* vrow = sv + (dt * 32 + l31) * VROW + kb;
-                    const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
-                    const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
+                    const u32x2 v0 = tr_read(vb + dt * 64);
+                    const u32x2 v1 = tr_read(vb + 8 * VROW + dt * 64);
                     const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
-#pragma unroll
-                    for (int j = 0; j < QB; ++j) {
-                        const u32x4 pf = {pw[j][kt2][4 * s2], pw[j][kt2][4 * s2 + 1], pw[j][kt2][4 * s2 + 2], pw[j][kt2][4 * s2 + 3]};
-                        o[j][dt] = MmaA<T>::run(vf, pf, o[j][dt]);
-                    }
+                    o[dt] = MmaA<T>::run(vf, pf, o[dt]);
                 }
+                lacc = MmaA<T>::run(ones_v, pf, lacc);
             }
         }
 
@@ -280,13 +283,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: O / l, 8-byte stores of 4 consecutive d ----
-#pragma unroll
-    for (int j = 0; j < QB; ++j) {
-        const float l_tot = l_run[j] + __shfl_xor(l_run[j], 32, 64);
+    // ---- epilogue: O / l, 8-byte stores of 4 consecutive d (every accumulator register of lacc holds the query's full row sum) ----
+    {
+        const float l_tot = lacc[0];
         const float inv = 1.f / l_tot;
-        const int qr = q0 + 32 * j + l31;
-        if (p.lse && hh == 0 && qr < p.nq) p.lse[((long)b * p.heads + head) * p.nq + qr] = m_run[j] * p.c + __builtin_amdgcn_logf(l_tot);
+        const int qr = q0 + l31;
+        if (p.lse && hh == 0 && qr < p.nq) p.lse[((long)b * p.heads + head) * p.nq + qr] = m_ref + __builtin_amdgcn_logf(l_tot);
         if (qr < p.nq) {
             T* dst = (T*)p.out + ((long)b * p.nq + qr) * p.ldo + head * 64;
 #pragma unroll
@@ -294,8 +296,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     u32x2 w;
-                    w[0] = pack2<T>(o[j][dt][4 * g] * inv, o[j][dt][4 * g + 1] * inv);
-                    w[1] = pack2<T>(o[j][dt][4 * g + 2] * inv, o[j][dt][4 * g + 3] * inv);
+                    w[0] = pack2<T>(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
+                    w[1] = pack2<T>(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
                     *reinterpret_cast<u32x2*>(dst + dt * 32 + 8 * g + 4 * hh) = w;
                 }
         }
@@ -330,17 +332,11 @@ extern "C" int e2eft_attn_fwd_lse(const E2eftAttnDesc* d, const void* q, const v
     p.lse = lse;
     hipStream_t s = (hipStream_t)stream;
     const bool joint = d->kv_nseg > 1;
-    // 64 query rows per wave when that still leaves two 256-row workgroups per CU's worth of work and the key loop is long enough to matter
     const long pairs = (long)d->heads * d->batch;
-    const bool wide = option(E2EFT_OPT_ATTN_WIDE) && pairs * cdiv(d->nq, 256) >= 512 && p.nk_total >= 256;
-    p.nqb = cdiv(d->nq, wide ? 256 : 128);
+    p.nqb = cdiv(d->nq, 128);
     E2EFT_REQUIRE(pairs * p.nqb < 2147483647L, "attn: grid");
     dim3 grid((unsigned)(pairs * p.nqb));
-#define E2EFT_ATTN_LAUNCH(TT, JJ)                                                                   \
-    do {                                                                                            \
-        if (wide) hipLaunchKernelGGL((attn_fwd_kernel<TT, JJ, 2>), grid, dim3(256), 0, s, p);       \
-        else hipLaunchKernelGGL((attn_fwd_kernel<TT, JJ, 1>), grid, dim3(256), 0, s, p);            \
-    } while (0)
+#define E2EFT_ATTN_LAUNCH(TT, JJ) hipLaunchKernelGGL((attn_fwd_kernel<TT, JJ, 1>), grid, dim3(256), 0, s, p)
     if (d->dtype == E2EFT_F16) {
         if (joint) E2EFT_ATTN_LAUNCH(f16, true); else E2EFT_ATTN_LAUNCH(f16, false);
     } else {

@@ -57,8 +57,7 @@ enum {
     E2EFT_OPT_NARROW_MFMA = 3,       /* 1 (default): MFMA 16x16x32 form of that kernel; 0: v_dot2 form */
     E2EFT_OPT_IGEMM_GENERAL_OPERANDS = 4, /* 0 (default); 1: igemm2 takes its general (per-lane gather) operand path for every launch */
     E2EFT_OPT_IGEMM2_WAVES = 5,      /* 0 (default): 8-wave 256-row tiles when >= 256 of them exist, else 4-wave 128-row; 4 / 8: forced */
-    E2EFT_OPT_ATTN_WIDE = 6,         /* 1 (default): d = 64 attention takes 64 query rows per wave on big launches; 0: always 32 */
-    E2EFT_OPT_COUNT = 7
+    E2EFT_OPT_COUNT = 6
 };
 int e2eft_set_option(int32_t key, int32_t value);
 int e2eft_get_option(int32_t key);

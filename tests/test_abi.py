@@ -32,8 +32,8 @@ def test_options_are_the_only_global_state_and_the_library_never_reads_the_envir
     """eight getenv switches inside an ABI whose contract says "no global mutable state" -> e2eft_set_option / e2eft_get_option"""
     from diffusion_e2e_ft_amd import _lib
     lib = _lib.load()
-    defaults = [lib.e2eft_get_option(k) for k in range(7)]
-    assert defaults == [1, 0, 1, 1, 0, 0, 1]
+    defaults = [lib.e2eft_get_option(k) for k in range(6)]
+    assert defaults == [1, 0, 1, 1, 0, 0]
     assert lib.e2eft_set_option(_lib.OPT_PERSISTENT_GRID, 8) == 0 and lib.e2eft_get_option(_lib.OPT_PERSISTENT_GRID) == 8
     assert lib.e2eft_set_option(_lib.OPT_PERSISTENT_GRID, 12) == 1 and b"out of range" in lib.e2eft_last_error()     # not a multiple of 8
     assert lib.e2eft_set_option(99, 0) == 1 and lib.e2eft_get_option(99) == -1

@@ -122,7 +122,14 @@ def test_two_ranks_share_one_gpu_hooks_exchange_and_update(dev):
         assert err < 1e-5, ("exchanged gradient != sum over ranks", r[1], err)
         assert r[4] == 1 and r[5] == 0
     assert torch.equal(res[0][3], res[1][3]), "ranks diverged"
-    training.train_step(unet, vae, ref_opt, shards, text, "depth")
-    torch.cuda.synchronize()
-    perr = (res[0][3] - ref_opt.flat_param.cpu()).abs().max().item()
-    assert perr < 2e-6, perr       # lr 1e-3: a wrong gradient scale (sum instead of mean) moves parameters by ~1e-3
+    # the update: clip_grad_norm_(1.0) + torch.optim.AdamW on the MEAN of the ranks' gradients (train.py:561-566 under DDP).  Fed with the very buffer
+    # the ranks exchanged (an Adam step is ~ lr * sign(g) where |g| >> eps and ill-conditioned in g where |g| ~ eps, so a reference built from
+    # separately rounded gradients would differ there by O(lr) without anything being wrong)
+    before = ref_opt.flat_param.detach().clone().cpu()
+    rp = torch.nn.Parameter(before.clone())
+    rp.grad = res[0][2] / 2
+    torch.nn.utils.clip_grad_norm_([rp], 1.0)
+    torch.optim.AdamW([rp], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2).step()
+    perr = (res[0][3] - rp.detach()).abs().max().item()
+    moved = (res[0][3] - before).abs().max().item()
+    assert moved > 5e-4 and perr < 1e-6, (moved, perr)       # lr 1e-3: a wrong gradient scale (sum instead of mean) would change the clip factor
