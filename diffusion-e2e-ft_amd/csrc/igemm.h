@@ -40,6 +40,9 @@ struct IgemmParams {
     float* gn_partial;   // optional: [img][gn_nslabs][N][3] (n, mean, M2) GroupNorm partials of the rounded output
     int gn_nslabs;       // row slabs (one per M-tile) per image
     int ksplit_taps;     // conv split-K: batch index zi covers filter taps [zi * ksplit_taps, (zi + 1) * ksplit_taps) (0 = whole K)
+    int debug_flags;     // instrumented build (-DE2EFT_STAMPS) only: bit 0 / 1 / 2 = the persistent kernel issues its A-operand LDS-DMA never / on the
+                         // first tap of a filter row only / on the first tap of a 64-channel chunk only (WRONG results; the price of operand
+                         // delivery, scripts/experiments/README: "what an A-reuse scheme could buy at most")
 };
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -240,7 +240,13 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
             off2[i] = ok ? (pix * (unsigned)p.ldx2 + (unsigned)(jc * EPC)) * (unsigned)sizeof(T) : OOB;
         }
     };
+#ifdef E2EFT_STAMPS
+    bool fire_a = true;
+#endif
     auto advance = [&]() {   // offsets / descriptor of the next k-tile to issue (k-tiles of a tile are issued in order)
+#ifdef E2EFT_STAMPS
+        fire_a = !(p.debug_flags & 1) && !((p.debug_flags & 2) && kx != 0) && !((p.debug_flags & 4) && (kx != 0 || ky != 0));
+#endif
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur_a[i] += 128u;
@@ -273,6 +279,9 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     auto fire = [&](const int stage, auto piece_c) {
         constexpr int Q = decltype(piece_c)::value;
         char* sa = smem + stage + wave * 1024;
+#ifdef E2EFT_STAMPS
+        if (Q < 4 && !fire_a) return;
+#endif
         if constexpr (Q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lptr5_t)(sa + Q * (RSTEP * 128)), 16, cur_a[Q], 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr5_t)(sa + A_STAGE + (Q - 4) * (RSTEP * 128)), 16, cur_b[Q - 4], 0, 0, 0);
     };
@@ -685,6 +694,9 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
 static std::atomic<long> g_pers_launches{0};      // debug counter (tests assert that the variant under test really ran)
 
 int device_cus();   // api.hip: CU count of the current device
+#ifdef E2EFT_STAMPS
+extern int g_debug_flags5;
+#endif
 
 template <typename T, int MODE> static int launch5(IgemmParams& p, int nz, int total, int grid, hipStream_t s) {
     if (p.residual) hipLaunchKernelGGL((igemm5_kernel<T, MODE, true>), dim3(grid), dim3(512), 0, s, p, total);
@@ -725,6 +737,9 @@ int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStre
         p.gn_nslabs = p.rows_per_img / BM;
     }
     g_pers_launches.fetch_add(1, std::memory_order_relaxed);
+#ifdef E2EFT_STAMPS
+    p.debug_flags = g_debug_flags5;
+#endif
     if (dtype == E2EFT_F16) return mode ? launch5<f16, 1>(p, nz, (int)total, g_pers_cus, s) : launch5<f16, 0>(p, nz, (int)total, g_pers_cus, s);
     return mode ? launch5<bf16, 1>(p, nz, (int)total, g_pers_cus, s) : launch5<bf16, 0>(p, nz, (int)total, g_pers_cus, s);
 }
@@ -732,6 +747,8 @@ int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStre
 }  // namespace e2eft
 
 #ifdef E2EFT_STAMPS
+namespace e2eft { int g_debug_flags5 = 0; }
+extern "C" void e2eft_debug_set_flags5(int f) { e2eft::g_debug_flags5 = f; }
 extern "C" int e2eft_debug_read_stamps5(long long* host, int nworkgroups) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(e2eft::g_stamps5), (size_t)nworkgroups * 32 * 8 * sizeof(long long));
 }
