@@ -234,7 +234,7 @@ class FlatAdamW(torch.optim.Optimizer):
         for lo, hi in zip(cuts[:-1], cuts[1:]):
             start = self.offsets[lo]
             end = self.offsets[hi] if hi < len(self.params) else n
-            self.slices.append(dict(lo=lo, hi=hi, start=start, end=end, ready=0, work=None))
+            self.slices.append(dict(lo=lo, hi=hi, start=start, end=end, ready=0, work=None, done=False))
         self._slice_of = {}
         for si, sl in enumerate(self.slices):
             for i in range(sl["lo"], sl["hi"]):
@@ -310,14 +310,21 @@ class FlatAdamW(torch.optim.Optimizer):
             sl["work"] = dist.all_reduce(self.flat_grad[sl["start"]:sl["end"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _finish_exchange(self):
+        """wait for the slices the hooks launched, exchange the ones no hook completed (parameters without a gradient this step).  Idempotent
+        within an optimizer step: a slice is summed over the ranks exactly once until `step()` / `zero_grad()` re-arm it."""
         if self.world == 1:
             return
         for sl in self.slices:
-            if sl["work"] is None:     # parameters that received no gradient this step: exchange the slice now
+            if sl["work"] is None and not sl["done"]:
                 sl["work"] = dist.all_reduce(self.flat_grad[sl["start"]:sl["end"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         for sl in self.slices:
-            sl["work"].wait()
-            sl["work"], sl["ready"] = None, 0
+            if sl["work"] is not None:
+                sl["work"].wait()
+            sl["work"], sl["ready"], sl["done"] = None, 0, True
+
+    def _rearm_exchange(self):
+        for sl in self.slices:
+            sl["done"] = False
 
     def _adopt_grads(self):
         """A caller may have re-bound .grad (zero_grad(set_to_none=True) of a generic training loop, then autograd created fresh tensors;
@@ -349,6 +356,7 @@ class FlatAdamW(torch.optim.Optimizer):
             ops.adamw_step_guarded_(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, float(g["lr"]) * lr_scale, g["betas"][0], g["betas"][1],
                                     g["eps"], g["weight_decay"], self._steps, self._coef, sumsq, grad_scale=grad_scale / self.world,
                                     max_norm=float(self.max_grad_norm or 0.0))
+        self._rearm_exchange()
         F.bump_param_epoch()
         return loss
 
@@ -363,6 +371,7 @@ class FlatAdamW(torch.optim.Optimizer):
         """Gradients are zeroed in ONE memset of the flat buffer and stay bound to it (also with set_to_none=True: a fresh `.grad` tensor
         per parameter would take the gradient out of the exchange buffer; `step()` would copy it back, at a price)."""
         self.flat_grad.zero_()
+        self._rearm_exchange()
         for p, o in zip(self.params, self.offsets):      # autograd may have re-bound .grad (e.g. set_to_none by a caller)
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)

@@ -57,6 +57,7 @@ def _worker(rank, world, port, q):
     (net(xs[rank]).sum() * 0.5).backward()
     assert all(sl["work"] is not None for sl in opt.slices)
     opt._finish_exchange()
+    opt._finish_exchange()                      # idempotent within a step: a second call must not sum the ranks again
     for p, a, b in zip(net.parameters(), refs[0], refs[1]):
         assert p.grad.data_ptr() >= opt.flat_grad.data_ptr()
         assert torch.allclose(p.grad / world, (a + b) / 2, atol=1e-6)
