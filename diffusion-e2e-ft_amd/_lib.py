@@ -115,6 +115,9 @@ SIGNATURES = {
     "e2eft_masked_quantiles_workspace_bytes": (_Z, [_I]),
     "e2eft_masked_quantiles": (_I, [_I, _L, _P, _F, _F, _F, _F, _P, _P, _Z, _P]),
     "e2eft_prepare_sample": (_I, [_I, _L, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "e2eft_resample_bilinear_aa": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
+    "e2eft_minmax_unit_workspace_bytes": (_Z, []),
+    "e2eft_minmax_unit": (_I, [_L, _P, _P, _P, _P, _Z, _P]),
     "e2eft_aug_resample_bilinear_u8": (_I, [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "e2eft_aug_gather_f32": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "e2eft_aug_gather_u8": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),

@@ -971,6 +971,35 @@ def cast_(x, y, mul=1.0, accumulate=False):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# pre- / post-processing of the pipelines' __call__ (csrc/prepost.hip)
+def resample_bilinear_aa(x, size, xtab, ytab, round_u8=False, mul=1.0, add=0.0):
+    """torch's antialiased bilinear resize of planar images: x [P, h0, w0] uint8 or fp32 (device, contiguous) -> fp32 [P, h, w];
+    xtab / ytab = (bounds int32 [out, 2], weights fp32 [out, ksize]) device tables (pipeline.aa_bilinear_tables); round_u8: round to the
+    uint8 grid first; then v * mul + add."""
+    _check_cuda(x, xtab[0], xtab[1], ytab[0], ytab[1])
+    assert x.dim() == 3 and x.is_contiguous() and x.dtype in (torch.uint8, torch.float32)
+    P, h0, w0 = x.shape
+    h, w = size
+    mid = torch.empty((P, h0, w), dtype=torch.float32, device=x.device)
+    out = torch.empty((P, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().e2eft_resample_bilinear_aa(P, h0, w0, h, w, 1 if x.dtype == torch.uint8 else 0, _ptr(x), _ptr(xtab[0]), _ptr(xtab[1]), xtab[1].shape[1],
+                                                 _ptr(ytab[0]), _ptr(ytab[1]), ytab[1].shape[1], 1 if round_u8 else 0, mul, add, _ptr(mid), _ptr(out), _stream()))
+    return out
+
+
+def minmax_unit(x):
+    """(x - min) / (max - min) over the whole fp32 tensor (zeros when max == min)"""
+    _check_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    lib = _lib.load()
+    nbytes = lib.e2eft_minmax_unit_workspace_bytes()
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    out = torch.empty_like(x)
+    check(lib.e2eft_minmax_unit(x.numel(), _ptr(x), _ptr(out), _ptr(None), _ptr(ws), nbytes, _stream()))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
 # test-time ensembling (csrc/ensemble.hip): x is the fp32 [N, ...] stack of the N predictions of one image
 def _ens_stack(x):
     _check_cuda(x)

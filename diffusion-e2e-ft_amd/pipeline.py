@@ -278,6 +278,9 @@ class MarigoldPipeline:
             rgb = torch.from_numpy(np.asarray(input_image.convert("RGB"))).permute(2, 0, 1)
         input_size = rgb.shape
         assert rgb.dim() == 3 and input_size[0] == 3, "Wrong input shape %s, expected [rgb, H, W]" % (tuple(input_size),)
+        on_dev = resample_method == "bilinear" and self.device.type == "cuda"      # pre / post-processing on the device (csrc/prepost.hip)
+        if on_dev:
+            rgb = rgb.to(self.device)
         if processing_res > 0:
             rgb = resize_max_res(rgb, processing_res, resample_method)
         rgb_norm = (rgb / 255.0 * 2.0 - 1.0).to(self.dtype)
@@ -295,10 +298,15 @@ class MarigoldPipeline:
             pred, pred_uncert = preds, None
         if normals:
             pred = pred / (torch.norm(pred, p=2, dim=0, keepdim=True) + 1e-5)
+        elif on_dev and pred.is_cuda:
+            pred = ops.minmax_unit(pred.contiguous())
         else:
             mn, mx = torch.min(pred), torch.max(pred)
             pred = torch.zeros_like(pred) if mx == mn else (pred - mn) / (mx - mn)
-        if match_input_res and tuple(pred.shape[-2:]) != tuple(input_size[-2:]):
+        if match_input_res and tuple(pred.shape[-2:]) != tuple(input_size[-2:]) and on_dev and pred.is_cuda:
+            pred = resize_device(pred if normals else pred[None], tuple(input_size[-2:]))
+            pred = pred if normals else pred[0]
+        elif match_input_res and tuple(pred.shape[-2:]) != tuple(input_size[-2:]):
             p4 = pred[None] if normals else pred[None, None]
             p4 = torch.nn.functional.interpolate(p4, size=tuple(input_size[-2:]), mode=resample_method,
                                                  antialias=resample_method != "nearest",
@@ -364,12 +372,51 @@ def _scaled(x, mul):
     return out.permute(0, 3, 1, 2)
 
 
+def aa_bilinear_tables(in_size, out_size, device):
+    """aten `_compute_indices_min_size_weights_aa` (UpSampleKernel.cpp) for the bilinear (triangle) filter, align_corners = False, in aten's
+    float32 arithmetic: (bounds int32 [out, 2] = (first tap, tap count), weights fp32 [out, ksize]) — what `F.interpolate(mode="bilinear",
+    antialias=True)` applies along one dimension.  Built on the host (a few hundred numbers), consumed by e2eft_resample_bilinear_aa."""
+    f32 = np.float32
+    scale = f32(in_size) / f32(out_size)
+    support = f32(scale) if scale >= 1.0 else f32(1.0)
+    invscale = f32(1.0) / scale if scale >= 1.0 else f32(1.0)
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    weights = np.zeros((out_size, ksize), dtype=np.float32)
+    for i in range(out_size):
+        center = scale * f32(i + 0.5)
+        xmin = max(int(center - support + f32(0.5)), 0)
+        xsize = min(int(center + support + f32(0.5)), in_size) - xmin
+        j = np.arange(xsize, dtype=np.float32)
+        wv = np.maximum(f32(0.0), f32(1.0) - np.abs((j + f32(xmin) - center + f32(0.5)) * invscale)).astype(np.float32)
+        tot = f32(0.0)
+        for v in wv:                       # aten sums sequentially in float32
+            tot = f32(tot + v)
+        if tot != 0:
+            wv = (wv / tot).astype(np.float32)
+        bounds[i] = (xmin, xsize)
+        weights[i, :xsize] = wv
+    return torch.from_numpy(bounds).to(device), torch.from_numpy(weights).to(device)
+
+
+def resize_device(img, size, round_u8=False, mul=1.0, add=0.0):
+    """antialiased bilinear resize of a planar [P,H,W] device tensor (uint8 or fp32) by libe2eft (csrc/prepost.hip) -> fp32 [P,h,w]"""
+    H, W = img.shape[-2:]
+    h, w = size
+    x = img.contiguous() if img.dtype == torch.uint8 else img.float().contiguous()
+    return ops.resample_bilinear_aa(x, (h, w), aa_bilinear_tables(W, w, img.device), aa_bilinear_tables(H, h, img.device), round_u8=round_u8, mul=mul, add=add)
+
+
 def resize_max_res(img, max_edge_resolution, resample_method="bilinear"):
-    """Marigold/marigold/util/image_util.py:79-108 — keep aspect ratio, longer edge = max_edge_resolution (host side)."""
+    """Marigold/marigold/util/image_util.py:79-108 — keep aspect ratio, longer edge = max_edge_resolution.  A device tensor is resized by the
+    library's antialiased-bilinear kernels, a host tensor by torch (the reference's own path)."""
     assert img.dim() == 3
     H, W = img.shape[-2:]
     f = min(max_edge_resolution / W, max_edge_resolution / H)
     nw, nh = int(W * f), int(H * f)
+    if img.is_cuda and resample_method == "bilinear":
+        out = resize_device(img, (nh, nw), round_u8=not img.is_floating_point())
+        return out if img.is_floating_point() else out.to(img.dtype)
     kw = {} if resample_method == "nearest" else {"align_corners": False}
     out = torch.nn.functional.interpolate(img[None].float(), size=(nh, nw), mode=resample_method,
                                           antialias=resample_method != "nearest", **kw)[0]
@@ -594,8 +641,11 @@ class DepthNormalEstimationPipeline:
             normal_pred = ensemble_normals(normal_preds)[0]
         else:
             depth_pred, normal_pred = depth_preds[0], normal_preds[0]
-        mn, mx = depth_pred.min(), depth_pred.max()
-        depth_pred = (depth_pred - mn) / (mx - mn)
+        if depth_pred.is_cuda:
+            depth_pred = ops.minmax_unit(depth_pred.float().contiguous())       # csrc/prepost.hip (zeros when the prediction is constant)
+        else:
+            mn, mx = depth_pred.min(), depth_pred.max()
+            depth_pred = (depth_pred - mn) / (mx - mn)
         hwc = False
         if match_input_res and tuple(depth_pred.shape[-2:]) != (H0, W0):
             depth_pred = torch.nn.functional.interpolate(depth_pred[None, None], size=(H0, W0), mode="bicubic", align_corners=False)[0, 0]

@@ -358,6 +358,18 @@ int e2eft_prepare_sample(int32_t batch, int64_t hw, const float* rgb01, const fl
  *   e2eft_aug_resample_bilinear_u8  in [B][h0][w0][3] uint8 -> out [B][3][h][w] fp32 in [0,1]; mid: [B][h0][w][3] uint8 scratch
  *   e2eft_aug_gather_f32            out[b][y][x] = in[b][ymap[y]][xmap[x]] (x mirrored when flip[b]): depth maps, fp32
  *   e2eft_aug_gather_u8             the same for uint8 HWC -> planar fp32 / 255 */
+/* Pre- / post-processing of the pipelines' `__call__` on the device (Marigold/marigold/marigold_pipeline.py:221-247,301-321,
+ * Marigold/marigold/util/image_util.py:79-108): torch's antialiased bilinear resize (aten `_upsample_bilinear2d_aa`, align_corners = False) of
+ * planar [planes][h0][w0] images (uint8 or fp32) to [planes][h][w] fp32 — separable, float weight tables built on the host in aten's arithmetic:
+ * bounds [out][2] = (first tap, tap count), weights [out][ksize]; mid: [planes][h0][w] fp32 scratch; round_u8: round half-to-even and clamp to
+ * [0, 255] first (torchvision's treatment of an integer image); then y = v * mul + add.
+ * e2eft_minmax_unit: out = (x - min x) / (max x - min x), zeros when max == min (marigold_pipeline.py:301-306); two-stage fixed-order reduction;
+ * minmax (optional): the two values for the caller; workspace: e2eft_minmax_unit_workspace_bytes(). */
+int e2eft_resample_bilinear_aa(int32_t planes, int32_t h0, int32_t w0, int32_t h, int32_t w, int32_t in_is_u8, const void* in,
+                               const int32_t* xbounds, const float* xweights, int32_t xksize, const int32_t* ybounds, const float* yweights,
+                               int32_t yksize, int32_t round_u8, float mul, float add, float* mid, float* out, void* stream);
+size_t e2eft_minmax_unit_workspace_bytes(void);
+int e2eft_minmax_unit(int64_t n, const float* x, float* out, float* minmax, void* workspace, size_t ws_bytes, void* stream);
 int e2eft_aug_resample_bilinear_u8(int32_t batch, int32_t h0, int32_t w0, int32_t h, int32_t w, const uint8_t* in, const uint8_t* flip,
                                    int32_t invert_x_on_flip, const int32_t* xbounds, const int32_t* xcoef, int32_t xksize,
                                    const int32_t* ybounds, const int32_t* ycoef, int32_t yksize, uint8_t* mid, float* out, void* stream);

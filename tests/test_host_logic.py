@@ -260,3 +260,28 @@ def test_evaluate_rejects_multi_channel_input_instead_of_spinning():
         evaluate._b(torch.zeros(2, 3, 4, 5))
     with pytest.raises(ValueError):
         evaluate._b(torch.zeros(2, 4, 5, 1, 1))
+
+
+def test_aa_bilinear_tables_are_atens_weights():
+    """pipeline.aa_bilinear_tables restates aten's `_compute_indices_min_size_weights_aa`: applying the tables separably (numpy model of
+    csrc/prepost.hip: horizontal pass, then vertical pass, fp32) must reproduce `F.interpolate(mode="bilinear", antialias=True)` — down-scaling
+    (support grows), up-scaling, odd ratios, and the uint8-rounded form `resize_max_res` uses"""
+    import numpy as np
+    from diffusion_e2e_ft_amd.pipeline import aa_bilinear_tables
+    g = torch.Generator().manual_seed(0)
+    for (H, W, h, w) in [(480, 640, 576, 768), (1000, 750, 768, 576), (64, 96, 64, 96), (37, 53, 11, 200), (96, 64, 480, 640)]:
+        img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
+        want = torch.nn.functional.interpolate(img[None].float(), size=(h, w), mode="bilinear", antialias=True, align_corners=False)[0].numpy()
+        (xb, xw), (yb, yw) = aa_bilinear_tables(W, w, "cpu"), aa_bilinear_tables(H, h, "cpu")
+        x = img.numpy().astype(np.float32)
+        mid = np.zeros((3, H, w), np.float32)
+        for o in range(w):
+            a, n = int(xb[o, 0]), int(xb[o, 1])
+            mid[:, :, o] = (x[:, :, a:a + n] * xw[o, :n].numpy()).sum(-1, dtype=np.float32)
+        out = np.zeros((3, h, w), np.float32)
+        for o in range(h):
+            a, n = int(yb[o, 0]), int(yb[o, 1])
+            out[:, o, :] = (mid[:, a:a + n, :] * yw[o, :n].numpy()[None, :, None]).sum(1, dtype=np.float32)
+        assert np.abs(out - want).max() <= 2e-4, ((H, W, h, w), np.abs(out - want).max())        # 0..255 scale: fp32 summation order only
+        bad = np.rint(out) != np.rint(want)          # a value within fp32 round-off of k + 0.5 may land on either side
+        assert bad.mean() < 2e-3 and (np.abs(want[bad] - np.floor(want[bad]) - 0.5) < 1e-3).all()

@@ -1,0 +1,77 @@
+"""csrc/prepost.hip — the pipelines' pre- / post-processing on the device (Marigold/marigold/marigold_pipeline.py:221-247,
+301-321, util/image_util.py:79-108): the antialiased bilinear resize against torch's own `F.interpolate(antialias=True)` on the CPU, the min-max
+normalisation, and `__call__` with a device image (everything up to the final `.cpu()` on the GPU) against the host-side path."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("H,W,h,w", [(480, 640, 576, 768), (1000, 750, 768, 576), (37, 53, 11, 200), (96, 64, 480, 640), (768, 768, 768, 768)])
+def test_resize_device_equals_torch_antialiased_bilinear(dev, H, W, h, w):
+    from diffusion_e2e_ft_amd.pipeline import resize_device
+    g = torch.Generator().manual_seed(H + w)
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
+    want = TF.interpolate(img[None].float(), size=(h, w), mode="bilinear", antialias=True, align_corners=False)[0]
+    out = resize_device(img.to(dev), (h, w)).cpu()
+    assert (out - want).abs().max().item() <= 2e-4
+    r8 = resize_device(img.to(dev), (h, w), round_u8=True, mul=2.0 / 255.0, add=-1.0).cpu()
+    w8 = want.round().clamp(0, 255) / 255.0 * 2.0 - 1.0
+    bad = (r8 - w8).abs() > 1e-6                   # a value within fp32 round-off of k + 0.5 may land on either side of the tie
+    assert bad.float().mean().item() < 2e-3 and (r8 - w8).abs().max().item() <= 2.0 / 255.0 + 1e-6
+    assert ((want[bad] - want[bad].floor() - 0.5).abs() < 1e-3).all()
+    f = torch.rand(1, H, W, generator=g)
+    want_f = TF.interpolate(f[None], size=(h, w), mode="bilinear", antialias=True, align_corners=False)[0]
+    assert (resize_device(f.to(dev), (h, w)).cpu() - want_f).abs().max().item() <= 2e-6
+
+
+def test_minmax_unit(dev):
+    from diffusion_e2e_ft_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(700, 900, generator=g) * 3 + 5
+    out = ops.minmax_unit(x.to(dev)).cpu()
+    want = (x - x.min()) / (x.max() - x.min())
+    assert torch.equal(out, want)
+    assert ops.minmax_unit(torch.full((5, 7), 2.5, device=dev)).abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("normals", [False, True])
+def test_call_with_device_pre_and_post_processing_equals_host_path(dev, normals):
+    """the same PIL-sized input through `MarigoldPipeline.__call__`: resize / normalise / min-max / resize back by libe2eft on the device vs the
+    torch host path (resample_method "bilinear" takes the device path on a GPU pipeline; forcing the host path = a CPU-side resize + the same
+    single_infer)"""
+    import golden_cases as gc
+    from oracle import config, synth
+    from diffusion_e2e_ft_amd import pipeline as P
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
+    unet = UNet2DConditionModel(**config.TINY_UNET)
+    unet.load_state_dict(gc.tiny_unet_sd())
+    vae = AutoencoderKL(**config.TINY_VAE)
+    vae.load_state_dict(gc.tiny_vae_sd())
+    pipe = P.MarigoldPipeline(unet.to(dev).eval(), vae.to(dev).eval(), DDIMScheduler())
+    _, ctx = synth.synth_inputs(1, 64, 96, 2, 128, seed=3)
+    pipe.empty_text_embed = ctx.to(dev)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (3, 150, 200), generator=g, dtype=torch.uint8)
+    kw = dict(denoising_steps=1, ensemble_size=1, processing_res=96, match_input_res=True, resample_method="bilinear", batch_size=0, color_map=None,
+              show_progress_bar=False, noise="zeros", normals=normals)
+    a = pipe(img, **kw)
+    # host path: the reference's own sequence with torch ops on the CPU around the same single_infer
+    rgb = P.resize_max_res(img, 96, "bilinear")
+    assert not rgb.is_cuda and rgb.dtype == torch.uint8
+    pred = pipe.single_infer((rgb / 255.0 * 2.0 - 1.0)[None], 1, False, noise="zeros", normals=normals).float().squeeze().cpu()
+    if normals:
+        pred = pred / (torch.norm(pred, p=2, dim=0, keepdim=True) + 1e-5)
+        want = TF.interpolate(pred[None], size=(150, 200), mode="bilinear", antialias=True, align_corners=False)[0].numpy().clip(-1, 1)
+        got = a.normal_np
+    else:
+        pred = (pred - pred.min()) / (pred.max() - pred.min())
+        want = TF.interpolate(pred[None, None], size=(150, 200), mode="bilinear", antialias=True, align_corners=False)[0, 0].numpy().clip(0, 1)
+        got = a.depth_np
+    assert got.shape == want.shape and got.dtype == np.float32
+    err = np.abs(got - want)
+    assert err.max() <= (2e-2 if normals else 5e-3) and err.mean() <= 1e-3, (err.max(), err.mean())    # a uint8 tie of the resized input may round differently
