@@ -90,6 +90,8 @@ SIGNATURES = {
     "e2eft_angular_loss_fwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     # backward / optimizer
     "e2eft_conv2d_dgrad": (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _I, _P, _I, _P]),
+    "e2eft_conv2d_wgrad_workspace_bytes": (_Z, [C.POINTER(ConvDesc), _I]),
+    "e2eft_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _P, _Z, C.POINTER(C.c_int32), _P]),
     "e2eft_conv2d_im2col_t": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _L, _P]),
     "e2eft_transpose": (_I, [_I, _I, _L, _I, _L, _L, _L, _L, _L, _P, _P, _P]),
     "e2eft_colsum_workspace_bytes": (_Z, [_I, _L, _I]),

@@ -181,11 +181,15 @@ class _Conv2dFn(torch.autograd.Function):
             if x2 is not None and need[1]:
                 dx2 = dxl[..., c1:]
         if need[2]:
-            P = dyp.shape[0] * dyp.shape[1] * dyp.shape[2]
-            nsplit, kc = ops.splitk_plan(Co, kh * kw * (c1 + c2), P)
-            dyT = ops.transpose(ops._as_rows(dyp), rows_pad=nsplit * kc)        # [cop, Pp]
-            col, _, _ = ops.im2col_t(xp, x2, kh, kw, stride, pad, up_to, Pp=nsplit * kc)   # [kh*kw*cin, Pp]
-            dwp = ops.gemm_splitk(dyT[:Co], col, nsplit, kc, alpha=alpha)       # [Co, kh*kw*cin] = OHWI
+            # straight from the NHWC tensors (csrc/wgrad.hip: transpose reads, no dY^T / im2col copies); None -> the GEMM path below (fp32, fused
+            # upsample, channel counts that are not multiples of 64)
+            dwp = ops.conv2d_wgrad(dyp, xp, x2, Co, kh, kw, stride, pad, alpha) if up_to is None else None
+            if dwp is None:
+                P = dyp.shape[0] * dyp.shape[1] * dyp.shape[2]
+                nsplit, kc = ops.splitk_plan(Co, kh * kw * (c1 + c2), P)
+                dyT = ops.transpose(ops._as_rows(dyp), rows_pad=nsplit * kc)        # [cop, Pp]
+                col, _, _ = ops.im2col_t(xp, x2, kh, kw, stride, pad, up_to, Pp=nsplit * kc)   # [kh*kw*cin, Pp]
+                dwp = ops.gemm_splitk(dyT[:Co], col, nsplit, kc, alpha=alpha)       # [Co, kh*kw*cin] = OHWI
             # the gradient is handed to autograd in the PARAMETER's stride order (OIHW contiguous): AccumulateGrad then adds / stores it
             # without a strided pass, and a DistributedDataParallel wrap finds "grad strides == bucket view strides"
             if kh == 1 and kw == 1:
@@ -270,10 +274,12 @@ class _LinearFn(torch.autograd.Function):
             dxp = ops.gemm(g64, wt, alpha=alpha)                    # [M, kp]
             dx = dxp.view(*xp.shape[:-1], kp)[..., :K]
         if any(need[7:]):
-            nsplit, kc = ops.splitk_plan(N, kp, M)
-            gT = ops.transpose(g, rows_pad=nsplit * kc)             # [N, Mp]
-            xT = ops.transpose(_rows(xp), rows_pad=nsplit * kc)     # [kp, Mp]
-            dw = ops.gemm_splitk(gT, xT, nsplit, kc, alpha=alpha)   # [N, kp]
+            dw = ops.linear_wgrad(g, _rows(xp), alpha) if M >= 512 else None      # csrc/wgrad.hip (1x1 case); None -> the transposes + GEMM below
+            if dw is None:
+                nsplit, kc = ops.splitk_plan(N, kp, M)
+                gT = ops.transpose(g, rows_pad=nsplit * kc)             # [N, Mp]
+                xT = ops.transpose(_rows(xp), rows_pad=nsplit * kc)     # [kp, Mp]
+                dw = ops.gemm_splitk(gT, xT, nsplit, kc, alpha=alpha)   # [N, kp]
             o = 0
             for i, wgt in enumerate(weights):
                 n = wgt.shape[0]

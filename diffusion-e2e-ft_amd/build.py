@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libe2eft.so")
-SOURCES = ["api.hip", "igemm.hip", "igemm2.hip", "igemm5.hip", "norm.hip", "attn.hip", "attn512.hip", "attn_bwd.hip", "elementwise.hip", "loss.hip", "bwd.hip", "ensemble.hip", "dataprep.hip", "narrow.hip", "dataaug.hip", "evalmetrics.hip", "prepost.hip"]
+SOURCES = ["api.hip", "igemm.hip", "igemm2.hip", "igemm5.hip", "norm.hip", "attn.hip", "attn512.hip", "attn_bwd.hip", "elementwise.hip", "loss.hip", "bwd.hip", "wgrad.hip", "ensemble.hip", "dataprep.hip", "narrow.hip", "dataaug.hip", "evalmetrics.hip", "prepost.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # Per-file flags.  The implicit-GEMM files are built without the SLP vectorizer: it turns the epilogue's per-column fp32
 # arithmetic into v_pk_add_f32 with operand swizzles (op_sel:[0,1] — the low result lane reads the HIGH dword of src1), and on

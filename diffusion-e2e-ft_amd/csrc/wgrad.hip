@@ -1,0 +1,275 @@
+// wgrad.hip — weight gradients of convolutions and Linears straight from the NHWC tensors (fp16 / bf16), gfx950.
+//
+//   dW[co][(ky, kx, ci)] = alpha * sum_p dY[p][co] * X[pixel(p) (+) (ky, kx)][ci]          (the reference: torch autograd of nn.Conv2d / nn.Linear in the
+//   UNet, training/train.py:563 `accelerator.backward(loss)`; a Linear is the 1x1 case with p = token)
+//
+// Both operands are contracted over their SLOW index (pixels), while an MFMA fragment wants 8 consecutive k per lane.  Round 1 / 2 therefore
+// materialised K-contiguous copies first — e2eft_transpose(dY), e2eft_conv2d_im2col_t(X) (9x the input for a 3x3 filter) — and ran the NT GEMM on
+// them: 24 of the 544 ms of an E2E-FT step were those copies.  Here the tiles stay pixel-major in LDS, exactly as they lie in HBM, and the k-contiguous
+// fragments are produced by the transpose read ds_read_b64_tr_b16 (a lane of a 16-lane group supplies the address of 4 consecutive channels of one
+// pixel and receives 4 pixels of one channel): no transposed or im2col'ed tensor exists anywhere.
+//
+//   * workgroup = 128 output channels x 128 columns (two 64-channel chunks of (tap, ci) space: a chunk never straddles a tap or a concat source, so
+//     its rows are one shifted window of ONE input tensor) x a range of pixels (split-K over the grid's z: a weight gradient has a handful of output
+//     tiles and 10^4 - 10^5 pixels); 4 waves, 64 x 64 each, 2 workgroups per CU;
+//   * k-tile = 64 pixels: four [64 pixels][64 channels] panels (two of dY, two of X) of 8 KB, filled by LDS-DMA in 1-KiB pieces of 8 pixel rows
+//     (`buffer_load ... lds`; the im2col shift, the zero padding, the stride and the split's end are the per-lane source offset — out of range reads
+//     zeros), two stages; 16-byte chunk c of pixel row r lands in slot c ^ (((r >> 1) & 1) << 2): the four rows of a transpose read then cover four
+//     different 64-byte bank windows (conflict-free), and the key is constant per lane;
+//   * partial sums leave as fp32 [split][Co][kh kw cin]; e2eft_colsum (the reduction the split-K NT path already used) adds the splits.
+// Eligibility is decided here (returns E2EFT_ERR_UNSUPPORTED and the caller keeps the transpose + im2col_t + GEMM path): 16-bit, cin and c1 multiples
+// of 64, no fused upsample, tensors below 4 GB.
+#include "common.h"
+#include <type_traits>
+
+namespace e2eft {
+
+namespace wg {
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int PANEL = 64 * 128;            // [64 pixels][64 channels] of 16-bit
+constexpr int STAGE = 4 * PANEL;           // dY panels 0, 1; X panels 0, 1
+constexpr int LDS = 2 * STAGE;             // 65536 B: two workgroups per CU
+}  // namespace wg
+
+struct WgradParams {
+    const void* dy;
+    const void* x1;
+    const void* x2;
+    float* out;
+    int ldy, ldx1, ldx2, c1, cin;
+    int batch, hin, win, hout, wout, kh, kw, stride, pad_t, pad_l;
+    int M, N, P;            // Co, kh * kw * cin, batch * hout * wout
+    int kchunk, nsplit;     // pixels per split (multiple of 64)
+    float alpha;
+};
+
+template <typename T> struct MmaW;
+template <> struct MmaW<f16> {
+    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+};
+template <> struct MmaW<bf16> {
+    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bhalf8, a), __builtin_bit_cast(bhalf8, b), c, 0, 0, 0);
+    }
+};
+
+typedef short short4vw __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 tr_read_w(const char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4vw*)p));
+}
+// one LDS-DMA piece (64 lanes x 16 B -> 1 KiB at m0) from asm: the compiler must not count it (it would drain vmcnt in front of LDS reads it cannot
+// prove disjoint); the kernel waits for its own pieces once per k-tile.  m0 is saved and restored (compiler-reserved).
+__device__ __forceinline__ void dma_piece_w(const __amdgpu_buffer_rsrc_t& rs, const unsigned voff, const unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ int fdiv_w(int n, int d) {   // float estimate + one correction (quotients below 2^22)
+    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
+    const int r = n - q * d;
+    if (r < 0) --q;
+    else if (r >= d) ++q;
+    return q;
+}
+
+// grid (ceil(N / 128), ceil(M / 128), nsplit), 256 threads
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+    using namespace wg;
+    __shared__ __attribute__((aligned(16))) char smem[LDS];
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int k_begin = blockIdx.z * p.kchunk, k_end = min(p.P, k_begin + p.kchunk);
+    const unsigned OOB = 0xFFFFFFF0u;
+
+    // ---- the two 64-column chunks of this tile: (tap, first channel, source)
+    const int cpt = p.cin >> 6;                        // chunks per tap
+    int tap[2], ci0[2], ky[2], kx[2];
+    bool cok[2], src2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = (n0 >> 6) + j;
+        cok[j] = q * 64 < p.N;
+        tap[j] = cok[j] ? q / cpt : 0;
+        ci0[j] = cok[j] ? (q - tap[j] * cpt) * 64 : 0;
+        ky[j] = tap[j] / p.kw; kx[j] = tap[j] - ky[j] * p.kw;
+        src2[j] = ci0[j] >= p.c1;
+    }
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)(((long)(p.P - 1) * p.ldy + p.M) * (long)sizeof(T)), 0x00020000);
+    const long xpix = (long)p.batch * p.hin * p.win;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, (unsigned)(((xpix - 1) * p.ldx1 + p.c1) * (long)sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x1), 0,
+                                                                         (unsigned)(((xpix - 1) * (p.x2 ? p.ldx2 : p.ldx1) + (p.x2 ? p.cin - p.c1 : p.c1)) * (long)sizeof(T)), 0x00020000);
+    const unsigned lds0 = (unsigned)(uintptr_t)((lptr_t)smem);
+
+    // ---- loader: wave w moves pieces 2 w and 2 w + 1 (pixel rows 16 w .. 16 w + 15 of the k-tile) of all four panels.  Lane l of a piece: pixel row
+    // (l >> 3) of the piece, LDS slot l & 7 of that row = source chunk (l & 7) ^ key(row)
+    const int prow = lane >> 3;
+    const int hw_out = p.hout * p.wout;
+    auto issue = [&](const int kt, const int stage) {
+        const int kbase = k_begin + kt * BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 16 * wave + 8 * j + prow;                 // pixel row inside the k-tile
+            const int pix = kbase + r;
+            const bool pok = pix < k_end;
+            const int sc = (lane & 7) ^ (((r >> 1) & 1) << 2);      // source chunk of this lane's slot
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(stage * STAGE + (16 * wave + 8 * j) * 128)));
+            // dY panels: columns m0 + 64 a + 8 sc .. + 7 of pixel row `pix`
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int col = m0 + 64 * a + 8 * sc;
+                const unsigned off = (pok && col < p.M) ? (unsigned)(((long)pix * p.ldy + col) * (long)sizeof(T)) : OOB;
+                dma_piece_w(rsy, off, dst + (unsigned)(a * PANEL));
+            }
+            // X panels: output pixel -> (image, oy, ox) -> input pixel of the chunk's tap
+            const int bimg = fdiv_w(pix, hw_out);
+            const int rem = pix - bimg * hw_out;
+            const int oy = fdiv_w(rem, p.wout), ox = rem - oy * p.wout;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int iy = oy * p.stride - p.pad_t + ky[c], ix = ox * p.stride - p.pad_l + kx[c];
+                const bool ok = pok && cok[c] && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
+                const long ipix = ((long)bimg * p.hin + iy) * p.win + ix;
+                const unsigned off = !ok ? OOB : (src2[c] ? (unsigned)((ipix * p.ldx2 + (ci0[c] - p.c1) + 8 * sc) * (long)sizeof(T))
+                                                          : (unsigned)((ipix * p.ldx1 + ci0[c] + 8 * sc) * (long)sizeof(T)));
+                if (src2[c]) dma_piece_w(rs2, off, dst + (unsigned)((2 + c) * PANEL));      // (uniform branch: a descriptor select would leave the SGPRs)
+                else dma_piece_w(rs1, off, dst + (unsigned)((2 + c) * PANEL));
+            }
+        }
+    };
+
+    // ---- fragment addresses (transpose reads).  32x32x16 operand of lane (column = l31, k-slots 8 hh .. + 7): two reads of 4 pixel rows each.
+    // 16-lane group g serves columns 16 (g & 1) .. + 15 of the 32-block; lane i of the group supplies pixel row (i >> 2) of the 4-row run and
+    // channels 4 (i & 3) .. + 3.  row = 16 ks + 8 hh [+ 4] + (i >> 2): (row >> 1) & 1 = (i >> 3) & 1 — the swizzle key is a lane constant.
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int key = ((i16 >> 3) & 1) << 2;
+    auto frag_off = [&](const int blk) {      // byte offset inside a panel of this lane's first read for 32-column block `blk` (0 / 1), k-step 0
+        const int chunk = (4 * blk + 2 * g1 + ((i16 >> 1) & 1)) ^ key;
+        return (8 * hh + (i16 >> 2)) * 128 + chunk * 16 + (i16 & 1) * 8;
+    };
+    const int fo[2] = {frag_off(0), frag_off(1)};
+    auto frag = [&](const char* panel, const int blk, const int ks) -> u32x4 {
+        const char* a = panel + fo[blk] + ks * (16 * 128);
+        const u32x2 v0 = tr_read_w(a);
+        const u32x2 v1 = tr_read_w(a + 4 * 128);
+        return u32x4{v0[0], v0[1], v1[0], v1[1]};
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nkt = (k_end - k_begin + BK - 1) / BK;
+    if (nkt > 0) {
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int st = kt & 1;
+            if (kt + 1 < nkt) issue(kt + 1, st ^ 1);
+            const char* pa = smem + st * STAGE + wm * PANEL;
+            const char* pb = smem + st * STAGE + (2 + wn) * PANEL;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 a0 = frag(pa, 0, ks), a1 = frag(pa, 1, ks), b0 = frag(pb, 0, ks), b1 = frag(pb, 1, ks);
+                acc[0][0] = MmaW<T>::run(a0, b0, acc[0][0]);
+                acc[0][1] = MmaW<T>::run(a0, b1, acc[0][1]);
+                acc[1][0] = MmaW<T>::run(a1, b0, acc[1][0]);
+                acc[1][1] = MmaW<T>::run(a1, b1, acc[1][1]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of k-tile kt + 1 have landed
+            __builtin_amdgcn_s_barrier();                        // ... everybody's, and everybody is done reading k-tile kt
+            asm volatile("" ::: "memory");
+        }
+    }
+    // ---- partial tile out: fp32 [split][M][N]; a lane holds column n of 16 rows per block (rows (r & 3) + 8 (r >> 2) + 4 hh)
+    float* out = p.out + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + 32 * j + l31;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (m < p.M) out[(long)m * p.N + n] = acc[i][j][r] * p.alpha;
+            }
+    }
+}
+
+static void wgrad_plan(long M, long N, long P, int& nsplit, int& kchunk) {
+    const long tiles = cdiv(M, wg::BM) * cdiv(N, wg::BN);
+    long want = cdiv(1024, tiles);
+    const long cap = P / 512 > 0 ? P / 512 : 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    kchunk = (int)(cdiv(cdiv(P, want), wg::BK) * wg::BK);
+    nsplit = cdiv(P, kchunk);
+}
+
+}  // namespace e2eft
+
+using namespace e2eft;
+
+static int wgrad_check(const E2eftConvDesc* d, int lddy) {
+    if (!d) return fail(E2EFT_ERR_BAD_ARG, "wgrad: null descriptor");
+    if (d->dtype != E2EFT_F16 && d->dtype != E2EFT_BF16) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: 16-bit only (fp32 keeps the transpose + GEMM path)");
+    const int cin = d->c1 + d->c2;
+    if (cin % 64 != 0 || d->c1 % 64 != 0) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: channel counts (%d, %d) must be multiples of 64", d->c1, d->c2);
+    if (d->hl != d->hin || d->wl != d->win) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: fused upsample not supported");
+    if (d->batch <= 0 || d->hin <= 0 || d->win <= 0 || d->hout <= 0 || d->wout <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0)
+        return fail(E2EFT_ERR_BAD_ARG, "wgrad: geometry");
+    const long P = (long)d->batch * d->hout * d->wout, xpix = (long)d->batch * d->hin * d->win;
+    const long ldx = d->ldx1 > d->ldx2 ? d->ldx1 : d->ldx2;
+    if (P * lddy * 2 >= 0xFFFF0000L || xpix * ldx * 2 >= 0xFFFF0000L) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: tensors of 4 GB and more");
+    if (P >= (1L << 24)) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: more than 2^24 output pixels (the pixel split uses float reciprocals)");
+    if ((long)d->hout * d->wout >= (1L << 22)) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: image too large for the index arithmetic");
+    if (d->ldx1 % 8 != 0 || (d->c2 > 0 && d->ldx2 % 8 != 0) || lddy % 8 != 0 || lddy < d->cout) return fail(E2EFT_ERR_BAD_ARG, "wgrad: row strides");
+    return E2EFT_OK;
+}
+
+extern "C" size_t e2eft_conv2d_wgrad_workspace_bytes(const E2eftConvDesc* d, int32_t lddy) {
+    if (wgrad_check(d, lddy) != E2EFT_OK) return 0;
+    int nsplit, kchunk;
+    const long N = (long)d->kh * d->kw * (d->c1 + d->c2);
+    wgrad_plan(d->cout, N, (long)d->batch * d->hout * d->wout, nsplit, kchunk);
+    return (size_t)nsplit * d->cout * N * sizeof(float);
+}
+
+extern "C" int e2eft_conv2d_wgrad(const E2eftConvDesc* d, const void* dy, int32_t lddy, const void* x1, const void* x2, float* partial, size_t partial_bytes,
+                                  int32_t* nsplit_out, void* stream) {
+    const int rc = wgrad_check(d, lddy);
+    if (rc != E2EFT_OK) return rc;
+    E2EFT_REQUIRE(dy && x1 && partial && nsplit_out && (d->c2 == 0 || x2), "wgrad: null pointer");
+    E2EFT_REQUIRE((((uintptr_t)dy | (uintptr_t)x1 | (uintptr_t)x2) & 15) == 0, "wgrad: pointers must be 16-byte aligned");
+    WgradParams p;
+    p.dy = dy; p.x1 = x1; p.x2 = d->c2 > 0 ? x2 : nullptr; p.out = partial;
+    p.ldy = lddy; p.ldx1 = d->ldx1; p.ldx2 = d->ldx2; p.c1 = d->c1; p.cin = d->c1 + d->c2;
+    p.batch = d->batch; p.hin = d->hin; p.win = d->win; p.hout = d->hout; p.wout = d->wout;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.M = d->cout; p.N = d->kh * d->kw * p.cin; p.P = d->batch * d->hout * d->wout;
+    wgrad_plan(p.M, p.N, p.P, p.nsplit, p.kchunk);
+    p.alpha = d->alpha;
+    const size_t need = (size_t)p.nsplit * p.M * p.N * sizeof(float);
+    if (partial_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "wgrad: partial buffer %zu < %zu bytes", partial_bytes, need);
+    *nsplit_out = p.nsplit;
+    dim3 grid(cdiv(p.N, wg::BN), cdiv(p.M, wg::BM), p.nsplit);
+    E2EFT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "wgrad: grid");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == E2EFT_F16) hipLaunchKernelGGL((wgrad_kernel<f16>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<bf16>), grid, dim3(256), 0, s, p);
+    return check_launch("wgrad");
+}

@@ -727,6 +727,51 @@ def im2col_t(x, x2, kh, kw, stride, pad, up_to=None, Pp=None):
     return col, P, Pp
 
 
+WGRAD_DIRECT = True   # tests / A-B: False keeps every weight gradient on the transpose + im2col_t + split-K GEMM path
+
+
+def conv2d_wgrad(dy, x, x2, cout, kh, kw, stride, pad, alpha):
+    """Weight gradient straight from the NHWC tensors (csrc/wgrad.hip): dy [B,hout,wout,>=cout] (pixel-dense), x [B,H,W,c1], x2 optional second
+    concat source -> fp32 [cout, kh*kw*(c1+c2)] (OHWI rows), or None when the kernel does not serve the problem (the caller falls back)."""
+    if not WGRAD_DIRECT or dy.dtype == torch.float32:
+        return None
+    _check_cuda(dy, x, x2)
+    d = _conv_desc(x, x2, cout, kh, kw, stride, pad, None, alpha)
+    assert tuple(dy.shape[:3]) == (d.batch, d.hout, d.wout), (dy.shape, d.batch, d.hout, d.wout)
+    lddy = _nhwc_ld(dy)
+    lib = _lib.load()
+    nbytes = lib.e2eft_conv2d_wgrad_workspace_bytes(C.byref(d), lddy)
+    if nbytes == 0:
+        return None
+    cin = d.c1 + d.c2
+    N = kh * kw * cin
+    part = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
+    ns = C.c_int32(0)
+    P = d.batch * d.hout * d.wout
+    with _timed("wgrad", 2.0 * P * cout * N, (P * (cout + cin)) * dy.element_size(), label="wgrad %dx%ds%d P%d %d->%d" % (kh, kw, stride, P, cin, cout)):
+        check(lib.e2eft_conv2d_wgrad(C.byref(d), _ptr(dy), lddy, _ptr(x), _ptr(x2), _ptr(part), nbytes, C.byref(ns), _stream()))
+    if ns.value == 1:
+        return part.view(cout, N)
+    return colsum(part.view(ns.value, cout * N), groups=1).view(cout, N)
+
+
+def linear_wgrad(dy2d, x2d, alpha=1.0):
+    """dW [N, K] fp32 = alpha * dy2d^T x2d for row views dy2d [M, N], x2d [M, K] (K a multiple of 64) — the 1x1 case of conv2d_wgrad; None = fall back"""
+    if not WGRAD_DIRECT or dy2d.dtype == torch.float32 or x2d.shape[1] % 64 != 0:
+        return None
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    try:
+        ldy, ldx = _rows_ld(dy2d), _rows_ld(x2d)
+    except ValueError:
+        return None
+    if ldy % 8 != 0 or ldx % 8 != 0 or dy2d.data_ptr() % 16 != 0 or x2d.data_ptr() % 16 != 0:
+        return None
+    xv = x2d.as_strided((1, 1, M, K), (M * ldx, M * ldx, ldx, 1))
+    dv = dy2d.as_strided((1, 1, M, N), (M * ldy, M * ldy, ldy, 1))
+    return conv2d_wgrad(dv, xv, None, N, 1, 1, 1, (0, 0, 0, 0), alpha)
+
+
 def conv2d_dgrad(dy, w_dgrad, x_shape, c2, kh, kw, stride, pad, up_to, alpha):
     """dy [B,hout,wout,cout_pad] (zero / finite pad channels), w_dgrad [cin, kh*kw*cout_pad]; x_shape = forward x [B,H,W,c1].
     Returns the gradient w.r.t. the logical (upsampled) concatenated input [B, hl, wl, c1+c2]."""

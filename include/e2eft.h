@@ -209,6 +209,16 @@ int e2eft_attn_fwd_lse(const E2eftAttnDesc* d, const void* q, const void* k, con
 size_t e2eft_attn512_workspace_bytes(const E2eftAttnDesc* d);
 int e2eft_attn512_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, void* workspace, size_t ws_bytes,
                       void* stream);
+/* Weight gradient of the convolution `d` describes (and of nn.Linear = its 1x1 case), 16-bit, straight from the NHWC tensors:
+ *   dW[co][(ky, kx, ci)] = alpha * sum over output pixels p of dy[p][co] * x[input pixel of (p, ky, kx)][ci]     (OHWI rows = the packed weight layout)
+ * — torch autograd of nn.Conv2d / nn.Linear w.r.t. the weight (training/train.py:563).  dy: [batch*hout*wout][lddy] (cout columns used), x1 / x2: the
+ * forward's input(s).  The pixel sum is split over the grid; `partial` receives fp32 [nsplit][cout][kh*kw*(c1+c2)] and *nsplit_out the number of
+ * splits to add up (e2eft_colsum).  e2eft_conv2d_wgrad_workspace_bytes: the size of `partial`, or 0 when this kernel does not serve the problem
+ * (fp32, channel counts not multiples of 64, fused upsample, >= 4 GB tensors): the caller then uses e2eft_transpose + e2eft_conv2d_im2col_t +
+ * e2eft_gemm; e2eft_conv2d_wgrad itself returns E2EFT_ERR_UNSUPPORTED for those. */
+size_t e2eft_conv2d_wgrad_workspace_bytes(const E2eftConvDesc* d, int32_t lddy);
+int e2eft_conv2d_wgrad(const E2eftConvDesc* d, const void* dy, int32_t lddy, const void* x1, const void* x2, float* partial, size_t partial_bytes,
+                       int32_t* nsplit_out, void* stream);
 /* Fused attention backward (head dim 64, fp16 / bf16, kv_nseg == 1; autograd of F.scaled_dot_product_attention /
  * xformers.memory_efficient_attention in diffusers Attention processors, attention.py:338-343,375-380): dq [B,Nq,heads*64],
  * dk / dv [B,Nk,heads*64] (row strides lddq / lddk / lddv), from q, k, v, the forward output `out` (desc ldo), its gradient
