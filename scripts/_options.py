@@ -1,0 +1,19 @@
+"""Shared by the micro-benchmarks: trailing `name=value` arguments (persistent=0, persistent_grid=8, narrow_conv=0, narrow_mfma=0,
+igemm_general_operands=1, igemm2_waves=4) become e2eft_set_option calls — the library itself never reads the environment."""
+from diffusion_e2e_ft_amd import _lib
+
+NAMES = {"persistent": _lib.OPT_PERSISTENT, "persistent_grid": _lib.OPT_PERSISTENT_GRID, "narrow_conv": _lib.OPT_NARROW_CONV,
+         "narrow_mfma": _lib.OPT_NARROW_MFMA, "igemm_general_operands": _lib.OPT_IGEMM_GENERAL_OPERANDS, "igemm2_waves": _lib.OPT_IGEMM2_WAVES}
+
+
+def take(argv):
+    """strip `name=value` items from argv, apply them, return the remaining positional arguments"""
+    rest = []
+    for a in argv:
+        k, _, v = a.partition("=")
+        if k in NAMES and v.lstrip("-").isdigit():
+            _lib.set_option(NAMES[k], int(v))
+            print("option %s = %s" % (k, v))
+        else:
+            rest.append(a)
+    return rest

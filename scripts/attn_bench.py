@@ -5,8 +5,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffusion_e2e_ft_amd import ops
+import _options
 
-a = sys.argv[1:]
+a = _options.take(sys.argv[1:])
 B, H, N = (int(v) for v in a[:3])
 iters = int(a[3]) if len(a) > 3 else 20
 dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[a[4] if len(a) > 4 else "fp16"]

@@ -1,5 +1,5 @@
 """Micro-benchmark of one implicit-GEMM conv shape through the C ABI (for rocprofv3 PMC passes and A/B runs).
-usage: python scripts/conv_bench.py B H W Cin Cout [k=3] [iters=10] [dtype=fp16] [residual=0]"""
+usage: python scripts/conv_bench.py B H W Cin Cout [k=3] [iters=10] [dtype=fp16] [residual=0] [option=value ...]   (options: scripts/_options.py, e.g. persistent=0)"""
 import os
 import sys
 import time
@@ -7,8 +7,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffusion_e2e_ft_amd import ops
+import _options
 
-a = sys.argv[1:]
+a = _options.take(sys.argv[1:])
 B, H, W, Ci, Co = (int(v) for v in a[:5])
 k = int(a[5]) if len(a) > 5 else 3
 iters = int(a[6]) if len(a) > 6 else 10

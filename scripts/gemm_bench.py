@@ -1,13 +1,14 @@
 """Micro-benchmark of one GEMM shape (out[M,N] = a[M,K] w[N,K]^T + bias) through the C ABI, for A/B runs of kernel heuristics.
-usage: python scripts/gemm_bench.py M N K [iters=20] [dtype=fp16] [residual=0]"""
+usage: python scripts/gemm_bench.py M N K [iters=20] [dtype=fp16] [residual=0] [option=value ...]   (options: scripts/_options.py, e.g. persistent=0)"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffusion_e2e_ft_amd import ops
+import _options
 
-a = sys.argv[1:]
+a = _options.take(sys.argv[1:])
 M, N, K = (int(v) for v in a[:3])
 iters = int(a[3]) if len(a) > 3 else 20
 dt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[a[4] if len(a) > 4 else "fp16"]
