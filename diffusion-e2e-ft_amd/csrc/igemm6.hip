@@ -1,0 +1,582 @@
+// igemm6.hip — persistent implicit GEMM for 3x3 / stride-1 / pad-1 convolutions whose A operand is a 2-D HALO PATCH held in LDS
+// (gfx950, fp16 / bf16): the variant of igemm5.hip that stops re-fetching every input pixel once per filter tap.
+//
+// Why: igemm5 walks K tap-major — k-tile (ky, kx, 64 channels) — and fetches a fresh 256-row x 128-byte A stage for every k-tile, so a
+// 64-channel slice of an input pixel travels L2 -> LDS nine times per output tile.  Measured with the A pieces of eight taps in nine
+// switched off (profiles/r03d_a_operand_delivery_probe.txt): +7.7 % at 128->128 @768^2, +9.2 % at 256->256 @384^2, +11.2 % at
+// 512->512 @192^2 — operand delivery (LDS-DMA issue, LDS write bandwidth, L2 reads and their energy at the package power cap), not MFMA
+// issue, is what the k-loop of the 3x3 layers still pays for.  Here
+//   * an output tile is an 8-row x 32-column block of ONE image (256 GEMM rows), K runs chunk-major — k-tile (64 channels, tap) — and the
+//     A operand of all nine taps of a chunk is one (8+2) x (32+2)-pixel patch: 340 rows of 128 bytes, 43 LDS-DMA pieces instead of
+//     9 x 32 = 288;
+//   * two patch buffers: while the nine k-tiles of chunk c multiply out of one, the patch of chunk c+1 (or chunk 0 of the workgroup's
+//     next tile) arrives in the other — at most one A piece per wave and k-tile, beside the two B pieces that the 3-stage weight ring
+//     needs; every k-tile issues exactly three pieces (surplus ones fetch zeros into a dump kilobyte), so all waits are counted;
+//   * the fragment of output pixel (y, x), tap (ky, kx) is patch row (y + ky) * 34 + x + kx: 32 consecutive patch rows per MFMA operand, the
+//     same XOR chunk swizzle as igemm2 / igemm5 keyed by the PATCH row (conflict-free for any start row); the nine k-tiles of a chunk are
+//     unrolled, the tap shift is an immediate;
+//   * zero padding costs nothing: patch rows outside the image carry an out-of-range buffer offset;
+//   * no row table, no per-tap offset arithmetic: a lane's six patch rows are fixed for the whole launch, a tile switch is six
+//     multiply-adds;
+//   * tile-entry arithmetic, epilogue operand prefetch, barrier placement, both epilogues (fp32 sliced with a residual, packed without),
+//     GroupNorm statistics: as igemm5.hip, with rows of the tile mapped to the 8 x 32 block (a wave's 64 rows = two image rows).
+// Eligibility (host, launch_igemm_patch returns -1 and the caller falls through to igemm5): conv mode, 3x3, stride 1, pad 1, no fused
+// upsample / zero insertion, width a multiple of 32, height of 8, channels (each concat part) multiples of 64 and at least 128, the
+// vector epilogue, at least two tiles per workgroup.  e2eft_set_option(E2EFT_OPT_PATCH_CONV, 0) disables it.
+// Summation order: per output element k runs (chunk, tap) instead of (tap, chunk) — fp32 accumulation, results differ from igemm5 in the
+// last bits (documented in include/e2eft.h; deterministic run to run).
+#include "igemm.h"
+#include <atomic>
+#include <type_traits>
+
+namespace e2eft {
+
+namespace patchk {
+constexpr int BM = 256, BN = 128, NW = 8;
+constexpr int TH = 8, TW = 32, PW = TW + 2, PROWS = (TH + 2) * PW;     // 340 patch rows
+constexpr int PPIECES = (PROWS + 7) / 8;                                // 43 one-KiB pieces
+constexpr int PATCH = PPIECES * 1024;                                   // 44,032 B
+constexpr int B_STAGE = BN * 128;
+constexpr int OFF_B = 2 * PATCH;
+constexpr int OFF_DEP = OFF_B + 3 * B_STAGE;
+constexpr int DEP = NW * 64 * 3 * 4;
+constexpr int OFF_DUMP = OFF_DEP + DEP;
+constexpr int LDS = OFF_DUMP + NW * 1024;                               // 151,552 B
+constexpr unsigned int OOB = 0xF0000000u;
+constexpr unsigned int RECORDS = 0xE0000000u;
+}  // namespace patchk
+
+template <typename T> struct Mma6;
+template <> struct Mma6<f16> {
+    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma6<bf16> {
+    __device__ static __forceinline__ floatx16 run(const u32x4& a, const u32x4& b, floatx16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bhalf8, a), __builtin_bit_cast(bhalf8, b), c, 0, 0, 0);
+    }
+};
+
+typedef __attribute__((address_space(3))) void* lptr6_t;
+template <int V> using IC6 = std::integral_constant<int, V>;
+
+__device__ __forceinline__ int fast_div6(int n, int d) {   // float estimate + one correction (quotients below 2^22)
+    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
+    const int r = n - q * d;
+    if (r < 0) --q;
+    else if (r >= d) ++q;
+    return q;
+}
+
+template <typename T, bool RES>
+__global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const int total_tiles) {
+    using namespace patchk;
+    __shared__ __attribute__((aligned(128))) char smem[LDS];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nch = p.cin >> 6;              // 64-channel chunks, host: >= 2
+    const int H = p.hin, W = p.win;
+    const int tw = W / TW, tpi = (H / TH) * tw;   // tiles per image row / per image
+
+    // ---- tile sequence of this workgroup: as igemm5 (eight contiguous chunks of the tile range, one per XCD)
+    const int nslots = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int q8 = total_tiles >> 3, r8 = total_tiles & 7;
+    const int cbeg = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int cend = cbeg + (xcd < r8 ? q8 + 1 : q8);
+    int u_dma = cbeg + slot;
+    if (u_dma >= cend) return;
+
+    // ---- loader state
+    // A: piece j = wave + 8 i (i = 0..5) covers patch rows 8 j .. 8 j + 7; this lane's row and its swizzled 16-byte chunk are fixed
+    const int jc16 = ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7)) * 16;   // ((patch row >> 1) & 7 = (4 j + (lane >> 4)) & 7, 32 i = 0 mod 8)
+    int pyx[6];                               // (patch y << 16) | patch x of the lane's row in piece i; y = 0x4000 for rows beyond the patch
+    int pix[6];                               // pixel index of that row inside the loader's image, -1 = padding / no tile
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int prow = 8 * (wave + 8 * i) + (lane >> 3);
+        const int py = (prow * 241) >> 13;    // prow / 34 for prow < 1000
+        pyx[i] = prow < PROWS ? (py << 16) | (prow - PW * py) : (0x4000 << 16);
+    }
+    // B: as igemm5 (rows lrow, lrow + 64 of the 128-row weight stage)
+    const int lrow = 8 * wave + (lane >> 3);
+    const int jcb = (lane & 7) ^ ((lrow >> 1) & 7);
+    unsigned int brow[2];
+    int d_n0 = 0, d_img = 0, d_oy0 = 0, d_ox0 = 0, d_mt = 0;   // the loader's tile
+    bool dma_done = false;
+    __amdgpu_buffer_rsrc_t rs1, rs2, rsw, rsa;
+    unsigned int a_ldb = 0, a_coff = 0;       // A pieces of the chunk being fetched: pixel pitch in bytes, channel + swizzle offset
+
+    auto tile_coords = [&](const int u) {
+        int mt = u, nt = 0;
+        if (p.ntiles > 1) { mt = fast_div6(u, p.ntiles); nt = u - mt * p.ntiles; }
+        d_mt = mt; d_n0 = nt * BN;
+        d_img = fast_div6(mt, tpi);
+        const int rem = mt - d_img * tpi;
+        const int ty = fast_div6(rem, tw);
+        d_oy0 = ty * TH; d_ox0 = (rem - ty * tw) * TW;
+    };
+    auto set_a = [&](const bool valid) {      // A address state of the loader's tile (d_*): pixel indices of the six rows, image descriptors
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int iy = d_oy0 - 1 + (pyx[i] >> 16), ix = d_ox0 - 1 + (pyx[i] & 0xffff);
+            const bool ok = valid && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            pix[i] = ok ? iy * W + ix : -1;
+        }
+        const T* b1 = (const T*)p.x1 + (long)d_img * H * W * p.ldx1;
+        const T* b2 = p.x2 ? (const T*)p.x2 + (long)d_img * H * W * p.ldx2 : b1;
+        rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, RECORDS, 0x00020000);
+        rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)b2, 0, RECORDS, 0x00020000);
+    };
+    auto set_b = [&](const bool valid) {      // B address state of the loader's tile
+        rsw = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.w + (long)d_n0 * p.ldw), 0, RECORDS, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = d_n0 + lrow + 64 * i;
+            brow[i] = (valid && n < p.N) ? (unsigned)((lrow + 64 * i) * p.ldw + jcb * 8) * (unsigned)sizeof(T) : OOB;
+        }
+    };
+    auto set_chunk = [&](const int cn) {      // source of chunk cn's patch: x1 for channels below c1, x2 above (concat)
+        const int ch = cn * 64;
+        if (ch < p.c1) { rsa = rs1; a_ldb = (unsigned)p.ldx1 * (unsigned)sizeof(T); a_coff = (unsigned)ch * (unsigned)sizeof(T) + (unsigned)jc16; }
+        else { rsa = rs2; a_ldb = (unsigned)p.ldx2 * (unsigned)sizeof(T); a_coff = (unsigned)(ch - p.c1) * (unsigned)sizeof(T) + (unsigned)jc16; }
+    };
+    int pcur = 0, pnext = PATCH;              // patch buffer being multiplied / being filled
+    int bs_cur = OFF_B, bs_nxt = OFF_B + B_STAGE, bs_dst = OFF_B + 2 * B_STAGE;
+    auto fire_a = [&](auto ic, const int pdst) {   // piece i of the patch being fetched (i >= 6: a surplus piece, zeros into the dump kilobyte)
+        constexpr int i = decltype(ic)::value;
+        unsigned off = OOB;
+        int dst = OFF_DUMP + wave * 1024;
+        if constexpr (i < 6) {
+            off = pix[i] < 0 ? OOB : (unsigned)pix[i] * a_ldb + a_coff;
+            const int j = wave + 8 * i;
+            if (j < PPIECES) dst = pdst + j * 1024;   // (wave-uniform)
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lptr6_t)(smem + dst), 16, off, 0, 0, 0);
+    };
+    auto fire_b = [&](const int stage, const unsigned kofs) {
+        char* sb = smem + stage + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr6_t)sb, 16, brow[0] + kofs, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr6_t)(sb + 64 * 128), 16, brow[1] + kofs, 0, 0, 0);
+    };
+
+    floatx16 acc[2][2];
+    // B fragment byte offsets inside a stage (read-side swizzle as igemm2.hip); A: computed per k-tile from the patch row
+    int bofs[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bofs[g] = (wn * 64 + l31) * 128 + (((g * 2 + h) ^ ((l31 >> 1) & 7)) * 16);
+    const int rbase = 2 * wm * PW + l31;      // patch row of this lane's first output pixel at tap (0, 0)
+    auto mma_group = [&](const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1) {
+        acc[0][0] = Mma6<T>::run(a0, b0, acc[0][0]);
+        acc[0][1] = Mma6<T>::run(a0, b1, acc[0][1]);
+        acc[1][0] = Mma6<T>::run(a1, b0, acc[1][0]);
+        acc[1][1] = Mma6<T>::run(a1, b1, acc[1][1]);
+    };
+
+    // ---- epilogue operands requested ahead of their use (as igemm5)
+    const int er = lane >> 3, ec = lane & 7;
+    const T* __restrict__ bias = (const T*)p.bias;
+    const T* __restrict__ rowadd = (const T*)p.rowadd;
+    constexpr bool has_res = RES;
+    const bool has_ra = rowadd != nullptr, stats = p.gn_partial != nullptr;
+    Vec16<T> pre_res[4], pre_bias, pre_ra;
+    T col_bias[2], col_ra[2];
+    long c_orow = 0, c_rrow = 0;              // element offsets of output / residual pixel (image row 2 wm of the tile, column er) at this lane's chunk
+    int c_n0 = 0, c_img = 0, c_mt = 0, c_ncl = 0;
+    bool c_colok = false;
+    const int npre = has_res ? 4 + (bias ? 1 : 0) + (has_ra ? 1 : 0) : 2 * ((bias ? 1 : 0) + (has_ra ? 1 : 0));
+    bool nxt = false;
+    // rows of a wave's 64-row block: r -> image row r >> 5, column r & 31
+    auto rofs = [&](const int r) -> long { return (long)(r & 31) + (long)(r >> 5) * W; };
+
+    auto enter_tile = [&]() {   // the MFMA side enters the tile the loader is on; then the loader's coordinates move to the workgroup's next tile
+        c_n0 = d_n0; c_img = d_img; c_mt = d_mt;
+        c_colok = c_n0 + wn * 64 + ec * 8 < p.N;
+        c_ncl = c_colok ? c_n0 + wn * 64 + ec * 8 : c_n0;
+        const long px0 = ((long)d_img * H + d_oy0 + 2 * wm) * W + d_ox0 + er;
+        c_orow = px0 * p.ldo + c_ncl;
+        c_rrow = px0 * p.ldr + c_ncl;
+        nxt = u_dma + nslots < cend;
+        if (nxt) tile_coords(u_dma + nslots);
+    };
+
+    // one k-tile = (chunk c, tap t).  CK: 1 first chunk of a tile (t = 0 multiplies into the constant 0 and carries the tile-entry arithmetic),
+    // 2 last chunk (t = 0: the A state moves to the workgroup's next tile — this chunk's pieces are that tile's first patch; t = 7: epilogue
+    // operands requested, then the B state moves on; t = 8: last k-tile), 0 otherwise.  Every k-tile issues three pieces: B of k-tile + 2 (two),
+    // one piece of the next patch.  The synchronisation that opens the next k-tile sits in front of the last two MFMA groups (igemm5.hip).
+    auto ktile = [&](auto tc, auto ckc, const int c) {
+        constexpr int t = decltype(tc)::value, CK = decltype(ckc)::value;
+        constexpr int TS = (t / 3) * PW + (t % 3);
+        unsigned kofs;                         // byte offset in a weight row of k-tile + 2 (uniform)
+        if constexpr (t < 7) kofs = (unsigned)((t + 2) * p.cin + c * 64) * (unsigned)sizeof(T);
+        else if constexpr (CK == 2) kofs = (unsigned)((t - 7) * p.cin) * (unsigned)sizeof(T);
+        else kofs = (unsigned)((t - 7) * p.cin + (c + 1) * 64) * (unsigned)sizeof(T);
+        const int pr0 = rbase + TS, pr1 = pr0 + PW;
+        const int A0 = pcur + pr0 * 128 + ((((pr0 >> 1) & 7) ^ h) << 4);
+        const int A1 = pcur + pr1 * 128 + ((((pr1 >> 1) & 7) ^ h) << 4);
+        const int sb = bs_cur;
+        u32x4 a0[3], a1[3], b0[3], b1[3];
+        auto rd = [&](auto gc, auto slotc) {
+            constexpr int g = decltype(gc)::value, sl = decltype(slotc)::value;
+            a0[sl] = *reinterpret_cast<const u32x4*>(smem + (A0 ^ (g << 5)));
+            a1[sl] = *reinterpret_cast<const u32x4*>(smem + (A1 ^ (g << 5)));
+            b0[sl] = *reinterpret_cast<const u32x4*>(smem + sb + bofs[g]);
+            b1[sl] = *reinterpret_cast<const u32x4*>(smem + sb + bofs[g] + 32 * 128);
+        };
+        rd(IC6<0>{}, IC6<0>{});
+        rd(IC6<1>{}, IC6<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        rd(IC6<2>{}, IC6<2>{});
+        if constexpr (!(CK == 2 && t == 7)) fire_b(bs_dst, kofs);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (CK == 1 && t == 0) {
+            const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[0][0] = Mma6<T>::run(a0[0], b0[0], z);
+            acc[0][1] = Mma6<T>::run(a0[0], b1[0], z);
+            acc[1][0] = Mma6<T>::run(a1[0], b0[0], z);
+            acc[1][1] = Mma6<T>::run(a1[0], b1[0], z);
+        } else {
+            mma_group(a0[0], a1[0], b0[0], b1[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (CK == 1 && t == 0) enter_tile();
+        if constexpr (t == 0) {
+            if constexpr (CK == 2) { set_a(nxt); set_chunk(0); }
+            else set_chunk(c + 1);
+        }
+        if constexpr (CK == 2 && t == 7) {
+            // every lane requests (columns beyond N read the tile's first chunk instead: the count of VMEM instructions must not depend on exec)
+            if (has_res) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) pre_res[s] = ld16((const T*)p.residual + c_rrow + (long)(s * 8) * p.ldr);
+                if (bias) pre_bias = ld16(bias + c_ncl);
+                if (has_ra) pre_ra = ld16(rowadd + (long)c_img * p.N + c_ncl);
+            } else {
+                const int cA = c_n0 + wn * 64 + l31, cB = cA + 32;
+                const int nA = cA < p.N ? cA : c_n0, nB = cB < p.N ? cB : c_n0;
+                if (bias) { col_bias[0] = bias[nA]; col_bias[1] = bias[nB]; }
+                if (has_ra) { col_ra[0] = rowadd[(long)c_img * p.N + nA]; col_ra[1] = rowadd[(long)c_img * p.N + nB]; }
+            }
+            u_dma += nslots;
+            set_b(nxt);
+            if (!nxt) dma_done = true;
+            __builtin_amdgcn_sched_barrier(0);
+            fire_b(bs_dst, kofs);
+        }
+        rd(IC6<3>{}, IC6<0>{});
+        fire_a(IC6<t>{}, pnext);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(a0[1], a1[1], b0[1], b1[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // lgkmcnt(0): this wave's reads of the current stage have RETURNED before the barrier lets others overwrite it
+        if constexpr (CK == 2 && t == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if constexpr (CK == 2 && t == 7) {
+            if (npre == 0) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            else if (npre == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else if (npre == 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+            else if (npre == 4) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+            else if (npre == 5) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(a0[2], a1[2], b0[2], b1[2]);
+        mma_group(a0[0], a1[0], b0[0], b1[0]);
+        asm volatile("" ::: "memory");
+        { const int x = bs_cur; bs_cur = bs_nxt; bs_nxt = bs_dst; bs_dst = x; }
+        if constexpr (t == 8) { const int x = pcur; pcur = pnext; pnext = x; }
+    };
+    auto chunk = [&](auto ckc, const int c) {
+        ktile(IC6<0>{}, ckc, c); ktile(IC6<1>{}, ckc, c); ktile(IC6<2>{}, ckc, c);
+        ktile(IC6<3>{}, ckc, c); ktile(IC6<4>{}, ckc, c); ktile(IC6<5>{}, ckc, c);
+        ktile(IC6<6>{}, ckc, c); ktile(IC6<7>{}, ckc, c); ktile(IC6<8>{}, ckc, c);
+    };
+
+    // ---- epilogues: igemm5.hip's, with the 8 x 32 row mapping (rofs).  Packed (no residual): rounds of 16 rows = half an image row.
+    auto epilogue_packed = [&](const int sfree) {
+        unsigned* win = reinterpret_cast<unsigned*>(smem + sfree + wave * 4096);
+        const float al = p.alpha;
+        T* __restrict__ out = (T*)p.out;
+        const f2 al2 = {al, al};
+        f2 bva[2], rav[2], pv[2], sm[2], sq[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bj = bias ? to_f(col_bias[j]) * al : 0.f, rj = has_ra ? to_f(col_ra[j]) : 0.f;
+            bva[j] = f2{bj, bj}; rav[j] = f2{rj, rj};
+            pv[j] = f2{0.f, 0.f}; sm[j] = f2{0.f, 0.f}; sq[j] = f2{0.f, 0.f};
+        }
+        const int wofs = ((l31 >> 2) & 1) * 256 + h * 64 + (l31 >> 3) * 4 + (l31 & 3);
+        auto wr = [&](auto rc_) {
+            constexpr int r = decltype(rc_)::value, i = r >> 1;
+            unsigned* wb = win + (r & 1) * 512 + wofs;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * (r & 1) + qq;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        f2 x = {acc[i][j][4 * q + 2 * t], acc[i][j][4 * q + 2 * t + 1]};
+                        x = __builtin_elementwise_fma(x, al2, bva[j]);
+                        if (has_ra) x = __builtin_elementwise_fma(rav[j], al2, x);
+                        if (stats) {
+                            if (r == 0 && qq == 0 && t == 0) {
+                                const float p0 = __shfl(x[0], l31, 64);
+                                pv[j] = f2{p0, p0};
+                            }
+                            const f2 d = x - pv[j];
+                            sm[j] += d;
+                            sq[j] = __builtin_elementwise_fma(d, d, sq[j]);
+                        }
+                        T e2[2] = {from_f<T>(x[0]), from_f<T>(x[1])};
+                        unsigned u;
+                        __builtin_memcpy(&u, e2, 4);
+                        wb[qq * 128 + t * 32 + j * 16] = u;
+                    }
+            }
+        };
+        const int rp8 = lane >> 3;
+        auto round = [&](auto rc_) {
+            constexpr int r = decltype(rc_)::value;
+            if constexpr (r < 3) wr(IC6<r + 1>{});
+            if constexpr (r == 2) __builtin_amdgcn_s_waitcnt(0x0F70);   // the next tile's first patch and first two weight stages have landed
+            const unsigned* rb = win + (r & 1) * 512 + lane * 4;
+            const u32x4 t0 = *reinterpret_cast<const u32x4*>(rb);
+            const u32x4 t1 = *reinterpret_cast<const u32x4*>(rb + 256);
+            u32x4 lo, hi;
+            lo[0] = __builtin_amdgcn_perm(t0[1], t0[0], 0x05040100u); hi[0] = __builtin_amdgcn_perm(t0[1], t0[0], 0x07060302u);
+            lo[1] = __builtin_amdgcn_perm(t0[3], t0[2], 0x05040100u); hi[1] = __builtin_amdgcn_perm(t0[3], t0[2], 0x07060302u);
+            lo[2] = __builtin_amdgcn_perm(t1[1], t1[0], 0x05040100u); hi[2] = __builtin_amdgcn_perm(t1[1], t1[0], 0x07060302u);
+            lo[3] = __builtin_amdgcn_perm(t1[3], t1[2], 0x05040100u); hi[3] = __builtin_amdgcn_perm(t1[3], t1[2], 0x07060302u);
+            if (c_colok) {
+                // c_orow is column `rp8` of image row 2 wm: rows 16 r + 2 rp8, + 1 of the wave's block = image row r >> 1, columns 16 (r & 1) + 2 rp8, + 1
+                T* o = out + c_orow + ((long)(16 * (r & 1) + rp8) + (long)(r >> 1) * W) * p.ldo;
+                *reinterpret_cast<u32x4*>(o) = lo;
+                *reinterpret_cast<u32x4*>(o + p.ldo) = hi;
+            }
+        };
+        wr(IC6<0>{});
+        round(IC6<0>{}); round(IC6<1>{}); round(IC6<2>{}); round(IC6<3>{});
+        if (stats) {
+            float* dep = reinterpret_cast<float*>(smem + OFF_DEP);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float su = sm[j][0] + sm[j][1], s2 = sq[j][0] + sq[j][1];
+                su += __shfl_xor(su, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (h == 0) {
+                    float* d3 = dep + (wave * 64 + 32 * j + l31) * 3;
+                    d3[0] = su; d3[1] = s2; d3[2] = pv[j][0];
+                }
+            }
+        }
+    };
+
+    auto epilogue = [&](const int sfree) {
+        float* win = reinterpret_cast<float*>(smem + sfree + wave * 4096);
+        const int wofs = ((l31 >> 2) & 1) * 256 + h * 128 + (l31 >> 3) * 4 + (l31 & 3);
+        const float al = p.alpha;
+        T* __restrict__ out = (T*)p.out;
+        const T* __restrict__ res = (const T*)p.residual;
+        f2 bva2[4], ra2[4], pv2[4], sm2[4], sq2[4];
+        const f2 al2 = {al, al};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bva2[q] = bias ? f2{to_f(pre_bias.e[2 * q]) * al, to_f(pre_bias.e[2 * q + 1]) * al} : f2{0.f, 0.f};
+            ra2[q] = has_ra ? f2{to_f(pre_ra.e[2 * q]), to_f(pre_ra.e[2 * q + 1])} : f2{0.f, 0.f};
+            pv2[q] = f2{0.f, 0.f}; sm2[q] = f2{0.f, 0.f}; sq2[q] = f2{0.f, 0.f};
+        }
+        auto wr = [&](auto sc_) {
+            constexpr int s = decltype(sc_)::value, i = s >> 2, q = s & 3;
+            float* wb = win + (s & 1) * 512 + wofs;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wb[e * 32 + j * 16] = acc[i][j][4 * q + e];
+        };
+        Vec16<T> late_res[4];
+        auto slice = [&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            if constexpr (s == 0) {
+                if (has_res) {   // slices 4-7 = the tile's second image row of this wave
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) late_res[t] = ld16(res + c_rrow + ((long)(t * 8) + W) * p.ldr);
+                }
+            }
+            if constexpr (s < 7) wr(IC6<s + 1>{});
+            if constexpr (s == 4) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+            const float* rb = win + (s & 1) * 512 + lane * 4;
+            const floatx4 t0 = *reinterpret_cast<const floatx4*>(rb);
+            const floatx4 t1 = *reinterpret_cast<const floatx4*>(rb + 256);
+            f2 x2[4] = {f2{t0[0], t0[1]}, f2{t0[2], t0[3]}, f2{t1[0], t1[1]}, f2{t1[2], t1[3]}};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x2[q] = __builtin_elementwise_fma(x2[q], al2, bva2[q]);
+            if (has_ra) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x2[q] = __builtin_elementwise_fma(ra2[q], al2, x2[q]);
+            }
+            if (has_res) {
+                const Vec16<T>& rv = s < 4 ? pre_res[s & 3] : late_res[s & 3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x2[q] += f2{to_f(rv.e[2 * q]), to_f(rv.e[2 * q + 1])};
+            }
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = from_f<T>(x2[e >> 1][e & 1]);
+            if (c_colok) st16(out + c_orow + rofs(s * 8) * p.ldo, o);
+            if (stats) {
+                if constexpr (s == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pv2[q] = f2{__shfl(x2[q][0], ec, 64), __shfl(x2[q][1], ec, 64)};
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f2 d = x2[q] - pv2[q];
+                    sm2[q] += d;
+                    sq2[q] = __builtin_elementwise_fma(d, d, sq2[q]);
+                }
+            }
+        };
+        wr(IC6<0>{});
+        slice(IC6<0>{}); slice(IC6<1>{}); slice(IC6<2>{}); slice(IC6<3>{});
+        slice(IC6<4>{}); slice(IC6<5>{}); slice(IC6<6>{}); slice(IC6<7>{});
+        if (stats) {   // reduce-scatter over the 8 row-lanes of a chunk (igemm5.hip)
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[2 * q] = sm2[q][0]; v[2 * q + 1] = sm2[q][1]; v[8 + 2 * q] = sq2[q][0]; v[8 + 2 * q + 1] = sq2[q][1]; }
+            const bool b0 = (er & 1) != 0, b1 = (er & 2) != 0, b2 = (er & 4) != 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float keep = b0 ? v[k + 8] : v[k], send = b0 ? v[k] : v[k + 8];
+                v[k] = keep + __shfl_xor(send, 8, 64);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float keep = b1 ? v[k + 4] : v[k], send = b1 ? v[k] : v[k + 4];
+                v[k] = keep + __shfl_xor(send, 16, 64);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float keep = b2 ? v[k + 2] : v[k], send = b2 ? v[k] : v[k + 2];
+                v[k] = keep + __shfl_xor(send, 32, 64);
+            }
+            const int e0 = ((er >> 1) & 1) * 4 + (er >> 2) * 2;
+            float pva[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pva[e] = pv2[e >> 1][e & 1];
+            const float pe0 = b1 ? (b2 ? pva[6] : pva[4]) : (b2 ? pva[2] : pva[0]);
+            const float pe1 = b1 ? (b2 ? pva[7] : pva[5]) : (b2 ? pva[3] : pva[1]);
+            float* d3 = reinterpret_cast<float*>(smem + OFF_DEP) + (wave * 64 + ec * 8 + e0) * 3;
+            d3[(int)b0] = v[0];
+            d3[3 + (int)b0] = v[1];
+            if (!b0) { d3[2] = pe0; d3[5] = pe1; }
+        }
+    };
+    auto combine = [&](const int mt, const int n0) {   // merge of the four row-waves' deposits, one thread per column (igemm5.hip); slab = tile inside the image
+        if (tid < BN && n0 + tid < p.N) {
+            const float* dep = reinterpret_cast<const float*>(smem + OFF_DEP);
+            const int cw = tid >> 6, cc = tid & 63;
+            float mean = 0.f, m2 = 0.f, na = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                const float* d3 = dep + ((w4 * 2 + cw) * 64 + cc) * 3;
+                const float s1 = d3[0], s2 = d3[1], pv = d3[2];
+                const float mb = pv + s1 * (1.0f / 64.0f);
+                const float m2b = fmaxf(s2 - s1 * s1 * (1.0f / 64.0f), 0.f);
+                if (w4 == 0) { mean = mb; m2 = m2b; na = 64.f; }
+                else {
+                    const float nt = na + 64.f, dl = mb - mean;
+                    mean += dl * (64.f / nt);
+                    m2 += m2b + dl * dl * (na * 64.f / nt);
+                    na = nt;
+                }
+            }
+            const int img = mt / tpi;
+            const int slab = mt - img * tpi;
+            float* o = p.gn_partial + (((long)img * p.gn_nslabs + slab) * p.N + n0 + tid) * 3;
+            o[0] = na; o[1] = mean; o[2] = m2;
+        }
+    };
+
+    // ================================ main ==========================================================================
+    tile_coords(u_dma);
+    set_a(true);
+    set_b(true);
+    set_chunk(0);
+    fire_a(IC6<0>{}, pcur); fire_a(IC6<1>{}, pcur); fire_a(IC6<2>{}, pcur);
+    fire_a(IC6<3>{}, pcur); fire_a(IC6<4>{}, pcur); fire_a(IC6<5>{}, pcur);
+    fire_b(bs_cur, 0u);
+    fire_b(bs_nxt, (unsigned)p.cin * (unsigned)sizeof(T));
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // the first patch and k-tile 0's weights
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (;;) {
+        chunk(IC6<1>{}, 0);
+        for (int c = 1; c < nch - 1; ++c) chunk(IC6<0>{}, c);
+        chunk(IC6<2>{}, nch - 1);
+        // the patch buffer of the last chunk (pnext after the swap) is scratch until the next tile's second patch is requested
+        if constexpr (RES) epilogue(pnext);
+        else epilogue_packed(pnext);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // statistics deposits written; every slice window read
+        __builtin_amdgcn_s_barrier();                        // opens k-tile 0 of the next tile
+        asm volatile("" ::: "memory");
+        if (stats) combine(c_mt, c_n0);
+        if (dma_done) break;
+    }
+}
+
+static std::atomic<long> g_patch_launches{0};
+
+int device_cus();   // api.hip
+
+template <typename T> static int launch6(IgemmParams& p, int total, int grid, hipStream_t s) {
+    if (p.residual) hipLaunchKernelGGL((igemm6_kernel<T, true>), dim3(grid), dim3(512), 0, s, p, total);
+    else hipLaunchKernelGGL((igemm6_kernel<T, false>), dim3(grid), dim3(512), 0, s, p, total);
+    tag_kernel("igemm6_kernel<%s, %s>", std::is_same<T, f16>::value ? "_Float16" : "__bf16", p.residual ? "true" : "false");
+    return check_launch("igemm6");
+}
+
+int launch_igemm_patch(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s) {
+    using namespace patchk;
+    if (!option(E2EFT_OPT_PATCH_CONV) || !option(E2EFT_OPT_PERSISTENT)) return -1;
+    if (mode != 1 || nz != 1 || (dtype != E2EFT_F16 && dtype != E2EFT_BF16)) return -1;
+    if (p.ksplit_taps > 0 || p.bias_along_m) return -1;
+    if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.zins > 1) return -1;
+    if (p.hl != p.hin || p.wl != p.win || p.hout != p.hin || p.wout != p.win) return -1;
+    if (p.win % TW != 0 || p.hin % TH != 0) return -1;
+    if (p.cin % 64 != 0 || p.c1 % 64 != 0 || p.cin < 128 || p.K != 9 * p.cin) return -1;
+    if (p.N % 8 != 0 || p.ldo % 8 != 0 || (((uintptr_t)p.out) & 15) != 0) return -1;
+    if (p.ldx1 % 8 != 0 || (((uintptr_t)p.x1) & 15) != 0 || (p.x2 && (p.ldx2 % 8 != 0 || (((uintptr_t)p.x2) & 15) != 0))) return -1;
+    if (p.ldw % 8 != 0 || (((uintptr_t)p.w) & 15) != 0) return -1;
+    if (p.residual && (p.ldr % 8 != 0 || (((uintptr_t)p.residual) & 15) != 0)) return -1;
+    if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return -1;
+    if (p.rowadd && ((((uintptr_t)p.rowadd) & 15) != 0 || p.rows_per_img != p.hin * p.win)) return -1;
+    const long img_bytes = (long)p.hin * p.win * (p.ldx1 > p.ldx2 ? p.ldx1 : p.ldx2) * 2;
+    if (img_bytes >= 0xD0000000L || (long)128 * p.ldw * 2 >= 0x40000000L) return -1;
+    if (p.M % (p.hin * p.win) != 0) return -1;
+    int cus = device_cus();
+    if (cus == 0) return -1;
+    const int gopt = option(E2EFT_OPT_PERSISTENT_GRID);
+    if (gopt >= 8 && gopt < cus) cus = gopt;
+    const int mtiles = p.M / BM, ntiles = cdiv(p.N, BN);
+    const long total = (long)mtiles * ntiles;
+    if (total < 2L * cus || total > 2000000000L || mtiles >= (1 << 22)) return -1;
+    if (p.gn_partial) {
+        if (p.rows_per_img != p.hin * p.win) return -1;
+        p.gn_nslabs = p.rows_per_img / BM;
+    }
+    p.mtiles = mtiles;
+    p.ntiles = ntiles;
+    g_patch_launches.fetch_add(1, std::memory_order_relaxed);
+    return dtype == E2EFT_F16 ? launch6<f16>(p, (int)total, cus, s) : launch6<bf16>(p, (int)total, cus, s);
+}
+
+}  // namespace e2eft
+
+extern "C" long e2eft_debug_patch_launches(void) { return e2eft::g_patch_launches.load(); }   // not part of include/e2eft.h
