@@ -359,5 +359,7 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, char* 
 int launch_igemm_v2(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 // igemm5.hip: persistent workgroups walking a tile sequence (16-bit FAST path, M % 256 == 0, >= 2 tiles per CU); -1 when not eligible
 int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
+// igemm6.hip: persistent, the A operand of a 3x3 / stride-1 / pad-1 convolution as a 2-D halo patch in LDS; -1 when not eligible
+int launch_igemm_patch(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 
 }  // namespace e2eft

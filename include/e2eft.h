@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define E2EFT_VERSION 112 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
+#define E2EFT_VERSION 113 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
 
 enum {
     E2EFT_OK = 0,
@@ -57,7 +57,8 @@ enum {
     E2EFT_OPT_NARROW_MFMA = 3,       /* 1 (default): MFMA 16x16x32 form of that kernel; 0: v_dot2 form */
     E2EFT_OPT_IGEMM_GENERAL_OPERANDS = 4, /* 0 (default); 1: igemm2 takes its general (per-lane gather) operand path for every launch */
     E2EFT_OPT_IGEMM2_WAVES = 5,      /* 0 (default): 8-wave 256-row tiles when >= 256 of them exist, else 4-wave 128-row; 4 / 8: forced */
-    E2EFT_OPT_COUNT = 6
+    E2EFT_OPT_PATCH_CONV = 6,        /* 1 (default): big 16-bit 3x3 / stride-1 / pad-1 convolutions on the halo-patch kernel (igemm6); 0: igemm5 */
+    E2EFT_OPT_COUNT = 7
 };
 int e2eft_set_option(int32_t key, int32_t value);
 int e2eft_get_option(int32_t key);

@@ -62,4 +62,6 @@ def dev():
         _lib.set_option(_lib.OPT_PERSISTENT_GRID, int(os.environ["E2EFT_TEST_PERSISTENT_GRID"]))
     if "E2EFT_TEST_PERSISTENT" in os.environ:
         _lib.set_option(_lib.OPT_PERSISTENT, int(os.environ["E2EFT_TEST_PERSISTENT"]))
+    if "E2EFT_TEST_PATCH_CONV" in os.environ:
+        _lib.set_option(_lib.OPT_PATCH_CONV, int(os.environ["E2EFT_TEST_PATCH_CONV"]))
     return torch.device("cuda:0")

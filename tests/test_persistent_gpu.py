@@ -26,6 +26,7 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 _lib.set_option(_lib.OPT_PERSISTENT_GRID, int(os.environ.get("TEST_PERSISTENT_GRID", "0")))
 _lib.set_option(_lib.OPT_PERSISTENT, int(os.environ.get("TEST_PERSISTENT", "1")))
+_lib.set_option(_lib.OPT_PATCH_CONV, 0)      # this file is about igemm5: the halo-patch kernel (tests/test_patch_conv_gpu.py) would take the 3x3 cases
 lib.e2eft_debug_persistent_launches.restype = ctypes.c_long
 EXPECT = int(os.environ.get("EXPECT_PERSISTENT", "1"))
 def launches():
