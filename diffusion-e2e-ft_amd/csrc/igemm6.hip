@@ -20,9 +20,10 @@
 //     multiply-adds;
 //   * tile-entry arithmetic, epilogue operand prefetch, barrier placement, both epilogues (fp32 sliced with a residual, packed without),
 //     GroupNorm statistics: as igemm5.hip, with rows of the tile mapped to the 8 x 32 block (a wave's 64 rows = two image rows).
-// Eligibility (host, launch_igemm_patch returns -1 and the caller falls through to igemm5): conv mode, 3x3, stride 1, pad 1, no fused
-// upsample / zero insertion, width a multiple of 32, height of 8, channels (each concat part) multiples of 64 and at least 128, the
-// vector epilogue, at least two tiles per workgroup.  e2eft_set_option(E2EFT_OPT_PATCH_CONV, 0) disables it.
+// Eligibility (host, launch_igemm_patch returns -1 and the caller falls through to igemm5): conv mode, 3x3, stride 1, pad 1, plain or with
+// the exact 2x nearest upsample fused into the read (the patch is built in the upsampled geometry), no zero insertion, width a multiple
+// of 32, height of 8, channels (each concat part) multiples of 64 and at least 128, the vector epilogue, at least two tiles per
+// workgroup.  e2eft_set_option(E2EFT_OPT_PATCH_CONV, 0) disables it.
 // Summation order: per output element k runs (chunk, tap) instead of (tap, chunk) — fp32 accumulation, results differ from igemm5 in the
 // last bits (documented in include/e2eft.h; deterministic run to run).
 #include "igemm.h"
@@ -81,7 +82,9 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
     const int nch = p.cin >> 6;              // 64-channel chunks, host: >= 2
-    const int H = p.hin, W = p.win;
+    const int H = p.hl, W = p.wl;            // the convolution's (logical) input = output size; with the fused 2x nearest upsample the source is hin x win = H/2 x W/2
+    const int Hs = p.hin, Ws = p.win;
+    const bool up2 = p.hl != p.hin;
     const int tw = W / TW, tpi = (H / TH) * tw;   // tiles per image row / per image
 
     // ---- tile sequence of this workgroup: as igemm5 (eight contiguous chunks of the tile range, one per XCD)
@@ -126,10 +129,10 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         for (int i = 0; i < 6; ++i) {
             const int iy = d_oy0 - 1 + (pyx[i] >> 16), ix = d_ox0 - 1 + (pyx[i] & 0xffff);
             const bool ok = valid && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            pix[i] = ok ? iy * W + ix : -1;
+            pix[i] = !ok ? -1 : up2 ? (iy >> 1) * Ws + (ix >> 1) : iy * W + ix;   // (fused upsample: four patch rows fetch the same source pixel — L2 hits)
         }
-        const T* b1 = (const T*)p.x1 + (long)d_img * H * W * p.ldx1;
-        const T* b2 = p.x2 ? (const T*)p.x2 + (long)d_img * H * W * p.ldx2 : b1;
+        const T* b1 = (const T*)p.x1 + (long)d_img * Hs * Ws * p.ldx1;
+        const T* b2 = p.x2 ? (const T*)p.x2 + (long)d_img * Hs * Ws * p.ldx2 : b1;
         rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, RECORDS, 0x00020000);
         rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)b2, 0, RECORDS, 0x00020000);
     };
@@ -548,18 +551,19 @@ int launch_igemm_patch(int dtype, int mode, IgemmParams& p, int nz, hipStream_t 
     if (mode != 1 || nz != 1 || (dtype != E2EFT_F16 && dtype != E2EFT_BF16)) return -1;
     if (p.ksplit_taps > 0 || p.bias_along_m) return -1;
     if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.zins > 1) return -1;
-    if (p.hl != p.hin || p.wl != p.win || p.hout != p.hin || p.wout != p.win) return -1;
-    if (p.win % TW != 0 || p.hin % TH != 0) return -1;
+    const bool same = p.hl == p.hin && p.wl == p.win, up2 = p.hl == 2 * p.hin && p.wl == 2 * p.win;   // plain, or the exact 2x nearest upsample fused into the read
+    if (!(same || up2) || p.hout != p.hl || p.wout != p.wl) return -1;
+    if (p.wl % TW != 0 || p.hl % TH != 0) return -1;
     if (p.cin % 64 != 0 || p.c1 % 64 != 0 || p.cin < 128 || p.K != 9 * p.cin) return -1;
     if (p.N % 8 != 0 || p.ldo % 8 != 0 || (((uintptr_t)p.out) & 15) != 0) return -1;
     if (p.ldx1 % 8 != 0 || (((uintptr_t)p.x1) & 15) != 0 || (p.x2 && (p.ldx2 % 8 != 0 || (((uintptr_t)p.x2) & 15) != 0))) return -1;
     if (p.ldw % 8 != 0 || (((uintptr_t)p.w) & 15) != 0) return -1;
     if (p.residual && (p.ldr % 8 != 0 || (((uintptr_t)p.residual) & 15) != 0)) return -1;
     if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return -1;
-    if (p.rowadd && ((((uintptr_t)p.rowadd) & 15) != 0 || p.rows_per_img != p.hin * p.win)) return -1;
+    if (p.rowadd && ((((uintptr_t)p.rowadd) & 15) != 0 || p.rows_per_img != p.hl * p.wl)) return -1;
     const long img_bytes = (long)p.hin * p.win * (p.ldx1 > p.ldx2 ? p.ldx1 : p.ldx2) * 2;
     if (img_bytes >= 0xD0000000L || (long)128 * p.ldw * 2 >= 0x40000000L) return -1;
-    if (p.M % (p.hin * p.win) != 0) return -1;
+    if (p.M % (p.hl * p.wl) != 0) return -1;
     int cus = device_cus();
     if (cus == 0) return -1;
     const int gopt = option(E2EFT_OPT_PERSISTENT_GRID);
@@ -568,7 +572,7 @@ int launch_igemm_patch(int dtype, int mode, IgemmParams& p, int nz, hipStream_t 
     const long total = (long)mtiles * ntiles;
     if (total < 2L * cus || total > 2000000000L || mtiles >= (1 << 22)) return -1;
     if (p.gn_partial) {
-        if (p.rows_per_img != p.hin * p.win) return -1;
+        if (p.rows_per_img != p.hl * p.wl) return -1;
         p.gn_nslabs = p.rows_per_img / BM;
     }
     p.mtiles = mtiles;

@@ -31,8 +31,12 @@ EXPECT = int(os.environ.get("TEST_PATCH_CONV", "1"))
 def launches():
     return lib.e2eft_debug_patch_launches()
 worst = 0.0
-# B, H, W, C1, C2, Co, rowadd, residual, alpha, eligible
+# B, H, W, C1, C2, Co, rowadd, residual, alpha, eligible[, fused nearest upsample to]
 cases = [
+    (2, 16, 32, 128, 0, 128, False, False, 1.0, True, (32, 64)),   # fused 2x upsample, 16 tiles
+    (1, 32, 32, 192, 0, 256, True, True, 1.0, True, (64, 64)),     # fused 2x upsample, 3 chunks, 16 x 2 tiles, rowadd + residual
+    (2, 16, 32, 128, 0, 128, False, False, 1.0, False, (48, 96)),  # 3x upsample: not eligible
+
     (2, 32, 64, 128, 0, 128, False, False, 1.0, True),     # 16 tiles, 2 chunks
     (1, 64, 64, 192, 0, 128, True, True, 0.7, True),       # 16 tiles, 3 chunks, rowadd + residual + alpha
     (1, 96, 96, 64, 64, 320, False, True, 1.0, True),      # 36 x 3 tiles (108 = 8 * 13 + 4), ragged last N tile, concat switch on the chunk boundary
@@ -46,13 +50,16 @@ cases = [
     (2, 32, 64, 64, 0, 128, False, False, 1.0, False),     # one chunk: not eligible
 ]
 for dtype in (torch.float16, torch.bfloat16):
-    for (B, H, W, C1, C2, Co, ra, rs, alpha, elig) in cases:
+    for case in cases:
+        (B, H, W, C1, C2, Co, ra, rs, alpha, elig), up = case[:10], (case[10] if len(case) > 10 else None)
         g = torch.Generator().manual_seed(B * 1000 + H * 10 + C1 + Co + W)
         x = q(torch.randn(B, C1, H, W, generator=g), dtype)
         x2 = q(torch.randn(B, C2, H, W, generator=g), dtype) if C2 else None
         w = q(torch.randn(Co, C1 + C2, 3, 3, generator=g) / ((C1 + C2) * 9) ** 0.5, dtype)
         b = q(torch.randn(Co, generator=g), dtype)
         xin = x if x2 is None else torch.cat([x, x2], dim=1)
+        if up is not None:
+            xin = F.interpolate(xin, size=up, mode="nearest")
         ref = F.conv2d(xin.double(), w.double(), b.double(), stride=1, padding=1).float()
         rav = q(torch.randn(B, Co, generator=g), dtype) if ra else None
         rsv = q(torch.randn(ref.shape, generator=g), dtype) if rs else None
@@ -63,14 +70,14 @@ for dtype in (torch.float16, torch.bfloat16):
             ref = ref + rsv
         n0 = launches()
         out = ops.conv2d(nhwc(x, dtype, dev), pack_conv_weight(w, dtype, dev), b.to(dtype).to(dev), Co, 3, 3, 1, (1, 1, 1, 1),
-                         x2=None if x2 is None else nhwc(x2, dtype, dev), rowadd=None if rav is None else rav.to(dtype).to(dev),
+                         x2=None if x2 is None else nhwc(x2, dtype, dev), up_to=up, rowadd=None if rav is None else rav.to(dtype).to(dev),
                          residual=None if rsv is None else nhwc(rsv, dtype, dev), alpha=alpha)
         torch.cuda.synchronize()
         took = launches() - n0
-        tiles = (B * H * W // 256) * ((Co + 127) // 128)
+        tiles = (ref.shape[0] * ref.shape[2] * ref.shape[3] // 256) * ((Co + 127) // 128)
         e = rel_err(to_nchw(out), ref)
         ok = e <= TOL[dtype] and bool(torch.isfinite(out.float()).all())
-        print("%%s conv %%s rel err %%.2e patch=%%d tiles=%%d %%s" %% (str(dtype)[6:], (B, H, W, C1, C2, Co), e, took, tiles, "ok" if ok else "FAIL"), flush=True)
+        print("%%s conv %%s rel err %%.2e patch=%%d tiles=%%d %%s" %% (str(dtype)[6:], (B, H, W, C1, C2, Co, up), e, took, tiles, "ok" if ok else "FAIL"), flush=True)
         worst = max(worst, e / TOL[dtype])
         assert ok
         assert took == (1 if (EXPECT and elig and tiles >= 16) else 0), (took, tiles)
