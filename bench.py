@@ -440,25 +440,40 @@ def by_symbol(timer, steps):
                     tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0) for k, v in sorted(out.items(), key=lambda kv: -kv[1]["ms"])}
 
 
-def pmc_traffic(launches_per_step, want):
+def kernel_mix(symbols):
+    """launches per step of each kernel of the igemm family ({'igemm6_kernel': 69.0, ...}) from by_symbol()'s rows"""
+    mix = {}
+    for sym, v in symbols.items():
+        k = sym.split("<")[0]
+        k = "conv3x3_narrow" if k.startswith("conv3x3_narrow") else k
+        mix[k] = mix.get(k, 0.0) + v["launches_per_step"]
+    return mix
+
+
+def pmc_traffic(mix, want):
     """HBM bytes per launch of the dominant family from the PMC counters.  rocprofv3 --pmc cannot wrap its own process, so the counters are
-    collected offline on exactly this workload (scripts/pmc_traffic.py) and committed with the build's launch count; the figure is printed
-    only when that count equals this run's (same kernel population), else null."""
+    collected offline on exactly this workload (scripts/pmc_traffic.py) and committed with the build's launch counts PER KERNEL of the
+    family; the figure is printed only when every one of those counts equals this run's (same kernel population), else null."""
     prof = os.path.join(ROOT, "profiles")
     files = sorted((f for f in os.listdir(prof) if f.endswith("_pmc_hbm_traffic.json")), reverse=True) if os.path.isdir(prof) else []
     if not want:
         return None, None, "no PMC profile for this workload", {}
     seen = []
+    names = {"igemm6_kernel": "igemm6", "igemm5_kernel": "igemm5", "igemm2_kernel": "igemm2", "conv3x3_narrow": "conv3x3_narrow"}
     for fn in files:
         with open(os.path.join(prof, fn)) as f:
             pj = json.load(f)
         k = pj["kernels"].get("igemm")
-        lps = k.get("launches_per_step") if k else None
-        seen.append("%s: %s" % (fn, lps))
-        if lps is not None and abs(lps - launches_per_step) < 0.01:
+        if not k or k.get("launches_per_step") is None:
+            seen.append("%s: no launch counts" % fn)
+            continue
+        theirs = {kern: (pj["kernels"].get(grp) or {}).get("launches_per_step", 0.0) for kern, grp in names.items()}
+        ours = {kern: mix.get(kern, 0.0) for kern in names}
+        seen.append("%s: %s" % (fn, {kk: vv for kk, vv in theirs.items() if vv}))
+        if all(abs(theirs[kern] - ours[kern]) < 0.01 for kern in names) and abs(k["launches_per_step"] - sum(mix.values())) < 0.01:
             others = {g: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "launches_per_step": v.get("launches_per_step")} for g, v in pj["kernels"].items() if g != "igemm"}
-            return k["hbm_bytes_per_launch"], "static: profiles/%s (PMC pass of the same build: %s igemm launches per step there and here)" % (fn, lps), pj["source"], others
-    return None, None, "no committed PMC profile has this run's %.1f igemm launches per step (%s)" % (launches_per_step, "; ".join(seen[:4])), {}
+            return k["hbm_bytes_per_launch"], "static: profiles/%s (PMC pass of the same build: launches per step %s there and here)" % (fn, {kk: vv for kk, vv in theirs.items() if vv}), pj["source"], others
+    return None, None, "no committed PMC profile has this run's igemm launches per step %s (%s)" % ({kk: vv for kk, vv in mix.items() if vv}, "; ".join(seen[:3])), {}
 
 
 def latency_leg(pipe, dev, dtype, warm=5, iters=30):
@@ -587,7 +602,8 @@ def main():
         peak = PEAK_TF[args.dtype]
         lps = ig["launches"] / args.steps
         alg_bpl = ig["bytes"] / max(ig["launches"], 1)
-        traffic, traffic_source, traffic_note, pmc_other = pmc_traffic(lps, (B, R, args.dtype, args.tiny) == (8, 768, "fp16", False))
+        symbols = by_symbol(full, args.steps)
+        traffic, traffic_source, traffic_note, pmc_other = pmc_traffic(kernel_mix(symbols), (B, R, args.dtype, args.tiny) == (8, 768, "fp16", False))
         extra = {}
         for k in ("attn", "attn512", "groupnorm"):
             if k in fsum and fsum[k]["ms"] > 0:
@@ -613,7 +629,7 @@ def main():
                                    % (B, RH, RW, args.dtype, " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
                        "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world,
                        "launch_mode": "hipGraph replay (one captured graph per batch shape)" if args.graph else "host launches"},
-            "roofline": {"bound": "mfma", "kernel": "igemm5_kernel (persistent) + igemm2_kernel: implicit-GEMM conv/linear, all launches of the timed region",
+            "roofline": {"bound": "mfma", "kernel": "igemm6_kernel (persistent, halo-patch 3x3 conv) + igemm5_kernel (persistent) + igemm2_kernel: implicit-GEMM conv/linear, all launches of the timed region",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_over_algorithmic": (traffic / alg_bpl) if traffic else None,
                          "traffic_source": traffic_source, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg_bpl,
@@ -621,7 +637,7 @@ def main():
                          "algorithmic_gflop_per_step": ig["flops"] / args.steps / 1e9,
                          "instrumentation": "HIP events around the igemm launches only inside the timed region; `other_kernels` and `by_symbol` from %d extra, "
                                             "fully instrumented steps right after it" % args.steps,
-                         "by_symbol": by_symbol(full, args.steps), "other_kernels": extra},
+                         "by_symbol": symbols, "other_kernels": extra},
         }
         try:   # stage split ("also report UNet-only"), measured after the timed region
             st = pipe.stage_times_ms(rgb, repeats=3)
