@@ -94,6 +94,10 @@ typedef struct E2eftConvDesc {
     float alpha;
 } E2eftConvDesc;
 
+/* Results are deterministic run to run for a fixed option set (e2eft_set_option).  The fp32 summation order over k depends on the kernel the
+ * launch is routed to: tap-major (ky, kx, channel) on igemm2 / igemm5, 64-channel-chunk-major on igemm6 (E2EFT_OPT_PATCH_CONV; 16-bit 3x3 / stride-1 /
+ * pad-1 launches with >= 128 input channels, width % 32 == 0, height % 8 == 0 and at least two 256-pixel tiles per CU) — outputs of the two routes differ
+ * in the last bits of the 16-bit result. */
 int e2eft_conv2d_fwd(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w,
                      const void* bias /* [cout] or NULL */,
                      const void* rowadd /* [batch, cout] per-image vector (time embedding) or NULL */,
