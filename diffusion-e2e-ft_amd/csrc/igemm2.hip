@@ -492,9 +492,13 @@ template <typename T, int MODE, int NW> static int launch2(IgemmParams& p, int n
 
 template <typename T> static int launch2_t(int mode, IgemmParams& p, int nz, hipStream_t s) {
     const int forced_nw = option(E2EFT_OPT_IGEMM2_WAVES);
-    // two 128-row workgroups per CU fill the machine better on mid-size problems; 256-row tiles halve the weight traffic on big ones
+    // 256-row tiles (8 waves) halve the weight traffic and the per-tile fixed cost; 128-row tiles (4 waves, two workgroups per CU) only pay when the
+    // 256-row grid would leave most of the machine idle.  16-bit, measured with the variant forced (profiles/r03k_variant_sweep.txt): at 150-180 tiles
+    // of 256 rows (conv 1280->1280 @12^2 with split K, GEMM 4608 x 1280 x 1280 / x 5120, conv 1280->1280 / 2560->1280 @24^2) the 8-wave kernel is
+    // 9-23 % faster than twice as many 128-row workgroups, at 360 tiles the two are equal: the switch sits at half a round.
     const long blocks256 = (long)cdiv(p.M, 256) * cdiv(p.N, BN2) * nz;
-    const int nw = forced_nw ? forced_nw : (blocks256 < 256 ? 4 : 8);
+    const long switch_at = sizeof(T) == 4 ? 256 : 128;
+    const int nw = forced_nw ? forced_nw : (blocks256 < switch_at ? 4 : 8);
     if (nw == 4) return mode ? launch2<T, 1, 4>(p, nz, s) : launch2<T, 0, 4>(p, nz, s);
     return mode ? launch2<T, 1, 8>(p, nz, s) : launch2<T, 0, 8>(p, nz, s);
 }

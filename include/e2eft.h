@@ -56,7 +56,7 @@ enum {
     E2EFT_OPT_NARROW_CONV = 2,       /* 1 (default): <= 4-output-channel 3x3 convs on the LDS-halo kernel (narrow.hip); 0: MFMA tile */
     E2EFT_OPT_NARROW_MFMA = 3,       /* 1 (default): MFMA 16x16x32 form of that kernel; 0: v_dot2 form */
     E2EFT_OPT_IGEMM_GENERAL_OPERANDS = 4, /* 0 (default); 1: igemm2 takes its general (per-lane gather) operand path for every launch */
-    E2EFT_OPT_IGEMM2_WAVES = 5,      /* 0 (default): 8-wave 256-row tiles when >= 256 of them exist, else 4-wave 128-row; 4 / 8: forced */
+    E2EFT_OPT_IGEMM2_WAVES = 5,      /* 0 (default): 8-wave 256-row tiles when >= 128 of them exist (fp32: 256), else 4-wave 128-row; 4 / 8: forced */
     E2EFT_OPT_PATCH_CONV = 6,        /* 1 (default): big 16-bit 3x3 / stride-1 / pad-1 convolutions on the halo-patch kernel (igemm6); 0: igemm5 */
     E2EFT_OPT_COUNT = 7
 };
