@@ -9,13 +9,14 @@
 // fragments are produced by the transpose read ds_read_b64_tr_b16 (a lane of a 16-lane group supplies the address of 4 consecutive channels of one
 // pixel and receives 4 pixels of one channel): no transposed or im2col'ed tensor exists anywhere.
 //
-//   * workgroup = 128 output channels x 128 columns (two 64-channel chunks of (tap, ci) space: a chunk never straddles a tap or a concat source, so
+//   * workgroup = 128 output channels x 256 columns (four 64-channel chunks of (tap, ci) space: a chunk never straddles a tap or a concat source, so
 //     its rows are one shifted window of ONE input tensor) x a range of pixels (split-K over the grid's z: a weight gradient has a handful of output
-//     tiles and 10^4 - 10^5 pixels); 4 waves, 64 x 64 each, 2 workgroups per CU;
-//   * k-tile = 64 pixels: four [64 pixels][64 channels] panels (two of dY, two of X) of 8 KB, filled by LDS-DMA in 1-KiB pieces of 8 pixel rows
+//     tiles and 10^4 - 10^5 pixels); 8 waves, 64 x 64 each, one workgroup per CU;
+//   * k-tile = 64 pixels: six [64 pixels][64 channels] panels (two of dY, four of X) of 8 KB, filled by LDS-DMA in 1-KiB pieces of 8 pixel rows
 //     (`buffer_load ... lds`; the im2col shift, the zero padding, the stride and the split's end are the per-lane source offset — out of range reads
-//     zeros), two stages; 16-byte chunk c of pixel row r lands in slot c ^ (((r >> 1) & 1) << 2): the four rows of a transpose read then cover four
-//     different 64-byte bank windows (conflict-free), and the key is constant per lane;
+//     zeros), three stages: the pieces of k-tile t + 2 fly while k-tile t multiplies; 16-byte chunk c of pixel row r lands in slot
+//     c ^ (((r >> 1) & 1) << 2): the four rows of a transpose read then cover four different 64-byte bank windows (conflict-free), and the key is
+//     constant per lane;
 //   * partial sums leave as fp32 [split][Co][kh kw cin]; e2eft_colsum (the reduction the split-K NT path already used) adds the splits.
 // Eligibility is decided here (returns E2EFT_ERR_UNSUPPORTED and the caller keeps the transpose + im2col_t + GEMM path): 16-bit, cin and c1 multiples
 // of 64, no fused upsample, tensors below 4 GB.
@@ -25,10 +26,11 @@
 namespace e2eft {
 
 namespace wg {
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 256, BK = 64, NW = 8;
 constexpr int PANEL = 64 * 128;            // [64 pixels][64 channels] of 16-bit
-constexpr int STAGE = 4 * PANEL;           // dY panels 0, 1; X panels 0, 1
-constexpr int LDS = 2 * STAGE;             // 65536 B: two workgroups per CU
+constexpr int STAGE = 6 * PANEL;           // dY panels 0, 1; X panels 0 .. 3
+constexpr int NSTAGE = 3;
+constexpr int LDS = NSTAGE * STAGE;        // 147,456 B: one 8-wave workgroup per CU
 }  // namespace wg
 
 struct WgradParams {
@@ -60,7 +62,7 @@ __device__ __forceinline__ u32x2 tr_read_w(const char* p) {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4vw*)p));
 }
 // one LDS-DMA piece (64 lanes x 16 B -> 1 KiB at m0) from asm: the compiler must not count it (it would drain vmcnt in front of LDS reads it cannot
-// prove disjoint); the kernel waits for its own pieces once per k-tile.  m0 is saved and restored (compiler-reserved).
+// prove disjoint); the kernel counts its own pieces — six per wave and k-tile, always.  m0 is saved and restored (compiler-reserved).
 __device__ __forceinline__ void dma_piece_w(const __amdgpu_buffer_rsrc_t& rs, const unsigned voff, const unsigned lds_addr) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
@@ -74,31 +76,36 @@ __device__ __forceinline__ int fdiv_w(int n, int d) {   // float estimate + one 
     return q;
 }
 
-// grid (ceil(N / 128), ceil(M / 128), nsplit), 256 threads
+// grid (ceil(N / 256), ceil(M / 128), nsplit), 512 threads.  Round 3, second version: the first one (128 x 128 tiles, 4 waves, two stages, two
+// workgroups per CU) waited for k-tile t + 1 at the end of k-tile t — 16 MFMAs = 0.25 us of cover for a 1-2 us L2 round trip — and paid two float
+// divisions + 64-bit multiplies per piece: 340-670 TF/s, latency-bound.  Now: three stages (the pieces of k-tile t + 2 are in flight while t multiplies,
+// `vmcnt(6)` in front of the barrier is exact because every wave issues six pieces per k-tile, out-of-range ones fetch zeros), a lane's pixel is
+// carried incrementally (one division per k-tile), one 8-wave workgroup per CU with a 128 x 256 tile (weights of a chunk's four (tap, channel)
+// windows share the dY panels: 1.5 operand bytes per MFMA instead of 2).
 template <typename T>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
     using namespace wg;
     __shared__ __attribute__((aligned(16))) char smem[LDS];
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hh = lane >> 5;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int k_begin = blockIdx.z * p.kchunk, k_end = min(p.P, k_begin + p.kchunk);
     const unsigned OOB = 0xFFFFFFF0u;
 
-    // ---- the two 64-column chunks of this tile: (tap, first channel, source)
+    // ---- the four 64-column chunks of this tile: (tap, first channel, source).  A chunk never straddles a tap or a concat source.
     const int cpt = p.cin >> 6;                        // chunks per tap
-    int tap[2], ci0[2], ky[2], kx[2];
-    bool cok[2], src2[2];
+    int ci0[4], ky[4], kx[4];
+    bool cok[4], src2[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
         const int q = (n0 >> 6) + j;
         cok[j] = q * 64 < p.N;
-        tap[j] = cok[j] ? q / cpt : 0;
-        ci0[j] = cok[j] ? (q - tap[j] * cpt) * 64 : 0;
-        ky[j] = tap[j] / p.kw; kx[j] = tap[j] - ky[j] * p.kw;
+        const int tap = cok[j] ? q / cpt : 0;
+        ci0[j] = cok[j] ? (q - tap * cpt) * 64 : 0;
+        ky[j] = tap / p.kw; kx[j] = tap - ky[j] * p.kw;
         src2[j] = ci0[j] >= p.c1;
     }
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)(((long)(p.P - 1) * p.ldy + p.M) * (long)sizeof(T)), 0x00020000);
@@ -108,41 +115,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
                                                                          (unsigned)(((xpix - 1) * (p.x2 ? p.ldx2 : p.ldx1) + (p.x2 ? p.cin - p.c1 : p.c1)) * (long)sizeof(T)), 0x00020000);
     const unsigned lds0 = (unsigned)(uintptr_t)((lptr_t)smem);
 
-    // ---- loader: wave w moves pieces 2 w and 2 w + 1 (pixel rows 16 w .. 16 w + 15 of the k-tile) of all four panels.  Lane l of a piece: pixel row
-    // (l >> 3) of the piece, LDS slot l & 7 of that row = source chunk (l & 7) ^ key(row)
-    const int prow = lane >> 3;
+    // ---- loader: wave w moves piece w (pixel rows 8 w .. 8 w + 7 of the k-tile) of all six panels.  Lane l: pixel row r = 8 w + (l >> 3), LDS slot
+    // l & 7 of that row = source chunk (l & 7) ^ key(r).  The lane's output pixel advances by 64 per k-tile: (image, position inside the image) are
+    // carried, only the row / column split is recomputed.
+    const int r_kt = 8 * wave + (lane >> 3);
+    const int sc8 = ((lane & 7) ^ (((r_kt >> 1) & 1) << 2)) * 8;      // first channel (of 64) of this lane's 16 bytes
     const int hw_out = p.hout * p.wout;
-    auto issue = [&](const int kt, const int stage) {
-        const int kbase = k_begin + kt * BK;
+    int pix = k_begin + r_kt;                                          // this lane's output pixel in the NEXT k-tile to issue
+    int bimg = fdiv_w(pix, hw_out);
+    int rem = pix - bimg * hw_out;
+    unsigned ycol[2];                                                  // dY byte offsets of the lane's columns (OOB beyond M)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = 16 * wave + 8 * j + prow;                 // pixel row inside the k-tile
-            const int pix = kbase + r;
-            const bool pok = pix < k_end;
-            const int sc = (lane & 7) ^ (((r >> 1) & 1) << 2);      // source chunk of this lane's slot
-            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(stage * STAGE + (16 * wave + 8 * j) * 128)));
-            // dY panels: columns m0 + 64 a + 8 sc .. + 7 of pixel row `pix`
+    for (int a = 0; a < 2; ++a) {
+        const int col = m0 + 64 * a + sc8;
+        ycol[a] = col < p.M ? (unsigned)col * (unsigned)sizeof(T) : OOB;
+    }
+    const unsigned ldyb = (unsigned)p.ldy * (unsigned)sizeof(T);
+    auto issue = [&](const int stage) {
+        const bool pok = pix < k_end;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(stage * STAGE + wave * 1024)));
+        const unsigned yrow = (unsigned)pix * ldyb;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int col = m0 + 64 * a + 8 * sc;
-                const unsigned off = (pok && col < p.M) ? (unsigned)(((long)pix * p.ldy + col) * (long)sizeof(T)) : OOB;
-                dma_piece_w(rsy, off, dst + (unsigned)(a * PANEL));
-            }
-            // X panels: output pixel -> (image, oy, ox) -> input pixel of the chunk's tap
-            const int bimg = fdiv_w(pix, hw_out);
-            const int rem = pix - bimg * hw_out;
-            const int oy = fdiv_w(rem, p.wout), ox = rem - oy * p.wout;
+        for (int a = 0; a < 2; ++a) dma_piece_w(rsy, (pok && ycol[a] != OOB) ? yrow + ycol[a] : OOB, dst + (unsigned)(a * PANEL));
+        const int oy = fdiv_w(rem, p.wout), ox = rem - oy * p.wout;
+        const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+        const int irow0 = bimg * p.hin;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int iy = oy * p.stride - p.pad_t + ky[c], ix = ox * p.stride - p.pad_l + kx[c];
-                const bool ok = pok && cok[c] && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
-                const long ipix = ((long)bimg * p.hin + iy) * p.win + ix;
-                const unsigned off = !ok ? OOB : (src2[c] ? (unsigned)((ipix * p.ldx2 + (ci0[c] - p.c1) + 8 * sc) * (long)sizeof(T))
-                                                          : (unsigned)((ipix * p.ldx1 + ci0[c] + 8 * sc) * (long)sizeof(T)));
-                if (src2[c]) dma_piece_w(rs2, off, dst + (unsigned)((2 + c) * PANEL));      // (uniform branch: a descriptor select would leave the SGPRs)
-                else dma_piece_w(rs1, off, dst + (unsigned)((2 + c) * PANEL));
+        for (int c = 0; c < 4; ++c) {
+            const int iy = iy0 + ky[c], ix = ix0 + kx[c];
+            const bool ok = pok && cok[c] && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
+            const unsigned ipix = (unsigned)((irow0 + iy) * p.win + ix);
+            if (src2[c]) {      // (uniform branch: a descriptor select would leave the SGPRs)
+                dma_piece_w(rs2, ok ? (ipix * (unsigned)p.ldx2 + (unsigned)(ci0[c] - p.c1 + sc8)) * (unsigned)sizeof(T) : OOB, dst + (unsigned)((2 + c) * PANEL));
+            } else {
+                dma_piece_w(rs1, ok ? (ipix * (unsigned)p.ldx1 + (unsigned)(ci0[c] + sc8)) * (unsigned)sizeof(T) : OOB, dst + (unsigned)((2 + c) * PANEL));
             }
         }
+        pix += BK;
+        rem += BK;
+        while (rem >= hw_out) { rem -= hw_out; ++bimg; }
     };
 
     // ---- fragment addresses (transpose reads).  32x32x16 operand of lane (column = l31, k-slots 8 hh .. + 7): two reads of 4 pixel rows each.
@@ -172,26 +183,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 
     const int nkt = (k_end - k_begin + BK - 1) / BK;
     if (nkt > 0) {
-        issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue(0);
+        issue(1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // k-tile 0 (this wave's pieces; the barrier makes it everybody's)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        int st = 0, st2 = 2;                                     // stage multiplied now / stage that receives k-tile kt + 2
         for (int kt = 0; kt < nkt; ++kt) {
-            const int st = kt & 1;
-            if (kt + 1 < nkt) issue(kt + 1, st ^ 1);
+            issue(st2);                                          // (beyond the split's end: zeros into a stage nobody reads — the count stays six)
             const char* pa = smem + st * STAGE + wm * PANEL;
             const char* pb = smem + st * STAGE + (2 + wn) * PANEL;
+            // fragments one k-step ahead of their MFMAs; the synchronisation that opens k-tile kt + 1 sits in front of the LAST MFMA group (every
+            // LDS read of this k-tile has returned by then): the barrier skew of the eight waves runs under four MFMAs (igemm5.hip's placement)
+            u32x4 fa[2][2], fb[2][2];
+            fa[0][0] = frag(pa, 0, 0); fa[0][1] = frag(pa, 1, 0); fb[0][0] = frag(pb, 0, 0); fb[0][1] = frag(pb, 1, 0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const u32x4 a0 = frag(pa, 0, ks), a1 = frag(pa, 1, ks), b0 = frag(pb, 0, ks), b1 = frag(pb, 1, ks);
-                acc[0][0] = MmaW<T>::run(a0, b0, acc[0][0]);
-                acc[0][1] = MmaW<T>::run(a0, b1, acc[0][1]);
-                acc[1][0] = MmaW<T>::run(a1, b0, acc[1][0]);
-                acc[1][1] = MmaW<T>::run(a1, b1, acc[1][1]);
+                const int c = ks & 1, n = c ^ 1;
+                if (ks < 3) { fa[n][0] = frag(pa, 0, ks + 1); fa[n][1] = frag(pa, 1, ks + 1); fb[n][0] = frag(pb, 0, ks + 1); fb[n][1] = frag(pb, 1, ks + 1); }
+                if (ks == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // this wave's pieces of k-tile kt + 1 have landed (kt + 2 may still fly); its reads of k-tile kt have returned
+                    __builtin_amdgcn_s_barrier();                                  // ... everybody's
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[0][0] = MmaW<T>::run(fa[c][0], fb[c][0], acc[0][0]);
+                acc[0][1] = MmaW<T>::run(fa[c][0], fb[c][1], acc[0][1]);
+                acc[1][0] = MmaW<T>::run(fa[c][1], fb[c][0], acc[1][0]);
+                acc[1][1] = MmaW<T>::run(fa[c][1], fb[c][1], acc[1][1]);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of k-tile kt + 1 have landed
-            __builtin_amdgcn_s_barrier();                        // ... everybody's, and everybody is done reading k-tile kt
             asm volatile("" ::: "memory");
+            st2 = st;
+            st = st == NSTAGE - 1 ? 0 : st + 1;
         }
     }
     // ---- partial tile out: fp32 [split][M][N]; a lane holds column n of 16 rows per block (rows (r & 3) + 8 (r >> 2) + 4 hh)
@@ -210,14 +234,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+int device_cus();   // api.hip
+
+// pixel split: one workgroup per CU and round.  Among the split counts that leave >= 8 k-tiles per workgroup the one with the best product of
+// (filled fraction of the last round) x (k-tiles / (k-tiles + 3): the pipeline fill of a workgroup) — e.g. conv 320 -> 320 3x3 at 32 x 72^2:
+// 36 tiles x 14 splits = 504 workgroups = 1.97 rounds, not 36 x 22 = 3.09.
 static void wgrad_plan(long M, long N, long P, int& nsplit, int& kchunk) {
     const long tiles = cdiv(M, wg::BM) * cdiv(N, wg::BN);
-    long want = cdiv(1024, tiles);
-    const long cap = P / 512 > 0 ? P / 512 : 1;
-    if (want > cap) want = cap;
-    if (want < 1) want = 1;
-    kchunk = (int)(cdiv(cdiv(P, want), wg::BK) * wg::BK);
-    nsplit = cdiv(P, kchunk);
+    int cus = device_cus();
+    if (cus <= 0) cus = 256;
+    const long ktiles = cdiv(P, wg::BK);
+    long cap = ktiles / 8;
+    if (cap < 1) cap = 1;
+    if (cap > 4L * cus) cap = 4L * cus;
+    double best = -1.0;
+    long best_ns = 1;
+    for (long ns = 1; ns <= cap; ++ns) {
+        const long kt = cdiv(ktiles, ns);                   // k-tiles per split
+        const long real_ns = cdiv(ktiles, kt);
+        const long w = tiles * real_ns, rounds = cdiv(w, (long)cus);
+        const double score = (double)w / (double)(rounds * cus) * (double)kt / (double)(kt + 3);
+        if (score > best * 1.0000001) { best = score; best_ns = real_ns; }
+    }
+    kchunk = (int)(cdiv(ktiles, best_ns) * wg::BK);
+    nsplit = (int)cdiv(P, kchunk);
 }
 
 }  // namespace e2eft
@@ -269,7 +309,7 @@ extern "C" int e2eft_conv2d_wgrad(const E2eftConvDesc* d, const void* dy, int32_
     dim3 grid(cdiv(p.N, wg::BN), cdiv(p.M, wg::BM), p.nsplit);
     E2EFT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "wgrad: grid");
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == E2EFT_F16) hipLaunchKernelGGL((wgrad_kernel<f16>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((wgrad_kernel<bf16>), grid, dim3(256), 0, s, p);
+    if (d->dtype == E2EFT_F16) hipLaunchKernelGGL((wgrad_kernel<f16>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<bf16>), grid, dim3(512), 0, s, p);
     return check_launch("wgrad");
 }
