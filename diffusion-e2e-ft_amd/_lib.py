@@ -43,7 +43,7 @@ class AttnDesc(C.Structure):
 
 
 # e2eft_set_option keys (include/e2eft.h)
-OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV = range(7)
+OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV, OPT_THIN_INPUT_CONV = range(8)
 
 _P = C.c_void_p
 _I = C.c_int32
@@ -156,7 +156,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.e2eft_version() < 113:
+    if lib.e2eft_version() < 114:
         raise RuntimeError("libe2eft.so is stale (version %d)" % lib.e2eft_version())
     _LIB = lib
     return lib

@@ -5,6 +5,8 @@
 
 namespace e2eft {
 
+template <int V> using IConst = std::integral_constant<int, V>;
+
 // -DE2EFT_STAMPS (build.py build_stamps(): lib/libe2eft_stamps.so, scripts/stamp_bench.py): thread 0 of every workgroup records the
 // shader clock at the phase boundaries of igemm2_kernel — start, k-loop entry, k-loop exit, accumulators staged, end.
 #ifdef E2EFT_STAMPS
@@ -361,5 +363,7 @@ int launch_igemm_v2(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 // igemm6.hip: persistent, the A operand of a 3x3 / stride-1 / pad-1 convolution as a 2-D halo patch in LDS; -1 when not eligible
 int launch_igemm_patch(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
+// convin.hip: 3x3 / stride-1 / pad-1 convolutions with eight input channels (operands straight from global memory, persistent); -1 when not eligible
+int launch_conv_thin_in(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 
 }  // namespace e2eft

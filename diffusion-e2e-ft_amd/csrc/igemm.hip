@@ -80,6 +80,8 @@ static int run_igemm(int dtype, int mode, IgemmParams& p, int nz, void* stream) 
     if (nz > 65535) return fail(E2EFT_ERR_BAD_ARG, "igemm: batch %d > 65535", nz);
     hipStream_t s = (hipStream_t)stream;
     if (dtype < 0 || dtype > 2) return fail(E2EFT_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
+    const int rc7 = launch_conv_thin_in(dtype, mode, p, nz, s);      // conv_in: eight input channels (convin.hip)
+    if (rc7 >= 0) return rc7;
     const int rc6 = launch_igemm_patch(dtype, mode, p, nz, s);        // big 16-bit 3x3 convolutions: halo patch in LDS (igemm6.hip)
     if (rc6 >= 0) return rc6;
     const int rc5 = launch_igemm_persistent(dtype, mode, p, nz, s);   // big 16-bit problems: persistent workgroups (igemm5.hip)

@@ -431,230 +431,12 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         rotate();
     };
 
-    // ---- the epilogue of the MFMA-side tile (c_m0, c_n0): out = alpha * (acc + bias + rowadd[img]) + residual, eight slices per wave
-    // Tiles WITHOUT a residual: everything that is per column (alpha, bias, row vector, GroupNorm statistics) is done in the accumulator layout,
-    // where a lane owns two columns; the values are rounded to T there and two rows of a column share a dword, so the LDS transpose moves half
-    // the bytes (the ds_write_b32 rate of 64 B/clk is what bounds the epilogue) and the row-wise readers only un-interleave and store.
-    // Rounds of 16 rows: window = 8 row pairs x 64 columns of packed dwords (2 KiB as one fp32 slice), two windows in flight.
-    auto epilogue_packed = [&](const int sfree, const long zoff_o) {
-        unsigned* win = reinterpret_cast<unsigned*>(smem + sfree + wave * 4096);
-        const float al = p.alpha;
-        T* __restrict__ out = (T*)p.out + zoff_o;
-        const f2 al2 = {al, al};
-        f2 bva[2], rav[2], pv[2], sm[2], sq[2];   // per owned column j: bias * alpha, row vector, pivot, shifted sums (pairs = two rows at a time)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            // association as in the fp32 epilogue below and igemm2's vector row pass: fma(rowadd, alpha, fma(acc, alpha, bias * alpha))
-            const float bj = bias ? to_f(col_bias[j]) * al : 0.f, rj = has_ra ? to_f(col_ra[j]) : 0.f;
-            bva[j] = f2{bj, bj}; rav[j] = f2{rj, rj};
-            pv[j] = f2{0.f, 0.f}; sm[j] = f2{0.f, 0.f}; sq[j] = f2{0.f, 0.f};
-        }
-        // physical dword of (row pair rp8, column x) inside a window: ((x >> 2) & 1) * 256 + rp8 * 32 + (x >> 3) * 4 + (x & 3): readers take the
-        // 16-byte units `lane` and `64 + lane`
-        const int wofs = ((l31 >> 2) & 1) * 256 + h * 64 + (l31 >> 3) * 4 + (l31 & 3);   // + qq * 128 + t * 32 + j * 16
-        auto wr = [&](auto rc_) {
-            constexpr int r = decltype(rc_)::value, i = r >> 1;
-            unsigned* wb = win + (r & 1) * 512 + wofs;
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                constexpr int dummy = 0; (void)dummy;
-                const int q = 2 * (r & 1) + qq;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        f2 x = {acc[i][j][4 * q + 2 * t], acc[i][j][4 * q + 2 * t + 1]};
-                        x = __builtin_elementwise_fma(x, al2, bva[j]);
-                        if (has_ra) x = __builtin_elementwise_fma(rav[j], al2, x);
-                        if (stats) {
-                            if (r == 0 && qq == 0 && t == 0) {   // pivot of a column: its first value in the wave (held by the h = 0 lane)
-                                const float p0 = __shfl(x[0], l31, 64);
-                                pv[j] = f2{p0, p0};
-                            }
-                            const f2 d = x - pv[j];
-                            sm[j] += d;
-                            sq[j] = __builtin_elementwise_fma(d, d, sq[j]);
-                        }
-                        T e2[2] = {from_f<T>(x[0]), from_f<T>(x[1])};
-                        unsigned u;
-                        __builtin_memcpy(&u, e2, 4);
-                        wb[qq * 128 + t * 32 + j * 16] = u;
-                    }
-            }
-        };
-        const int rp8 = lane >> 3;                                   // reader: row pair of the round, chunk ec
-        auto round = [&](auto rc_) {
-            constexpr int r = decltype(rc_)::value;
-            if constexpr (r < 3) wr(IC5<r + 1>{});
-            if constexpr (r == 2) __builtin_amdgcn_s_waitcnt(0x0F70);   // the next tile's first two k-tiles have landed (as slice 4 of the fp32 epilogue)
-            const unsigned* rb = win + (r & 1) * 512 + lane * 4;
-            const u32x4 t0 = *reinterpret_cast<const u32x4*>(rb);       // columns 8 ec .. +3, rows (2 rp8, 2 rp8 + 1) interleaved
-            const u32x4 t1 = *reinterpret_cast<const u32x4*>(rb + 256); // columns 8 ec + 4 .. +7
-            u32x4 lo, hi;
-            lo[0] = __builtin_amdgcn_perm(t0[1], t0[0], 0x05040100u); hi[0] = __builtin_amdgcn_perm(t0[1], t0[0], 0x07060302u);
-            lo[1] = __builtin_amdgcn_perm(t0[3], t0[2], 0x05040100u); hi[1] = __builtin_amdgcn_perm(t0[3], t0[2], 0x07060302u);
-            lo[2] = __builtin_amdgcn_perm(t1[1], t1[0], 0x05040100u); hi[2] = __builtin_amdgcn_perm(t1[1], t1[0], 0x07060302u);
-            lo[3] = __builtin_amdgcn_perm(t1[3], t1[2], 0x05040100u); hi[3] = __builtin_amdgcn_perm(t1[3], t1[2], 0x07060302u);
-            if (c_colok) {
-                T* o = out + c_orow + (long)(16 * r + rp8) * p.ldo;   // c_orow is row `rp8` of the wave's block: + rp8 more rows = row 2 rp8 of round r
-                *reinterpret_cast<u32x4*>(o) = lo;
-                *reinterpret_cast<u32x4*>(o + p.ldo) = hi;
-            }
-        };
-        wr(IC5<0>{});
-        round(IC5<0>{}); round(IC5<1>{}); round(IC5<2>{}); round(IC5<3>{});
-        if (stats) {   // uniform: per column totals = both halves of the pair accumulators + the other half-wave; h = 0 lanes deposit their two columns
-            float* dep = reinterpret_cast<float*>(smem + RING);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float su = sm[j][0] + sm[j][1], s2 = sq[j][0] + sq[j][1];
-                su += __shfl_xor(su, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (h == 0) {
-                    float* d3 = dep + (wave * 64 + 32 * j + l31) * 3;
-                    d3[0] = su; d3[1] = s2; d3[2] = pv[j][0];
-                }
-            }
-        }
-    };
-
-    auto epilogue = [&](const int sfree, const long zoff_o) {
-        // (opened by the barrier embedded in the last k-tile: every wave is done reading that k-tile, its stage is scratch now)
-        float* win = reinterpret_cast<float*>(smem + sfree + wave * 4096);   // two 2-KiB slice windows
-        // window layout: 16-byte unit U = ((x >> 2) & 1) * 64 + row * 8 + (x >> 3) for logical (row, column x): the row-wise readers take
-        // units `lane` and `64 + lane` (two conflict-free contiguous kilobytes), the accumulator lanes write 2-way (free on ds_write_b32)
-        const int wofs = ((l31 >> 2) & 1) * 256 + h * 128 + (l31 >> 3) * 4 + (l31 & 3);   // in floats; + e * 32 + j * 16
-        const float al = p.alpha;
-        T* __restrict__ out = (T*)p.out + zoff_o;
-        const T* __restrict__ res = (const T*)p.residual;   // c_rrow carries the batch offset
-        f2 bva2[4], ra2[4], pv2[4], sm2[4], sq2[4];
-        const f2 al2 = {al, al};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bva2[q] = bias ? f2{to_f(pre_bias.e[2 * q]) * al, to_f(pre_bias.e[2 * q + 1]) * al} : f2{0.f, 0.f};
-            ra2[q] = has_ra ? f2{to_f(pre_ra.e[2 * q]), to_f(pre_ra.e[2 * q + 1])} : f2{0.f, 0.f};
-            pv2[q] = f2{0.f, 0.f}; sm2[q] = f2{0.f, 0.f}; sq2[q] = f2{0.f, 0.f};
-        }
-        auto wr = [&](auto sc_) {
-            constexpr int s = decltype(sc_)::value, i = s >> 2, q = s & 3;
-            float* wb = win + (s & 1) * 512 + wofs;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) wb[e * 32 + j * 16] = acc[i][j][4 * q + e];
-        };
-        Vec16<T> late_res[4];
-        auto slice = [&](auto sc_) {
-            constexpr int s = decltype(sc_)::value;
-            if constexpr (s == 0) {
-                if (has_res) {   // residual rows of slices 4-7: consumed four slices from now
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) late_res[t] = ld16(res + c_rrow + (long)((4 + t) * 8) * p.ldr);
-                }
-            }
-            if constexpr (s < 7) wr(IC5<s + 1>{});
-            // the next tile's first two k-tiles (issued >= 1 k-tile + 4 slices ago) have landed.  The BUILTIN, not inline asm: the compiler's
-            // waitcnt pass then knows that nothing is pending and does not drain again in front of later register / LDS reuse
-            if constexpr (s == 4) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
-            const float* rb = win + (s & 1) * 512 + lane * 4;
-            const floatx4 t0 = *reinterpret_cast<const floatx4*>(rb);
-            const floatx4 t1 = *reinterpret_cast<const floatx4*>(rb + 256);
-            f2 x2[4] = {f2{t0[0], t0[1]}, f2{t0[2], t0[3]}, f2{t1[0], t1[1]}, f2{t1[2], t1[3]}};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x2[q] = __builtin_elementwise_fma(x2[q], al2, bva2[q]);
-            if (has_ra) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) x2[q] = __builtin_elementwise_fma(ra2[q], al2, x2[q]);
-            }
-            if (has_res) {
-                const Vec16<T>& rv = s < 4 ? pre_res[s & 3] : late_res[s & 3];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) x2[q] += f2{to_f(rv.e[2 * q]), to_f(rv.e[2 * q + 1])};
-            }
-            Vec16<T> o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o.e[e] = from_f<T>(x2[e >> 1][e & 1]);
-            if (c_colok) st16(out + c_orow + (long)(s * 8) * p.ldo, o);
-            if (stats) {
-                if constexpr (s == 0) {   // pivot: the wave's first row, broadcast down the eight row-lanes of every chunk
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) pv2[q] = f2{__shfl(x2[q][0], ec, 64), __shfl(x2[q][1], ec, 64)};
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f2 d = x2[q] - pv2[q];
-                    sm2[q] += d;
-                    sq2[q] = __builtin_elementwise_fma(d, d, sq2[q]);
-                }
-            }
-        };
-        wr(IC5<0>{});
-        slice(IC5<0>{});
-        STAMP5(tseq, 5);
-        slice(IC5<1>{}); slice(IC5<2>{}); slice(IC5<3>{});
-        STAMP5(tseq, 6);
-        slice(IC5<4>{}); slice(IC5<5>{}); slice(IC5<6>{}); slice(IC5<7>{});
-        if (stats) {   // uniform.  16 values (8 sums, 8 sums of squares) over the 8 row-lanes of a chunk: reduce-scatter butterfly —
-            // each step a lane hands half of its values to its partner and adds the partner's other half (14 exchanges instead of 48)
-            float v[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { v[2 * q] = sm2[q][0]; v[2 * q + 1] = sm2[q][1]; v[8 + 2 * q] = sq2[q][0]; v[8 + 2 * q + 1] = sq2[q][1]; }
-            const bool b0 = (er & 1) != 0, b1 = (er & 2) != 0, b2 = (er & 4) != 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float keep = b0 ? v[k + 8] : v[k], send = b0 ? v[k] : v[k + 8];
-                v[k] = keep + __shfl_xor(send, 8, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float keep = b1 ? v[k + 4] : v[k], send = b1 ? v[k] : v[k + 4];
-                v[k] = keep + __shfl_xor(send, 16, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float keep = b2 ? v[k + 2] : v[k], send = b2 ? v[k] : v[k + 2];
-                v[k] = keep + __shfl_xor(send, 32, 64);
-            }
-            // this lane now holds statistic (er & 1) of columns e0, e0 + 1 of its chunk, e0 = 4 * bit1 + 2 * bit2
-            const int e0 = ((er >> 1) & 1) * 4 + (er >> 2) * 2;
-            float pva[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pva[e] = pv2[e >> 1][e & 1];
-            const float pe0 = b1 ? (b2 ? pva[6] : pva[4]) : (b2 ? pva[2] : pva[0]);
-            const float pe1 = b1 ? (b2 ? pva[7] : pva[5]) : (b2 ? pva[3] : pva[1]);
-            float* d3 = reinterpret_cast<float*>(smem + RING) + (wave * 64 + ec * 8 + e0) * 3;
-            d3[(int)b0] = v[0];
-            d3[3 + (int)b0] = v[1];
-            if (!b0) { d3[2] = pe0; d3[5] = pe1; }
-        }
-    };
-    // merge of the four row-waves' deposits of tile (m0, n0), one thread per column (after a barrier that follows the deposits)
-    auto combine = [&](const int m0, const int n0) {
-        if (tid < BN && n0 + tid < p.N) {
-            const float* dep = reinterpret_cast<const float*>(smem + RING);
-            const int cw = tid >> 6, cc = tid & 63;
-            float mean = 0.f, m2 = 0.f, na = 0.f;
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) {
-                const float* d3 = dep + ((w4 * 2 + cw) * 64 + cc) * 3;
-                const float s1 = d3[0], s2 = d3[1], pv = d3[2];
-                const float mb = pv + s1 * (1.0f / 64.0f);
-                const float m2b = fmaxf(s2 - s1 * s1 * (1.0f / 64.0f), 0.f);
-                if (w4 == 0) { mean = mb; m2 = m2b; na = 64.f; }
-                else {
-                    const float nt = na + 64.f, dl = mb - mean;
-                    mean += dl * (64.f / nt);
-                    m2 += m2b + dl * dl * (na * 64.f / nt);
-                    na = nt;
-                }
-            }
-            const int img = m0 / p.rows_per_img;
-            const int slab = (m0 - img * p.rows_per_img) / BM;
-            float* o = p.gn_partial + (((long)img * p.gn_nslabs + slab) * p.N + n0 + tid) * 3;
-            o[0] = na; o[1] = mean; o[2] = m2;
-        }
-    };
-
+    // ---- epilogues and statistics merge: shared with igemm6.hip (rows of a wave's block are consecutive GEMM rows here)
+    auto epi_rofs = [&](const int r) -> long { return (long)r; };
+    constexpr int EPI_DEP = RING;
+#define EPI_STAMP(i) STAMP5(tseq, i)
+#include "igemm_persistent_epilogue.inc"
+#undef EPI_STAMP
     // ================================ main ==========================================================================
     tile_coords(u_dma);
     fill_rowtab();
@@ -684,7 +466,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // statistics deposits written; every slice window read
         __builtin_amdgcn_s_barrier();                        // opens k-tile 0 of the next tile (its pieces landed before slice 4 of every wave)
         asm volatile("" ::: "memory");
-        if (stats) combine(c_m0, c_n0);
+        if (stats) { const int img = c_m0 / p.rows_per_img; combine(img, (c_m0 - img * p.rows_per_img) / BM, c_n0); }
         STAMP5(tseq - 1, 7);
         if (dma_done) break;
         first = false;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define E2EFT_VERSION 113 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
+#define E2EFT_VERSION 114 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
 
 enum {
     E2EFT_OK = 0,
@@ -58,7 +58,8 @@ enum {
     E2EFT_OPT_IGEMM_GENERAL_OPERANDS = 4, /* 0 (default); 1: igemm2 takes its general (per-lane gather) operand path for every launch */
     E2EFT_OPT_IGEMM2_WAVES = 5,      /* 0 (default): 8-wave 256-row tiles when >= 128 of them exist (fp32: 256), else 4-wave 128-row; 4 / 8: forced */
     E2EFT_OPT_PATCH_CONV = 6,        /* 1 (default): big 16-bit 3x3 / stride-1 / pad-1 convolutions on the halo-patch kernel (igemm6); 0: igemm5 */
-    E2EFT_OPT_COUNT = 7
+    E2EFT_OPT_THIN_INPUT_CONV = 7,   /* 1 (default): big 16-bit 3x3 / stride-1 / pad-1 convolutions with EIGHT input channels on convin.hip; 0: igemm2 */
+    E2EFT_OPT_COUNT = 8
 };
 int e2eft_set_option(int32_t key, int32_t value);
 int e2eft_get_option(int32_t key);
