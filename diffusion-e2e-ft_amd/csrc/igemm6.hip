@@ -11,7 +11,8 @@
 //     9 x 32 = 288;
 //   * two patch buffers: while the nine k-tiles of chunk c multiply out of one, the patch of chunk c+1 (or chunk 0 of the workgroup's
 //     next tile) arrives in the other — at most one A piece per wave and k-tile, beside the two B pieces that the 3-stage weight ring
-//     needs; every k-tile issues exactly three pieces (surplus ones fetch zeros into a dump kilobyte), so all waits are counted;
+//     needs: three pieces in k-tiles 0-5 of a chunk, two in 6-8 (the counts are compile-time constants of the unrolled k-tiles, so all
+//     waits are counted; the five patch pieces beyond the 43rd fetch zeros into a dump kilobyte);
 //   * the fragment of output pixel (y, x), tap (ky, kx) is patch row (y + ky) * 34 + x + kx: 32 consecutive patch rows per MFMA operand, the
 //     same XOR chunk swizzle as igemm2 / igemm5 keyed by the PATCH row (conflict-free for any start row); the nine k-tiles of a chunk are
 //     unrolled, the tap shift is an immediate;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     };
     int pcur = 0, pnext = PATCH;              // patch buffer being multiplied / being filled
     int bs_cur = OFF_B, bs_nxt = OFF_B + B_STAGE, bs_dst = OFF_B + 2 * B_STAGE;
-    auto fire_a = [&](auto ic, const int pdst) {   // piece i of the patch being fetched (i >= 6: a surplus piece, zeros into the dump kilobyte)
+    auto fire_a = [&](auto ic, const int pdst) {   // piece i (0..5) of the patch being fetched (pieces beyond the 43rd: zeros into the dump kilobyte)
         constexpr int i = decltype(ic)::value;
         unsigned off = OOB;
         int dst = OFF_DUMP + wave * 1024;
@@ -208,8 +209,8 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
 
     // one k-tile = (chunk c, tap t).  CK: 1 first chunk of a tile (t = 0 multiplies into the constant 0 and carries the tile-entry arithmetic),
     // 2 last chunk (t = 0: the A state moves to the workgroup's next tile — this chunk's pieces are that tile's first patch; t = 7: epilogue
-    // operands requested, then the B state moves on; t = 8: last k-tile), 0 otherwise.  Every k-tile issues three pieces: B of k-tile + 2 (two),
-    // one piece of the next patch.  The synchronisation that opens the next k-tile sits in front of the last two MFMA groups (igemm5.hip).
+    // operands requested, then the B state moves on; t = 8: last k-tile), 0 otherwise.  Every k-tile issues the two B pieces of k-tile + 2, k-tiles
+    // 0-5 one piece of the next patch as well.  The synchronisation that opens the next k-tile sits in front of the last two MFMA groups (igemm5.hip).
     auto ktile = [&](auto tc, auto ckc, const int c) {
         constexpr int t = decltype(tc)::value, CK = decltype(ckc)::value;
         constexpr int TS = (t / 3) * PW + (t % 3);
@@ -270,20 +271,21 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
             fire_b(bs_dst, kofs);
         }
         rd(IC6<3>{}, IC6<0>{});
-        fire_a(IC6<t>{}, pnext);
+        if constexpr (t < 6) fire_a(IC6<t>{}, pnext);   // k-tiles 6-8 of a chunk issue the two weight pieces only
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[1], a1[1], b0[1], b1[1]);
         __builtin_amdgcn_sched_barrier(0);
         // lgkmcnt(0): this wave's reads of the current stage have RETURNED before the barrier lets others overwrite it
         if constexpr (CK == 2 && t == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        else if constexpr (CK == 2 && t == 7) {
-            if (npre == 0) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-            else if (npre == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else if (npre == 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-            else if (npre == 4) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-            else if (npre == 5) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if constexpr (CK == 2 && t == 7) {   // younger than the previous k-tile's pieces: this k-tile's operand requests + its two weight pieces
+            if (npre == 0) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else if (npre == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            else if (npre == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else if (npre == 4) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if (npre == 5) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        } else if constexpr (t < 6) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
