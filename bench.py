@@ -62,7 +62,14 @@ def parse():
                     "that are appended to the JSON line as `train_step` (bf16 compute) and `train_step_fp32` (the reference recipe)")
     ap.add_argument("--plumbing-check", action="store_true", help="launcher / rendezvous / timing-reduction check without GPU work (gloo, CPU): "
                     "prints a line with value null; used by tests/test_distributed_cpu.py")
+    ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B runs: e2eft_set_option before anything is launched (names: scripts/_options.py, e.g. patch_conv=0, fused_norm=0); recorded in the line's config")
     args = ap.parse_args()
+    if args.set_option:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import _options
+        left = _options.take(args.set_option)
+        assert not left, "unknown --set-option %s" % left
     if args.res is None:
         args.res = 576 if args.train else 768
     hw = str(args.res).lower().split("x")
@@ -628,7 +635,8 @@ def main():
             "config": {"workload": "marigold-e2e-ft-depth 1-step inference, batch=%d/GPU at %dx%d %s, random-init SD-v2 UNet (866M) + SD VAE (84M)%s"
                                    % (B, RH, RW, args.dtype, " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
                        "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world,
-                       "launch_mode": "hipGraph replay (one captured graph per batch shape)" if args.graph else "host launches"},
+                       "launch_mode": "hipGraph replay (one captured graph per batch shape)" if args.graph else "host launches",
+                       **({"options": args.set_option} if args.set_option else {})},
             "roofline": {"bound": "mfma", "kernel": "igemm6_kernel (persistent, halo-patch 3x3 conv) + igemm5_kernel (persistent) + igemm2_kernel: implicit-GEMM conv/linear, all launches of the timed region",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_over_algorithmic": (traffic / alg_bpl) if traffic else None,

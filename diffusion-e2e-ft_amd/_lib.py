@@ -43,7 +43,7 @@ class AttnDesc(C.Structure):
 
 
 # e2eft_set_option keys (include/e2eft.h)
-OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV, OPT_THIN_INPUT_CONV = range(8)
+OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV, OPT_THIN_INPUT_CONV, OPT_FUSED_NORM = range(9)
 
 _P = C.c_void_p
 _I = C.c_int32
@@ -64,6 +64,10 @@ SIGNATURES = {
     "e2eft_conv2d_fwd_splitk": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "e2eft_gemm_gnstats": (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _I, _P, _Z, C.POINTER(C.c_int32), _P]),
     "e2eft_groupnorm_fwd_pre": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _Z, _P]),
+    "e2eft_groupnorm_coeff_offset": (_Z, [C.POINTER(GroupNormDesc)]),
+    "e2eft_groupnorm_fwd_stats": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _I, _P, _I, _P, _Z, _P]),
+    "e2eft_conv2d_fwd_normed_supported": (_I, [C.POINTER(ConvDesc)]),
+    "e2eft_conv2d_fwd_normed": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int32), _P]),
     "e2eft_groupnorm_workspace_bytes": (_Z, [C.POINTER(GroupNormDesc)]),
     "e2eft_groupnorm_fwd": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _Z, _P]),
     "e2eft_layernorm_fwd": (_I, [_I, _L, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
@@ -156,7 +160,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.e2eft_version() < 114:
+    if lib.e2eft_version() < 115:
         raise RuntimeError("libe2eft.so is stale (version %d)" % lib.e2eft_version())
     _LIB = lib
     return lib

@@ -200,8 +200,13 @@ class _Conv2dFn(torch.autograd.Function):
         return dx, dx2, dw, dbias, drow, dres, None, None, None, None, None, None
 
 
-def conv(conv_mod, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0, pad=None, gn_stats=True):
-    """nn.Conv2d-shaped module on NHWC input (see modules.conv_nhwc); differentiable when a gradient is required."""
+def conv(conv_mod, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0, pad=None, gn_stats=True, norm=None):
+    """nn.Conv2d-shaped module on NHWC input (see modules.conv_nhwc); differentiable when a gradient is required.
+    norm = (GroupNorm module, silu): the convolution of norm(x) — without autograd the library may apply the norm inside the convolution's
+    operand fetch (ops.conv2d); under autograd the norm runs as its own differentiable op first."""
+    if norm is not None and (needs_grad(x, x2, conv_mod.weight, conv_mod.bias, rowadd, residual, norm[0].weight, norm[0].bias) or x2 is not None):
+        x = groupnorm(x, norm[0].weight, norm[0].bias, norm[0].num_groups, norm[0].eps, silu=norm[1], x2=x2)
+        x2, norm = None, None
     kh, kw = conv_mod.weight.shape[2:]
     stride = conv_mod.stride[0] if isinstance(conv_mod.stride, tuple) else conv_mod.stride
     if pad is None:
@@ -212,8 +217,9 @@ def conv(conv_mod, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0
     dt = x.dtype
     if x2 is None:
         x = ops.pad_channels(x)
+    nrm = None if norm is None else (_vec(norm[0].weight, dt), _vec(norm[0].bias, dt), norm[0].num_groups, norm[0].eps, norm[1])
     return ops.conv2d(x, packed_conv_weight(conv_mod, dt), _vec(conv_mod.bias, dt), conv_mod.weight.shape[0], kh, kw, stride, pad, x2=x2,
-                      up_to=up_to, rowadd=rowadd, residual=residual, alpha=alpha, gn_stats=gn_stats)
+                      up_to=up_to, rowadd=rowadd, residual=residual, alpha=alpha, gn_stats=gn_stats, norm=nrm)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -42,6 +42,9 @@ struct IgemmParams {
     float* gn_partial;   // optional: [img][gn_nslabs][N][3] (n, mean, M2) GroupNorm partials of the rounded output
     int gn_nslabs;       // row slabs (one per M-tile) per image
     int ksplit_taps;     // conv split-K: batch index zi covers filter taps [zi * ksplit_taps, (zi + 1) * ksplit_taps) (0 = whole K)
+    const float* nrm_ad; // optional (igemm6 only): the A operand is read through GroupNorm(+SiLU): [image][cin][2] fp32 (a, mean) pairs of e2eft_groupnorm_fwd_stats ...
+    const void* nrm_beta; // ... and the norm's beta [cin] (or null): value = (x - mean) * a + beta, then SiLU if nrm_silu
+    int nrm_silu;
     int debug_flags;     // instrumented build (-DE2EFT_STAMPS) only: bit 0 / 1 / 2 = the persistent kernel issues its A-operand LDS-DMA never / on the
                          // first tap of a filter row only / on the first tap of a 64-channel chunk only (WRONG results; the price of operand
                          // delivery, scripts/experiments/README: "what an A-reuse scheme could buy at most")
@@ -363,6 +366,7 @@ int launch_igemm_v2(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 // igemm6.hip: persistent, the A operand of a 3x3 / stride-1 / pad-1 convolution as a 2-D halo patch in LDS; -1 when not eligible
 int launch_igemm_patch(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
+bool igemm_patch_eligible(int dtype, int mode, IgemmParams& p, int nz);   // the host-side test of launch_igemm_patch alone (fills p.mtiles / ntiles / gn_nslabs)
 // convin.hip: 3x3 / stride-1 / pad-1 convolutions with eight input channels (operands straight from global memory, persistent); -1 when not eligible
 int launch_conv_thin_in(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 

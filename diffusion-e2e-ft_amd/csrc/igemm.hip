@@ -80,6 +80,10 @@ static int run_igemm(int dtype, int mode, IgemmParams& p, int nz, void* stream) 
     if (nz > 65535) return fail(E2EFT_ERR_BAD_ARG, "igemm: batch %d > 65535", nz);
     hipStream_t s = (hipStream_t)stream;
     if (dtype < 0 || dtype > 2) return fail(E2EFT_ERR_BAD_ARG, "igemm: bad dtype %d", dtype);
+    if (p.nrm_ad) {   // the fused-normalisation route exists on igemm6 only: the caller asked e2eft_conv2d_fwd_normed_supported first
+        const int rcn = launch_igemm_patch(dtype, mode, p, nz, s);
+        return rcn >= 0 ? rcn : fail(E2EFT_ERR_UNSUPPORTED, "conv2d_fwd_normed: this launch is not eligible for the fused-normalisation kernel");
+    }
     const int rc7 = launch_conv_thin_in(dtype, mode, p, nz, s);      // conv_in: eight input channels (convin.hip)
     if (rc7 >= 0) return rc7;
     const int rc6 = launch_igemm_patch(dtype, mode, p, nz, s);        // big 16-bit 3x3 convolutions: halo patch in LDS (igemm6.hip)
@@ -108,9 +112,10 @@ extern "C" size_t e2eft_conv2d_splitk_workspace_bytes(const E2eftConvDesc* d) {
     return ns ? (size_t)ns * d->batch * d->hout * d->wout * d->cout * dtype_size(d->dtype) : 0;
 }
 
+struct ConvNorm { const float* ad; const void* beta; int silu; };   // the input is read through GroupNorm(+SiLU): e2eft_conv2d_fwd_normed
 static int conv2d_core(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w, const void* bias, const void* rowadd,
                        const void* residual, void* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* workspace,
-                       size_t ws_bytes, void* stream);
+                       size_t ws_bytes, void* stream, const ConvNorm* norm = nullptr);
 
 extern "C" int e2eft_conv2d_fwd_splitk(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w, const void* bias,
                                        const void* rowadd, const void* residual, void* out, void* workspace, size_t ws_bytes, void* stream) {
@@ -128,9 +133,36 @@ extern "C" int e2eft_conv2d_fwd_gnstats(const E2eftConvDesc* d, const void* x1, 
     return conv2d_core(d, x1, x2, w, bias, rowadd, residual, out, gn_partial, gn_partial_bytes, slab_rows, nullptr, 0, stream);
 }
 
+extern "C" int e2eft_conv2d_fwd_normed(const E2eftConvDesc* d, const void* x1, const float* coeff, const void* beta, int32_t silu, const void* w,
+                                      const void* bias, const void* rowadd, const void* residual, void* out, float* gn_partial,
+                                      size_t gn_partial_bytes, int32_t* slab_rows, void* stream) {
+    E2EFT_REQUIRE(coeff, "conv2d_fwd_normed: null coefficients");
+    E2EFT_REQUIRE(d && d->c2 == 0, "conv2d_fwd_normed: one source only");
+    const ConvNorm n = {coeff, beta, silu ? 1 : 0};
+    return conv2d_core(d, x1, nullptr, w, bias, rowadd, residual, out, gn_partial, gn_partial_bytes, slab_rows, nullptr, 0, stream, &n);
+}
+
+// pure host arithmetic: would e2eft_conv2d_fwd_normed take this launch (with 16-byte aligned pointers)?
+extern "C" int e2eft_conv2d_fwd_normed_supported(const E2eftConvDesc* d) {
+    if (!d || d->c2 != 0 || d->dtype < 1 || d->dtype > 2 || !option(E2EFT_OPT_FUSED_NORM)) return 0;
+    if (d->batch <= 0 || d->hin <= 0 || d->win <= 0 || d->cout <= 0 || d->c1 <= 0) return 0;
+    IgemmParams p = {};
+    void* const al = (void*)(uintptr_t)256;
+    p.x1 = al; p.w = al; p.out = al; p.nrm_ad = (const float*)al;
+    p.M = d->batch * d->hout * d->wout; p.N = d->cout; p.K = d->kh * d->kw * d->c1;
+    p.ldx1 = d->ldx1; p.c1 = d->c1; p.cin = d->c1;
+    p.hin = d->hin; p.win = d->win; p.hl = d->hl; p.wl = d->wl;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.hout = d->hout; p.wout = d->wout;
+    p.ldw = d->ldw; p.ldr = d->ldr > 0 ? d->ldr : d->ldo; p.ldo = d->ldo;
+    p.rows_per_img = d->hout * d->wout;
+    p.nzi = 1;
+    return igemm_patch_eligible(d->dtype, 1, p, 1) ? 1 : 0;
+}
+
 static int conv2d_core(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w, const void* bias, const void* rowadd,
                        const void* residual, void* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* workspace,
-                       size_t ws_bytes, void* stream) {
+                       size_t ws_bytes, void* stream, const ConvNorm* norm) {
     if (slab_rows) *slab_rows = 0;
     E2EFT_REQUIRE(d && x1 && w && out, "conv2d: null pointer");
     const int epc = 16 / (int)dtype_size(d->dtype);
@@ -149,7 +181,7 @@ static int conv2d_core(const E2eftConvDesc* d, const void* x1, const void* x2, c
     // the last output row/col must read at least one in-range tap row/col origin
     E2EFT_REQUIRE((d->hout - 1) * d->stride - d->pad_t < d->hl && (d->wout - 1) * d->stride - d->pad_l < d->wl, "conv2d: output larger than padded input");
 
-    if (!x2 && !rowadd && !residual && !gn_partial && !workspace) {   // <= 4 output channels: LDS-halo dot-product kernel instead of a 128-wide MFMA tile
+    if (!x2 && !rowadd && !residual && !gn_partial && !workspace && !norm) {   // <= 4 output channels: LDS-halo dot-product kernel instead of a 128-wide MFMA tile
         const int rn = launch_conv3x3_narrow(d, x1, w, bias, out, stream);
         if (rn >= 0) return rn;
     }
@@ -170,6 +202,7 @@ static int conv2d_core(const E2eftConvDesc* d, const void* x1, const void* x2, c
     p.rows_per_img = d->hout * d->wout;
     p.alpha = d->alpha;
     p.nzi = 1;
+    if (norm) { p.nrm_ad = norm->ad; p.nrm_beta = norm->beta; p.nrm_silu = norm->silu; }
     const bool plain = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->c2 == 0 &&
                        d->hl == d->hin && d->wl == d->win && d->hout == d->hin && d->wout == d->win;
     if (gn_partial && slab_rows) {

@@ -44,6 +44,9 @@ constexpr int OFF_DEP = OFF_B + 3 * B_STAGE;
 constexpr int DEP = NW * 64 * 3 * 4;
 constexpr int OFF_DUMP = OFF_DEP + DEP;
 constexpr int LDS = OFF_DUMP + NW * 1024;                               // 151,552 B
+constexpr int NORM_CMAX = 640;                                          // NORM: input channels the (a, mean, beta) table of one image holds
+constexpr int OFF_TAB = LDS, OFF_TABB = OFF_TAB + NORM_CMAX * 8;
+constexpr int LDS_NORM = OFF_TABB + NORM_CMAX * 4;                      // 159,232 B
 constexpr unsigned int OOB = 0xF0000000u;
 constexpr unsigned int RECORDS = 0xE0000000u;
 }  // namespace patchk
@@ -71,10 +74,13 @@ __device__ __forceinline__ int fast_div6(int n, int d) {   // float estimate + o
     return q;
 }
 
-template <typename T, bool RES>
+// NORM: the input is read through GroupNorm(+SiLU) — the statistics exist (e2eft_groupnorm_fwd_stats), the apply pass does not: every lane normalises, in
+// place in LDS, exactly the 16-byte units of the patch it fetched itself (k-tile t of a chunk: piece t - 2, landed since the previous k-tile's wait), with the
+// arithmetic of gn_apply_kernel (norm.hip) — the convolution's result is bit-identical to GroupNorm followed by igemm6.  Padding rows stay zero.
+template <typename T, bool RES, bool NORM>
 __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const int total_tiles) {
     using namespace patchk;
-    __shared__ __attribute__((aligned(128))) char smem[LDS];
+    __shared__ __attribute__((aligned(128))) char smem[NORM ? LDS_NORM : LDS];
     typedef float f2 __attribute__((ext_vector_type(2)));
 
     const int tid = threadIdx.x;
@@ -115,6 +121,8 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     bool dma_done = false;
     __amdgpu_buffer_rsrc_t rs1, rs2, rsw, rsa;
     unsigned int a_ldb = 0, a_coff = 0;       // A pieces of the chunk being fetched: pixel pitch in bytes, channel + swizzle offset
+    int n_c0 = 0, tab_img = -1;               // NORM: first of this lane's eight channels in the chunk being fetched; image whose coefficients are in LDS
+    const unsigned lds_base = (unsigned)(uintptr_t)((lptr6_t)smem);
 
     auto tile_coords = [&](const int u) {
         int mt = u, nt = 0;
@@ -136,6 +144,18 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         const T* b2 = p.x2 ? (const T*)p.x2 + (long)d_img * Hs * Ws * p.ldx2 : b1;
         rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)b1, 0, RECORDS, 0x00020000);
         rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)b2, 0, RECORDS, 0x00020000);
+        if constexpr (NORM) {
+            if (valid && d_img != tab_img) {   // (uniform, once per image and workgroup) nobody reads the table between k-tile 8 of a chunk and k-tile 2 of the next
+                tab_img = d_img;
+                float* ta = reinterpret_cast<float*>(smem + OFF_TAB);
+                float* tb = reinterpret_cast<float*>(smem + OFF_TABB);
+                for (int c = tid; c < p.cin; c += 512) {
+                    ta[2 * c] = p.nrm_ad[((long)d_img * p.cin + c) * 2];
+                    ta[2 * c + 1] = p.nrm_ad[((long)d_img * p.cin + c) * 2 + 1];
+                    tb[c] = p.nrm_beta ? to_f(((const T*)p.nrm_beta)[c]) : 0.f;
+                }
+            }
+        }
     };
     auto set_b = [&](const bool valid) {      // B address state of the loader's tile
         rsw = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.w + (long)d_n0 * p.ldw), 0, RECORDS, 0x00020000);
@@ -149,6 +169,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         const int ch = cn * 64;
         if (ch < p.c1) { rsa = rs1; a_ldb = (unsigned)p.ldx1 * (unsigned)sizeof(T); a_coff = (unsigned)ch * (unsigned)sizeof(T) + (unsigned)jc16; }
         else { rsa = rs2; a_ldb = (unsigned)p.ldx2 * (unsigned)sizeof(T); a_coff = (unsigned)(ch - p.c1) * (unsigned)sizeof(T) + (unsigned)jc16; }
+        n_c0 = ch + (jc16 >> 1);
     };
     int pcur = 0, pnext = PATCH;              // patch buffer being multiplied / being filled
     int bs_cur = OFF_B, bs_nxt = OFF_B + B_STAGE, bs_dst = OFF_B + 2 * B_STAGE;
@@ -167,6 +188,71 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         char* sb = smem + stage + wave * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr6_t)sb, 16, brow[0] + kofs, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr6_t)(sb + 64 * 128), 16, brow[1] + kofs, 0, 0, 0);
+    };
+
+    // NORM: piece i of the patch in buffer `pbuf` (fetched by this wave, landed): x -> act((x - mean) * a + beta) in place, in three steps that a
+    // k-tile spreads over its second half: the LDS reads (patch unit, coefficients) are requested in front of the embedded barrier — its lgkmcnt(0)
+    // covers them —, four values are computed behind each of the last two MFMA groups, then the unit is written back.  Inline-asm DS instructions
+    // (in front of LDS accesses it can see the compiler may drain vmcnt: pieces are in flight by design).
+    u32x4 n_x;
+    floatx4 n_am[2], n_bb;      // coefficients of four channels at a time: (a, mean) pairs, betas
+    Vec16<T> n_o;
+    unsigned n_addr = 0, n_ta = 0, n_tb = 0;
+    bool n_on = false;
+    auto norm_issue = [&](auto ic, const int pbuf) {   // the patch unit and the coefficients of its first four channels
+        constexpr int i = decltype(ic)::value;
+        const int j = wave + 8 * i;
+        n_on = j < PPIECES;                                          // (wave-uniform)
+        if (!n_on) return;
+        n_addr = lds_base + (unsigned)(pbuf + j * 1024) + (unsigned)lane * 16u;
+        n_ta = lds_base + (unsigned)OFF_TAB + (unsigned)n_c0 * 8u;
+        n_tb = lds_base + (unsigned)OFF_TABB + (unsigned)n_c0 * 4u;
+        const unsigned ad = n_addr, ta = n_ta, tb = n_tb;
+        u32x4 x0;
+        floatx4 t0, t1, t4;     // (asm outputs into locals: clang does not capture variables that appear only as asm operands of a nested generic lambda)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(x0) : "v"(ad) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(t0) : "v"(ta) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(t1) : "v"(ta) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(t4) : "v"(tb) : "memory");
+        n_x = x0; n_am[0] = t0; n_am[1] = t1; n_bb = t4;
+    };
+    auto norm_issue2 = [&]() {   // the coefficients of the unit's last four channels (into the registers the first half is done with)
+        if (!n_on) return;
+        const unsigned ta = n_ta, tb = n_tb;
+        floatx4 t0, t1, t4;
+        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(t0) : "v"(ta) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(t1) : "v"(ta) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(t4) : "v"(tb) : "memory");
+        n_am[0] = t0; n_am[1] = t1; n_bb = t4;
+    };
+    auto norm_wait = [&]() {
+        u32x4 x0 = n_x;
+        floatx4 t0 = n_am[0], t1 = n_am[1], t4 = n_bb;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(t0), "+v"(t1), "+v"(t4) :: "memory");
+        n_x = x0; n_am[0] = t0; n_am[1] = t1; n_bb = t4;
+    };
+    auto norm_half = [&](auto hc) {   // values 4 hf .. 4 hf + 3 of the unit: gn_apply_kernel's arithmetic, two values per packed instruction
+        constexpr int hf = decltype(hc)::value;
+        if (!n_on) return;
+        Vec16<T> v;
+        v.raw = n_x;
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            const int e = 4 * hf + 2 * q2;
+            const f2 xx = {to_f(v.e[e]), to_f(v.e[e + 1])};
+            const f2 aa = {n_am[q2][0], n_am[q2][2]}, mu = {n_am[q2][1], n_am[q2][3]};
+            const f2 be = {n_bb[2 * q2], n_bb[2 * q2 + 1]};
+            f2 t = __builtin_elementwise_fma(xx - mu, aa, be);
+            if (p.nrm_silu) { t[0] = silu_f(t[0]); t[1] = silu_f(t[1]); }
+            n_o.e[e] = from_f<T>(t[0]);
+            n_o.e[e + 1] = from_f<T>(t[1]);
+        }
+    };
+    auto norm_store = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const unsigned ad = n_addr;
+        const u32x4 ov = n_o.raw;
+        if (n_on && pix[i] >= 0) asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(ov) : "memory");   // padding rows (zeros from the out-of-range fetch) stay zero
     };
 
     floatx16 acc[2][2];
@@ -275,6 +361,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[1], a1[1], b0[1], b1[1]);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NORM && t >= 2 && t <= 7) norm_issue(IC6<t - 2>{}, pnext);   // piece t - 2 of the next patch: landed since the previous k-tile's wait
         // lgkmcnt(0): this wave's reads of the current stage have RETURNED before the barrier lets others overwrite it
         if constexpr (CK == 2 && t == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else if constexpr (CK == 2 && t == 7) {   // younger than the previous k-tile's pieces: this k-tile's operand requests + its two weight pieces
@@ -290,7 +377,9 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[2], a1[2], b0[2], b1[2]);
+        if constexpr (NORM && t >= 2 && t <= 7) { __builtin_amdgcn_sched_barrier(0); norm_half(IC6<0>{}); norm_issue2(); __builtin_amdgcn_sched_barrier(0); }
         mma_group(a0[0], a1[0], b0[0], b1[0]);
+        if constexpr (NORM && t >= 2 && t <= 7) { __builtin_amdgcn_sched_barrier(0); norm_wait(); norm_half(IC6<1>{}); norm_store(IC6<t - 2>{}); }
         asm volatile("" ::: "memory");
         { const int x = bs_cur; bs_cur = bs_nxt; bs_nxt = bs_dst; bs_dst = x; }
         if constexpr (t == 8) { const int x = pcur; pcur = pnext; pnext = x; }
@@ -318,6 +407,12 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     fire_b(bs_cur, 0u);
     fire_b(bs_nxt, (unsigned)p.cin * (unsigned)sizeof(T));
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // the first patch and k-tile 0's weights
+    if constexpr (NORM) {
+        __syncthreads();                                      // the coefficient table (written in set_a) is visible
+        auto whole = [&](auto ic) { norm_issue(ic, pcur); norm_wait(); norm_half(IC6<0>{}); norm_issue2(); norm_wait(); norm_half(IC6<1>{}); norm_store(ic); };
+        whole(IC6<0>{}); whole(IC6<1>{}); whole(IC6<2>{}); whole(IC6<3>{}); whole(IC6<4>{}); whole(IC6<5>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     for (;;) {
@@ -340,46 +435,67 @@ static std::atomic<long> g_patch_launches{0};
 int device_cus();   // api.hip
 
 template <typename T> static int launch6(IgemmParams& p, int total, int grid, hipStream_t s) {
-    if (p.residual) hipLaunchKernelGGL((igemm6_kernel<T, true>), dim3(grid), dim3(512), 0, s, p, total);
-    else hipLaunchKernelGGL((igemm6_kernel<T, false>), dim3(grid), dim3(512), 0, s, p, total);
-    tag_kernel("igemm6_kernel<%s, %s>", std::is_same<T, f16>::value ? "_Float16" : "__bf16", p.residual ? "true" : "false");
+    if (p.nrm_ad) {
+        if (p.residual) hipLaunchKernelGGL((igemm6_kernel<T, true, true>), dim3(grid), dim3(512), 0, s, p, total);
+        else hipLaunchKernelGGL((igemm6_kernel<T, false, true>), dim3(grid), dim3(512), 0, s, p, total);
+    } else {
+        if (p.residual) hipLaunchKernelGGL((igemm6_kernel<T, true, false>), dim3(grid), dim3(512), 0, s, p, total);
+        else hipLaunchKernelGGL((igemm6_kernel<T, false, false>), dim3(grid), dim3(512), 0, s, p, total);
+    }
+    tag_kernel("igemm6_kernel<%s, %s, %s>", std::is_same<T, f16>::value ? "_Float16" : "__bf16", p.residual ? "true" : "false", p.nrm_ad ? "true" : "false");
     return check_launch("igemm6");
 }
 
-int launch_igemm_patch(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s) {
+static bool patch_eligible(int dtype, int mode, IgemmParams& p, int nz, int& grid_out, long& total_out) {
     using namespace patchk;
-    if (!option(E2EFT_OPT_PATCH_CONV) || !option(E2EFT_OPT_PERSISTENT)) return -1;
-    if (mode != 1 || nz != 1 || (dtype != E2EFT_F16 && dtype != E2EFT_BF16)) return -1;
-    if (p.ksplit_taps > 0 || p.bias_along_m) return -1;
-    if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.zins > 1) return -1;
+    if (!option(E2EFT_OPT_PATCH_CONV) || !option(E2EFT_OPT_PERSISTENT)) return false;
+    if (mode != 1 || nz != 1 || (dtype != E2EFT_F16 && dtype != E2EFT_BF16)) return false;
+    if (p.ksplit_taps > 0 || p.bias_along_m) return false;
+    if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.zins > 1) return false;
     const bool same = p.hl == p.hin && p.wl == p.win, up2 = p.hl == 2 * p.hin && p.wl == 2 * p.win;   // plain, or the exact 2x nearest upsample fused into the read
-    if (!(same || up2) || p.hout != p.hl || p.wout != p.wl) return -1;
-    if (p.wl % TW != 0 || p.hl % TH != 0) return -1;
-    if (p.cin % 64 != 0 || p.c1 % 64 != 0 || p.cin < 128 || p.K != 9 * p.cin) return -1;
-    if (p.N % 8 != 0 || p.ldo % 8 != 0 || (((uintptr_t)p.out) & 15) != 0) return -1;
-    if (p.ldx1 % 8 != 0 || (((uintptr_t)p.x1) & 15) != 0 || (p.x2 && (p.ldx2 % 8 != 0 || (((uintptr_t)p.x2) & 15) != 0))) return -1;
-    if (p.ldw % 8 != 0 || (((uintptr_t)p.w) & 15) != 0) return -1;
-    if (p.residual && (p.ldr % 8 != 0 || (((uintptr_t)p.residual) & 15) != 0)) return -1;
-    if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return -1;
-    if (p.rowadd && ((((uintptr_t)p.rowadd) & 15) != 0 || p.rows_per_img != p.hl * p.wl)) return -1;
+    if (!(same || up2) || p.hout != p.hl || p.wout != p.wl) return false;
+    if (p.wl % TW != 0 || p.hl % TH != 0) return false;
+    if (p.cin % 64 != 0 || p.c1 % 64 != 0 || p.cin < 128 || p.K != 9 * p.cin) return false;
+    if (p.nrm_ad && (p.x2 || p.cin > NORM_CMAX || p.N > BN || !option(E2EFT_OPT_FUSED_NORM))) return false;   // one N tile: every N tile would redo the normalisation
+    if (p.N % 8 != 0 || p.ldo % 8 != 0 || (((uintptr_t)p.out) & 15) != 0) return false;
+    if (p.ldx1 % 8 != 0 || (((uintptr_t)p.x1) & 15) != 0 || (p.x2 && (p.ldx2 % 8 != 0 || (((uintptr_t)p.x2) & 15) != 0))) return false;
+    if (p.ldw % 8 != 0 || (((uintptr_t)p.w) & 15) != 0) return false;
+    if (p.residual && (p.ldr % 8 != 0 || (((uintptr_t)p.residual) & 15) != 0)) return false;
+    if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return false;
+    if (p.rowadd && ((((uintptr_t)p.rowadd) & 15) != 0 || p.rows_per_img != p.hl * p.wl)) return false;
     const long img_bytes = (long)p.hin * p.win * (p.ldx1 > p.ldx2 ? p.ldx1 : p.ldx2) * 2;
-    if (img_bytes >= 0xD0000000L || (long)128 * p.ldw * 2 >= 0x40000000L) return -1;
-    if (p.M % (p.hl * p.wl) != 0) return -1;
+    if (img_bytes >= 0xD0000000L || (long)128 * p.ldw * 2 >= 0x40000000L) return false;
+    if (p.M % (p.hl * p.wl) != 0) return false;
     int cus = device_cus();
-    if (cus == 0) return -1;
+    if (cus == 0) return false;
     const int gopt = option(E2EFT_OPT_PERSISTENT_GRID);
     if (gopt >= 8 && gopt < cus) cus = gopt;
     const int mtiles = p.M / BM, ntiles = cdiv(p.N, BN);
     const long total = (long)mtiles * ntiles;
-    if (total < 2L * cus || total > 2000000000L || mtiles >= (1 << 22)) return -1;
+    if (total < 2L * cus || total > 2000000000L || mtiles >= (1 << 22)) return false;
     if (p.gn_partial) {
-        if (p.rows_per_img != p.hl * p.wl) return -1;
+        if (p.rows_per_img != p.hl * p.wl) return false;
         p.gn_nslabs = p.rows_per_img / BM;
     }
     p.mtiles = mtiles;
     p.ntiles = ntiles;
+    grid_out = cus;
+    total_out = total;
+    return true;
+}
+
+bool igemm_patch_eligible(int dtype, int mode, IgemmParams& p, int nz) {
+    int grid;
+    long total;
+    return patch_eligible(dtype, mode, p, nz, grid, total);
+}
+
+int launch_igemm_patch(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s) {
+    int grid;
+    long total;
+    if (!patch_eligible(dtype, mode, p, nz, grid, total)) return -1;
     g_patch_launches.fetch_add(1, std::memory_order_relaxed);
-    return dtype == E2EFT_F16 ? launch6<f16>(p, (int)total, cus, s) : launch6<bf16>(p, (int)total, cus, s);
+    return dtype == E2EFT_F16 ? launch6<f16>(p, (int)total, grid, s) : launch6<bf16>(p, (int)total, grid, s);
 }
 
 }  // namespace e2eft

@@ -272,6 +272,7 @@ static int gn_run(const E2eftGroupNormDesc* d, const GnGeom& g, const void* x1, 
     // the apply pass has its own work split: short slabs (two unrolled iterations of four 16-byte loads per thread) in many workgroups —
     // 0.414 ms instead of 0.472 ms on 8 x 768^2 x 128 fp16, 5.8 of the ~5.8 TB/s this part copies at (scripts/stream_bench.hip,
     // profiles/r02_stream_bench.txt); the statistics kernels keep the coarser split, their partials are per slab
+    if (!y) return check_launch("groupnorm_stats");   // statistics only: the consumer applies (x - mean) * a + beta itself (e2eft_conv2d_fwd_normed)
     GnGeom ga = g;
     ga.slab = g.pl * 8;
     ga.nslabs = (d->hw + ga.slab - 1) / ga.slab;
@@ -804,6 +805,27 @@ extern "C" int e2eft_groupnorm_fwd_pre(const E2eftGroupNormDesc* d, const void* 
     if (ws_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "groupnorm: workspace %zu < %zu", ws_bytes, need);
     E2EFT_REQUIRE(g.batch <= 65535 && g.nchb <= 65535, "groupnorm: grid");
     E2EFT_DISPATCH_DTYPE(d->dtype, T, return gn_run<T>(d, g, x1, x2, gamma, beta, y, partial1, nslabs1, d->c2 > 0 ? partial2 : nullptr, nslabs2,
+                                                      workspace, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" size_t e2eft_groupnorm_coeff_offset(const E2eftGroupNormDesc* d) {
+    if (gn_validate(d)) return 0;
+    return gn_ws_bytes(d) - ((size_t)d->batch * (d->c1 + d->c2) * 2 + (size_t)d->batch * d->groups) * sizeof(float);
+}
+
+extern "C" int e2eft_groupnorm_fwd_stats(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma, const float* partial1,
+                                         int32_t nslabs1, const float* partial2, int32_t nslabs2, void* workspace, size_t ws_bytes, void* stream) {
+    if (int e = gn_validate(d)) return e;
+    E2EFT_REQUIRE(x1 && workspace, "groupnorm_stats: null pointer");
+    E2EFT_REQUIRE(d->c2 == 0 || x2, "groupnorm_stats: x2 missing");
+    E2EFT_REQUIRE((!partial1 || nslabs1 > 0) && (!partial2 || nslabs2 > 0), "groupnorm_stats: precomputed statistics need a slab count");
+    GnGeom g;
+    gn_geom(d, g);
+    const size_t need = gn_ws_bytes(d);
+    if (ws_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "groupnorm_stats: workspace %zu < %zu", ws_bytes, need);
+    E2EFT_REQUIRE(g.batch <= 65535 && g.nchb <= 65535, "groupnorm_stats: grid");
+    E2EFT_DISPATCH_DTYPE(d->dtype, T, return gn_run<T>(d, g, x1, x2, gamma, nullptr, nullptr, partial1, nslabs1, d->c2 > 0 ? partial2 : nullptr, nslabs2,
                                                       workspace, (hipStream_t)stream));
     return 0;
 }

@@ -22,13 +22,14 @@ def packed_conv_weight(conv):
     return F.packed_conv_weight(conv, conv.weight.dtype)
 
 
-def conv_nhwc(conv, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0, pad=None, out=None, gn_stats=True):
+def conv_nhwc(conv, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0, pad=None, out=None, gn_stats=True, norm=None):
     """Run any nn.Conv2d-shaped module (weight/bias/stride/padding) on NHWC input through the implicit-GEMM kernel.
     Works for plain torch.nn.Conv2d objects too (training/util/unet_prep.py:6-20 swaps conv_in for one).  Differentiable:
     under autograd the backward runs e2eft_conv2d_dgrad / the wgrad GEMM (autograd.py)."""
     assert out is None
     # gn_stats: nearly every conv output of the path is consumed by a GroupNorm next; the epilogue then emits its statistics
-    return F.conv(conv, x, x2=x2, up_to=up_to, rowadd=rowadd, residual=residual, alpha=alpha, pad=pad, gn_stats=gn_stats)
+    # norm = (GroupNorm module, silu): conv(norm(x)); inference may never materialise norm(x) (ops.conv2d)
+    return F.conv(conv, x, x2=x2, up_to=up_to, rowadd=rowadd, residual=residual, alpha=alpha, pad=pad, gn_stats=gn_stats, norm=norm)
 
 
 def checkpointed(enabled, fn, *args):
@@ -118,15 +119,20 @@ class ResnetBlock2D(nn.Module):
 
     def nhwc(self, x, temb_act=None, x2=None):
         """x2: second source of a fused channel concat (skip connection, unet_2d_blocks.py:2328,2456)."""
-        if x2 is None:
-            h, x = self.norm1.nhwc(x, silu=True, split=True)     # x: the same tensor, routed through the norm for its gradient
-        else:
-            h = self.norm1.nhwc(x, x2=x2, silu=True)
         rowadd = self.__dict__.pop("_rowadd_pre", None)     # inference: projected for all blocks at once (unet.py::_batch_small_gemms)
         if torch.is_grad_enabled():
             rowadd = None                                    # never under autograd: the slice carries no graph
         if rowadd is None and self.time_emb_proj is not None:
             rowadd = self.time_emb_proj(temb_act)
+        if not torch.is_grad_enabled() and x2 is None:
+            # inference: conv(SiLU(GroupNorm(.))) as ONE op — where the library can, the normalised tensor never exists (ops.conv2d, norm=)
+            h = conv_nhwc(self.conv1, x, rowadd=rowadd, norm=(self.norm1, True))
+            sc = conv_nhwc(self.conv_shortcut, x) if self.conv_shortcut is not None else x
+            return conv_nhwc(self.conv2, h, residual=sc, norm=(self.norm2, True))
+        if x2 is None:
+            h, x = self.norm1.nhwc(x, silu=True, split=True)     # x: the same tensor, routed through the norm for its gradient
+        else:
+            h = self.norm1.nhwc(x, x2=x2, silu=True)
         h = conv_nhwc(self.conv1, h, rowadd=rowadd)
         h = self.norm2.nhwc(h, silu=True)
         if self.conv_shortcut is not None:

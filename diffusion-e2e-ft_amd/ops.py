@@ -227,10 +227,12 @@ def _attach_stats(out, buf, slab_rows, images, rows_per_image, cout):
 
 # ---------------------------------------------------------------------------------------------------------
 def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None, up_to=None, rowadd=None,
-           residual=None, alpha=1.0, out=None, gn_stats=False):
+           residual=None, alpha=1.0, out=None, gn_stats=False, norm=None):
     """Implicit-GEMM convolution. x: [B,H,W,C1] (C1 % epc == 0), x2: optional [B,H,W,C2] fused channel concat,
     w_packed: [cout, ldw] rows = (ky,kx,c) K-contiguous, pad = (top, bottom, left, right), up_to=(hl,wl) fused
-    nearest upsample, rowadd: [B,cout] per-image vector added before alpha, residual: [B,hout,wout,cout]."""
+    nearest upsample, rowadd: [B,cout] per-image vector added before alpha, residual: [B,hout,wout,cout].
+    norm = (gamma, beta, groups, eps, silu): the convolution of GroupNorm(+SiLU)(x) — where the library can (e2eft_conv2d_fwd_normed_supported) the
+    norm is never applied as a pass of its own: its statistics are finalised and the convolution reads x through them; otherwise groupnorm() runs first."""
     _check_cuda(x, w_packed, x2, bias, rowadd, residual, out)
     B, H, W, c1 = x.shape
     hl, wl = (H, W) if up_to is None else up_to
@@ -265,11 +267,27 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
     want = gn_stats and GN_STATS_ENABLED and cout % 8 == 0
     es = x.element_size()
     nb = (B * H * W * (d.c1 + d.c2) + B * hout * wout * cout * (2 if residual is not None else 1) + cout * kh * kw * (d.c1 + d.c2)) * es
+    lib = _lib.load()
+    sk = lib.e2eft_conv2d_splitk_workspace_bytes(C.byref(d)) if SPLITK_ENABLED else 0
+    coeff = None
+    if norm is not None:
+        gamma, beta, groups, eps, silu = norm
+        if NORM_FUSION_ENABLED and x2 is None and not sk and lib.e2eft_conv2d_fwd_normed_supported(C.byref(d)) == 1:
+            ws, coeff = groupnorm_stats(x, gamma, groups, eps)     # (a, mean) pairs; the apply pass is the convolution's operand fetch
+        else:
+            x = groupnorm(x, gamma, beta, groups, eps, silu=silu)
+            d.ldx1 = _nhwc_ld(x)
     with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2), nb,
-                label="conv%dx%ds%d%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", B, hout, wout, d.c1 + d.c2, cout)):
-        lib = _lib.load()
-        sk = lib.e2eft_conv2d_splitk_workspace_bytes(C.byref(d)) if SPLITK_ENABLED else 0
-        if sk:   # few output tiles, long reduction: split-K (the consumer GroupNorm computes its own statistics)
+                label="conv%dx%ds%d%s%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", "n" if coeff is not None else "", B, hout, wout, d.c1 + d.c2, cout)):
+        if coeff is not None:
+            buf, nbytes = _gn_buffer(B, hout * wout, cout, x.device) if want else (None, 0)
+            slab = C.c_int32(0)
+            check(lib.e2eft_conv2d_fwd_normed(C.byref(d), _ptr(x), C.c_void_p(coeff), _ptr(beta), 1 if silu else 0, _ptr(w_packed), _ptr(bias), _ptr(rowadd),
+                                              _ptr(residual), _ptr(out), _ptr(buf), nbytes, C.byref(slab), _stream()))
+            if want:
+                _attach_stats(out, buf, slab.value, B, hout * wout, cout)
+            out._e2eft_keep = ws            # (the coefficient workspace lives as long as the launch may: stream-ordered free after the output)
+        elif sk:   # few output tiles, long reduction: split-K (the consumer GroupNorm computes its own statistics)
             ws = torch.empty(sk // x.element_size(), dtype=x.dtype, device=x.device)
             check(lib.e2eft_conv2d_fwd_splitk(C.byref(d), _ptr(x), _ptr(x2), _ptr(w_packed), _ptr(bias), _ptr(rowadd), _ptr(residual), _ptr(out),
                                               _ptr(ws), sk, _stream()))
@@ -403,6 +421,30 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None):
                                           _ptr(s1.partial) if s1 else C.c_void_p(0), s1.nslabs if s1 else 0,
                                           _ptr(s2.partial) if s2 else C.c_void_p(0), s2.nslabs if s2 else 0, _ptr(ws), nbytes, _stream()))
     return out
+
+
+NORM_FUSION_ENABLED = True    # conv2d(norm=...): GroupNorm(+SiLU) applied inside the consuming convolution where the library supports it
+
+
+def groupnorm_stats(x, gamma, groups, eps):
+    """The statistics half of groupnorm() alone -> (workspace, device address of the fp32 (a, mean) pairs [B][C][2] inside it)."""
+    _check_cuda(x, gamma)
+    B, H, W, c1 = x.shape
+    d = GroupNormDesc()
+    d.dtype = dtype_id(x.dtype)
+    d.batch, d.hw = B, H * W
+    d.c1, d.ldx1, d.c2, d.ldx2 = c1, _nhwc_ld(x), 0, 0
+    d.groups, d.ldy, d.silu, d.eps = groups, c1, 0, eps
+    lib = _lib.load()
+    nbytes = lib.e2eft_groupnorm_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError("groupnorm_stats: %s" % lib.e2eft_last_error().decode())
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    s1 = getattr(x, "_e2eft_gn", None) if GN_STATS_ENABLED else None
+    with _timed("groupnorm_stats", 0.0, 0.0, label="gn stats B%d %dx%d C%d" % (B, H, W, c1)):
+        check(lib.e2eft_groupnorm_fwd_stats(C.byref(d), _ptr(x), C.c_void_p(0), _ptr(gamma), _ptr(s1.partial) if s1 else C.c_void_p(0), s1.nslabs if s1 else 0,
+                                            C.c_void_p(0), 0, _ptr(ws), nbytes, _stream()))
+    return ws, ws.data_ptr() + lib.e2eft_groupnorm_coeff_offset(C.byref(d))
 
 
 def layernorm(x, gamma, beta, eps, out=None):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define E2EFT_VERSION 114 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
+#define E2EFT_VERSION 115 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
 
 enum {
     E2EFT_OK = 0,
@@ -59,7 +59,8 @@ enum {
     E2EFT_OPT_IGEMM2_WAVES = 5,      /* 0 (default): 8-wave 256-row tiles when >= 128 of them exist (fp32: 256), else 4-wave 128-row; 4 / 8: forced */
     E2EFT_OPT_PATCH_CONV = 6,        /* 1 (default): big 16-bit 3x3 / stride-1 / pad-1 convolutions on the halo-patch kernel (igemm6); 0: igemm5 */
     E2EFT_OPT_THIN_INPUT_CONV = 7,   /* 1 (default): big 16-bit 3x3 / stride-1 / pad-1 convolutions with EIGHT input channels on convin.hip; 0: igemm2 */
-    E2EFT_OPT_COUNT = 8
+    E2EFT_OPT_FUSED_NORM = 8,        /* 1 (default): e2eft_conv2d_fwd_normed_supported may answer 1; 0: it answers 0 (GroupNorm applied by its own pass) */
+    E2EFT_OPT_COUNT = 9
 };
 int e2eft_set_option(int32_t key, int32_t value);
 int e2eft_get_option(int32_t key);
@@ -130,6 +131,17 @@ int e2eft_gemm(const E2eftGemmDesc* d, const void* a, const void* w, const void*
 int e2eft_conv2d_fwd_gnstats(const E2eftConvDesc* d, const void* x1, const void* x2, const void* w, const void* bias,
                              const void* rowadd, const void* residual, void* out, float* gn_partial,
                              size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
+/* out = conv(act(GroupNorm(x1))) [+ ...]: e2eft_conv2d_fwd_gnstats whose input is read THROUGH a GroupNorm(+SiLU) that was never applied — the
+ * GroupNorm -> SiLU -> conv3x3 pairs of ResnetBlock2D (resnet.py: norm1 / conv1, norm2 / conv2) without the normalised tensor's round trip through
+ * HBM.  coeff: the (a, mean) pairs of e2eft_groupnorm_fwd_stats for x1 ([batch][c1][2] fp32), beta: the norm's bias [c1] or NULL, silu != 0: SiLU.
+ * The values that enter the convolution are those e2eft_groupnorm_fwd would have written (same arithmetic, same rounding to the 16-bit type), so the
+ * result equals e2eft_groupnorm_fwd followed by e2eft_conv2d_fwd_gnstats bit for bit.  Served by the halo-patch kernel only (inference): ask
+ * e2eft_conv2d_fwd_normed_supported(d) (pure host arithmetic; 1 = yes) before skipping the apply pass — 16-bit, 3x3 / stride 1 / pad 1, one source,
+ * 128 <= c1 <= 640, cout <= 128, width % 32 == 0, height % 8 == 0, at least two 256-pixel tiles per CU; otherwise E2EFT_ERR_UNSUPPORTED. */
+int e2eft_conv2d_fwd_normed_supported(const E2eftConvDesc* d);
+int e2eft_conv2d_fwd_normed(const E2eftConvDesc* d, const void* x1, const float* coeff, const void* beta, int32_t silu, const void* w,
+                            const void* bias, const void* rowadd, const void* residual, void* out, float* gn_partial,
+                            size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
 /* Split-K variant for convolutions with few output tiles and a long reduction (the 9x9 - 24x24 UNet layers: M = B*H*W ~ 10^3,
  * K = 9*Cin up to 23040): the reduction is split by rows of filter taps across workgroups, partial sums go to `workspace`, a finish
  * pass applies bias / rowadd / alpha / residual.  e2eft_conv2d_splitk_workspace_bytes returns 0 when the library would not split. */
@@ -165,6 +177,12 @@ int e2eft_groupnorm_fwd(const E2eftGroupNormDesc* d, const void* x1, const void*
 int e2eft_groupnorm_fwd_pre(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma,
                             const void* beta, void* y, const float* partial1, int32_t nslabs1, const float* partial2,
                             int32_t nslabs2, void* workspace, size_t ws_bytes, void* stream);
+/* The statistics half of e2eft_groupnorm_fwd_pre alone: leaves, inside the workspace at byte offset e2eft_groupnorm_coeff_offset(d), the fp32 pairs
+ * (a = gamma * rstd, mean) [batch][c1 + c2][2] that the apply pass would use (y = (x - mean) * a + beta), and applies nothing: the consumer does
+ * (e2eft_conv2d_fwd_normed).  Same workspace size, same arguments. */
+size_t e2eft_groupnorm_coeff_offset(const E2eftGroupNormDesc* d);
+int e2eft_groupnorm_fwd_stats(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma, const float* partial1,
+                              int32_t nslabs1, const float* partial2, int32_t nslabs2, void* workspace, size_t ws_bytes, void* stream);
 
 /* LayerNorm over the last dim of [rows, c] (row stride ldx / ldy), eps, affine.
  * Replaces nn.LayerNorm norm1/2/3 of BasicTransformerBlock (attention.py:205,237,264). */

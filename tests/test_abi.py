@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "libe2eft.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.e2eft_version() == 114
+    assert lib.e2eft_version() == 115
 
 
 def test_options_are_the_only_global_state_and_the_library_never_reads_the_environment():

@@ -1,0 +1,90 @@
+"""e2eft_conv2d_fwd_normed (igemm6.hip, NORM variant): conv3x3(SiLU(GroupNorm(x))) with the norm applied inside the convolution's operand fetch must
+equal GroupNorm followed by the same convolution BIT FOR BIT (same arithmetic, same rounding of the normalised values), and torch CPU fp64 within the
+16-bit tolerance: 2 / 3 / 5 channel chunks, with and without SiLU / beta / bias / row vector / residual, several images per workgroup (the coefficient
+table in LDS is refilled at image changes), one tile row per image (padding rows above and below must stay zero AFTER the affine map), both dtypes,
+statistics of the output; shapes the fused route does not take (cout > 128, two sources) must fall back to the two-pass route inside ops.conv2d.
+Subprocess + 8-workgroup grid as tests/test_patch_conv_gpu.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SCRIPT = r'''
+import sys, os
+sys.path.insert(0, os.path.join(%r, ".."))
+sys.path.insert(0, %r)
+import ctypes
+import torch
+import torch.nn.functional as F
+from diffusion_e2e_ft_amd import ops, _lib
+from util import nhwc, to_nchw, pack_conv_weight, q, rel_err, TOL
+dev = torch.device("cuda:0")
+lib = _lib.load()
+_lib.set_option(_lib.OPT_PERSISTENT_GRID, 8)
+lib.e2eft_debug_patch_launches.restype = ctypes.c_long
+worst = 0.0
+# B, H, W, C, Co, silu, beta, bias, rowadd, residual, fused
+cases = [
+    (2, 32, 64, 128, 128, True, True, True, False, False, True),
+    (4, 32, 32, 192, 128, True, True, True, True, True, True),      # 3 chunks, four images, row vector + residual
+    (17, 8, 32, 128, 64, True, True, False, False, True, True),     # one tile = one image: table refilled every tile; cout 64
+    (5, 8, 512, 320, 128, False, False, True, False, False, True),  # no SiLU, no beta, 5 chunks, one tile row (top and bottom padding everywhere); enough tiles that the host does not split K
+    (2, 32, 64, 128, 256, True, True, True, False, False, False),   # cout 256: two N tiles -> the two-pass route
+]
+for dtype in (torch.float16, torch.bfloat16):
+    for (B, H, W, Cc, Co, silu, hbeta, hb, ra, rs, fused) in cases:
+        g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cc + Co + W)
+        x = q(torch.randn(B, Cc, H, W, generator=g) * 2.0 + 0.7, dtype)
+        gamma = q(torch.randn(Cc, generator=g) * 0.3 + 1.0, dtype)
+        beta = q(torch.randn(Cc, generator=g) * 0.5, dtype) if hbeta else None
+        w = q(torch.randn(Co, Cc, 3, 3, generator=g) / (Cc * 9) ** 0.5, dtype)
+        b = q(torch.randn(Co, generator=g), dtype) if hb else None
+        rav = q(torch.randn(B, Co, generator=g), dtype) if ra else None
+        xd = nhwc(x, dtype, dev)
+        gd, bd = gamma.to(dtype).to(dev), (None if beta is None else beta.to(dtype).to(dev))
+        wd, biasd = pack_conv_weight(w, dtype, dev), (None if b is None else b.to(dtype).to(dev))
+        rad = None if rav is None else rav.to(dtype).to(dev)
+        rsd = nhwc(q(torch.randn(B, Co, H, W, generator=g), dtype), dtype, dev) if rs else None
+        # two passes: GroupNorm(+SiLU), then the convolution (igemm6 where eligible)
+        hn = ops.groupnorm(xd, gd, bd, 32, 1e-5, silu=silu)
+        y2 = ops.conv2d(hn, wd, biasd, Co, 3, 3, 1, (1, 1, 1, 1), rowadd=rad, residual=rsd, gn_stats=True)
+        n0 = lib.e2eft_debug_patch_launches()
+        y1 = ops.conv2d(xd, wd, biasd, Co, 3, 3, 1, (1, 1, 1, 1), rowadd=rad, residual=rsd, gn_stats=True, norm=(gd, bd, 32, 1e-5, silu))
+        torch.cuda.synchronize()
+        label = getattr(y1, "_e2eft_keep", None) is not None
+        assert label == fused, (label, fused)
+        assert lib.e2eft_debug_patch_launches() - n0 == 1
+        same = torch.equal(y1, y2)
+        st = torch.equal(y1._e2eft_gn.partial, y2._e2eft_gn.partial)
+        ref = F.group_norm(x.double(), 32, gamma.double(), None if beta is None else beta.double(), 1e-5)
+        if silu:
+            ref = F.silu(ref)
+        ref = F.conv2d(q(ref.float(), dtype).double(), w.double(), None if b is None else b.double(), padding=1).float()
+        if rav is not None:
+            ref = ref + rav[:, :, None, None]
+        if rsd is not None:
+            ref = ref + to_nchw(rsd).float()
+        e = rel_err(to_nchw(y1), ref)
+        print("%%s norm-conv %%s fused=%%d bit-equal=%%d stats-equal=%%d rel err %%.2e" %% (str(dtype)[6:], (B, H, W, Cc, Co, silu), fused, same, st, e), flush=True)
+        assert same and st
+        assert e <= 2.0 * TOL[dtype], e      # (the reference rounds the normalised tensor once more than fp64 would: 2x the conv tolerance)
+        worst = max(worst, e / TOL[dtype])
+# the option switches the route off
+_lib.set_option(_lib.OPT_FUSED_NORM, 0)
+x = nhwc(q(torch.randn(2, 128, 32, 64), torch.float16), torch.float16, dev)
+w = pack_conv_weight(q(torch.randn(128, 128, 3, 3) / 34.0, torch.float16), torch.float16, dev)
+ga = torch.ones(128, device=dev).half()
+y = ops.conv2d(x, w, None, 128, 3, 3, 1, (1, 1, 1, 1), norm=(ga, None, 32, 1e-5, True))
+assert getattr(y, "_e2eft_keep", None) is None
+print("FUSED NORM CASES PASSED worst %%.2f of tolerance" %% worst)
+''' % (HERE, HERE)
+
+
+def test_fused_groupnorm_conv(dev):
+    r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=dict(os.environ), timeout=600)
+    print(r.stdout[-6000:])
+    assert r.returncode == 0 and "FUSED NORM CASES PASSED" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
