@@ -45,7 +45,7 @@ constexpr int DEP = NW * 64 * 3 * 4;
 constexpr int OFF_DUMP = OFF_DEP + DEP;
 constexpr int LDS = OFF_DUMP + NW * 1024;                               // 151,552 B
 constexpr int NORM_CMAX = 640;                                          // NORM: input channels the (a, mean, beta) table of one image holds
-constexpr int OFF_TAB = LDS, OFF_TABB = OFF_TAB + NORM_CMAX * 8;
+constexpr int OFF_TAB = LDS, OFF_TABM = OFF_TAB + NORM_CMAX * 4, OFF_TABB = OFF_TABM + NORM_CMAX * 4;   // a[C], mean[C], beta[C] (fp32) of the loader's image
 constexpr int LDS_NORM = OFF_TABB + NORM_CMAX * 4;                      // 159,232 B
 constexpr unsigned int OOB = 0xF0000000u;
 constexpr unsigned int RECORDS = 0xE0000000u;
@@ -148,10 +148,11 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
             if (valid && d_img != tab_img) {   // (uniform, once per image and workgroup) nobody reads the table between k-tile 8 of a chunk and k-tile 2 of the next
                 tab_img = d_img;
                 float* ta = reinterpret_cast<float*>(smem + OFF_TAB);
+                float* tm = reinterpret_cast<float*>(smem + OFF_TABM);
                 float* tb = reinterpret_cast<float*>(smem + OFF_TABB);
                 for (int c = tid; c < p.cin; c += 512) {
-                    ta[2 * c] = p.nrm_ad[((long)d_img * p.cin + c) * 2];
-                    ta[2 * c + 1] = p.nrm_ad[((long)d_img * p.cin + c) * 2 + 1];
+                    ta[c] = p.nrm_ad[((long)d_img * p.cin + c) * 2];
+                    tm[c] = p.nrm_ad[((long)d_img * p.cin + c) * 2 + 1];
                     tb[c] = p.nrm_beta ? to_f(((const T*)p.nrm_beta)[c]) : 0.f;
                 }
             }
@@ -195,9 +196,9 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     // covers them —, four values are computed behind each of the last two MFMA groups, then the unit is written back.  Inline-asm DS instructions
     // (in front of LDS accesses it can see the compiler may drain vmcnt: pieces are in flight by design).
     u32x4 n_x;
-    floatx4 n_am[2], n_bb;      // coefficients of four channels at a time: (a, mean) pairs, betas
-    Vec16<T> n_o;
-    unsigned n_addr = 0, n_ta = 0, n_tb = 0;
+    floatx4 n_a, n_m, n_b;      // coefficients of four channels at a time: a, mean, beta (natural register pairs for the packed fp32 instructions)
+    u32x4 n_o;
+    unsigned n_addr = 0, n_t = 0;
     bool n_on = false;
     auto norm_issue = [&](auto ic, const int pbuf) {   // the patch unit and the coefficients of its first four channels
         constexpr int i = decltype(ic)::value;
@@ -205,53 +206,56 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         n_on = j < PPIECES;                                          // (wave-uniform)
         if (!n_on) return;
         n_addr = lds_base + (unsigned)(pbuf + j * 1024) + (unsigned)lane * 16u;
-        n_ta = lds_base + (unsigned)OFF_TAB + (unsigned)n_c0 * 8u;
-        n_tb = lds_base + (unsigned)OFF_TABB + (unsigned)n_c0 * 4u;
-        const unsigned ad = n_addr, ta = n_ta, tb = n_tb;
+        n_t = lds_base + (unsigned)OFF_TAB + (unsigned)n_c0 * 4u;
+        const unsigned ad = n_addr, ta = n_t;
         u32x4 x0;
-        floatx4 t0, t1, t4;     // (asm outputs into locals: clang does not capture variables that appear only as asm operands of a nested generic lambda)
+        floatx4 t0, t1, t2;     // (asm outputs into locals: clang does not capture variables that appear only as asm operands of a nested generic lambda)
         asm volatile("ds_read_b128 %0, %1" : "=v"(x0) : "v"(ad) : "memory");
         asm volatile("ds_read_b128 %0, %1" : "=v"(t0) : "v"(ta) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(t1) : "v"(ta) : "memory");
-        asm volatile("ds_read_b128 %0, %1" : "=v"(t4) : "v"(tb) : "memory");
-        n_x = x0; n_am[0] = t0; n_am[1] = t1; n_bb = t4;
+        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(t1) : "v"(ta), "n"(NORM_CMAX * 4) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(t2) : "v"(ta), "n"(NORM_CMAX * 8) : "memory");
+        n_x = x0; n_a = t0; n_m = t1; n_b = t2;
     };
     auto norm_issue2 = [&]() {   // the coefficients of the unit's last four channels (into the registers the first half is done with)
         if (!n_on) return;
-        const unsigned ta = n_ta, tb = n_tb;
-        floatx4 t0, t1, t4;
-        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(t0) : "v"(ta) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(t1) : "v"(ta) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(t4) : "v"(tb) : "memory");
-        n_am[0] = t0; n_am[1] = t1; n_bb = t4;
+        const unsigned ta = n_t;
+        floatx4 t0, t1, t2;
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(t0) : "v"(ta) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(t1) : "v"(ta), "n"(NORM_CMAX * 4 + 16) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(t2) : "v"(ta), "n"(NORM_CMAX * 8 + 16) : "memory");
+        n_a = t0; n_m = t1; n_b = t2;
     };
     auto norm_wait = [&]() {
         u32x4 x0 = n_x;
-        floatx4 t0 = n_am[0], t1 = n_am[1], t4 = n_bb;
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(t0), "+v"(t1), "+v"(t4) :: "memory");
-        n_x = x0; n_am[0] = t0; n_am[1] = t1; n_bb = t4;
+        floatx4 t0 = n_a, t1 = n_m, t2 = n_b;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(t0), "+v"(t1), "+v"(t2) :: "memory");
+        n_x = x0; n_a = t0; n_m = t1; n_b = t2;
     };
-    auto norm_half = [&](auto hc) {   // values 4 hf .. 4 hf + 3 of the unit: gn_apply_kernel's arithmetic, two values per packed instruction
+    auto norm_half = [&](auto hc) {   // values 4 hf .. 4 hf + 3 of the unit: gn_apply_kernel's arithmetic (norm.hip) on natural fp32 pairs — packed sub / fma / mul / add, one v_exp + one v_rcp per value, one packed convert per pair
         constexpr int hf = decltype(hc)::value;
         if (!n_on) return;
+        typedef T T2 __attribute__((ext_vector_type(2)));
         Vec16<T> v;
         v.raw = n_x;
 #pragma unroll
         for (int q2 = 0; q2 < 2; ++q2) {
             const int e = 4 * hf + 2 * q2;
             const f2 xx = {to_f(v.e[e]), to_f(v.e[e + 1])};
-            const f2 aa = {n_am[q2][0], n_am[q2][2]}, mu = {n_am[q2][1], n_am[q2][3]};
-            const f2 be = {n_bb[2 * q2], n_bb[2 * q2 + 1]};
+            const f2 aa = {n_a[2 * q2], n_a[2 * q2 + 1]}, mu = {n_m[2 * q2], n_m[2 * q2 + 1]}, be = {n_b[2 * q2], n_b[2 * q2 + 1]};
             f2 t = __builtin_elementwise_fma(xx - mu, aa, be);
-            if (p.nrm_silu) { t[0] = silu_f(t[0]); t[1] = silu_f(t[1]); }
-            n_o.e[e] = from_f<T>(t[0]);
-            n_o.e[e + 1] = from_f<T>(t[1]);
+            if (p.nrm_silu) {   // silu_f (common.h): t * rcp(1 + exp2(-log2(e) * t)).  The constant operands stay scalar instructions: a packed form would
+                                // broadcast them with op_sel — the operand-swizzle family of DESIGN.md §3.6; sub / fma / the last mul run on natural pairs
+                const float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[0] * -1.4426950408889634f));
+                const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[1] * -1.4426950408889634f));
+                t = t * f2{r0, r1};
+            }
+            n_o[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, T2));
         }
     };
     auto norm_store = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const unsigned ad = n_addr;
-        const u32x4 ov = n_o.raw;
+        const u32x4 ov = n_o;
         if (n_on && pix[i] >= 0) asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(ov) : "memory");   // padding rows (zeros from the out-of-range fetch) stay zero
     };
 
