@@ -95,7 +95,9 @@ static int run_igemm(int dtype, int mode, IgemmParams& p, int nz, void* stream) 
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-int launch_conv3x3_narrow(const E2eftConvDesc* d, const void* x1, const void* w, const void* bias, void* out, void* stream);   // narrow.hip
+int launch_conv3x3_narrow(const E2eftConvDesc* d, const void* x1, const void* w, const void* bias, void* out, void* stream, const float* nrm_ad = nullptr,
+                          const void* nrm_beta = nullptr, int nrm_silu = 0);   // narrow.hip
+bool conv3x3_narrow_eligible(const E2eftConvDesc* d, bool normed);
 
 }  // namespace e2eft
 
@@ -146,6 +148,7 @@ extern "C" int e2eft_conv2d_fwd_normed(const E2eftConvDesc* d, const void* x1, c
 extern "C" int e2eft_conv2d_fwd_normed_supported(const E2eftConvDesc* d) {
     if (!d || d->c2 != 0 || d->dtype < 1 || d->dtype > 2 || !option(E2EFT_OPT_FUSED_NORM)) return 0;
     if (d->batch <= 0 || d->hin <= 0 || d->win <= 0 || d->cout <= 0 || d->c1 <= 0) return 0;
+    if (conv3x3_narrow_eligible(d, true)) return 1;   // conv_norm_out -> conv_out
     IgemmParams p = {};
     void* const al = (void*)(uintptr_t)256;
     p.x1 = al; p.w = al; p.out = al; p.nrm_ad = (const float*)al;
@@ -181,8 +184,8 @@ static int conv2d_core(const E2eftConvDesc* d, const void* x1, const void* x2, c
     // the last output row/col must read at least one in-range tap row/col origin
     E2EFT_REQUIRE((d->hout - 1) * d->stride - d->pad_t < d->hl && (d->wout - 1) * d->stride - d->pad_l < d->wl, "conv2d: output larger than padded input");
 
-    if (!x2 && !rowadd && !residual && !gn_partial && !workspace && !norm) {   // <= 4 output channels: LDS-halo dot-product kernel instead of a 128-wide MFMA tile
-        const int rn = launch_conv3x3_narrow(d, x1, w, bias, out, stream);
+    if (!x2 && !rowadd && !residual && !gn_partial && !workspace) {   // <= 4 output channels: LDS-halo kernel instead of a 128-wide MFMA tile
+        const int rn = norm ? launch_conv3x3_narrow(d, x1, w, bias, out, stream, norm->ad, norm->beta, norm->silu) : launch_conv3x3_narrow(d, x1, w, bias, out, stream);
         if (rn >= 0) return rn;
     }
 

@@ -34,6 +34,9 @@ struct NarrowParams {
     void* out;          // [B][H][W][ldo]
     int H, W, cin, ldx, ldw, cout, ldo, tiles_x, tiles_y;
     float alpha;
+    const float* nrm_ad;   // optional (MFMA form): the input is read through GroupNorm(+SiLU) — (a, mean) pairs [image][cin][2] of e2eft_groupnorm_fwd_stats,
+    const void* nrm_beta;  // the norm's beta [cin] or null; value = (x - mean) * a + beta, then SiLU if nrm_silu: gn_apply_kernel's arithmetic (norm.hip)
+    int nrm_silu;
 };
 
 // grid (tiles_x * tiles_y, B), block 256 (thread = output pixel (ty, tx) of the tile).  The weights are wave-uniform: they are read with
@@ -144,16 +147,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_narrow_mfma_kernel(const Narro
                 const bool ok = wrow && sl * 32 < nch;
                 bf[tap][sl] = ok ? *reinterpret_cast<const u32x4*>(wg + (long)m * p.ldw + (long)tap * p.cin + c0 + sl * 32 + kq * 8) : u32x4{0u, 0u, 0u, 0u};
             }
+        // fused GroupNorm(+SiLU) of the input: a thread stages the same 8-channel group (tid & 7) of every pixel it handles, so its 24 coefficients
+        // are loaded once per chunk; the staged value is what e2eft_groupnorm_fwd would have written (padding stays zero)
+        float na[8], nm[8], nb[8];
+        const bool nrm = p.nrm_ad != nullptr && (tid & 7) < ngr;
+        if (nrm) {
+            const int c = c0 + (tid & 7) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                na[e] = p.nrm_ad[((long)blockIdx.y * p.cin + c + e) * 2];
+                nm[e] = p.nrm_ad[((long)blockIdx.y * p.cin + c + e) * 2 + 1];
+                nb[e] = p.nrm_beta ? to_f(((const T*)p.nrm_beta)[c + e]) : 0.f;
+            }
+        }
         __syncthreads();                              // the previous chunk is consumed
         for (int i = tid; i < NR_H * NR_H * 8; i += 256) {
             const int g = i & 7, pix = i >> 3;
             if (g >= ngr) continue;
             const int hy = pix / NR_H, hx = pix - hy * NR_H;
             const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                v = *reinterpret_cast<const u32x4*>(xb + ((long)iy * p.W + ix) * p.ldx + c0 + g * 8);
-            *reinterpret_cast<u32x4*>(halo + pix * NR_PIX + g * 16) = v;
+            Vec16<T> v;
+            v.raw = u32x4{0u, 0u, 0u, 0u};
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                v.raw = *reinterpret_cast<const u32x4*>(xb + ((long)iy * p.W + ix) * p.ldx + c0 + g * 8);
+                if (nrm) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = fmaf(to_f(v.e[e]) - nm[e], na[e], nb[e]);
+                        if (p.nrm_silu) t = silu_f(t);
+                        v.e[e] = from_f<T>(t);
+                    }
+                }
+            }
+            *reinterpret_cast<u32x4*>(halo + pix * NR_PIX + g * 16) = v.raw;
         }
         __syncthreads();
 #pragma unroll
@@ -200,15 +226,23 @@ template <typename T> static void launch_narrow_t(const NarrowParams& p, dim3 gr
 }
 
 // returns -1 when the problem is not this kernel's (the caller then runs the implicit-GEMM path), else the launch status
-int launch_conv3x3_narrow(const E2eftConvDesc* d, const void* x1, const void* w, const void* bias, void* out, void* stream) {
-    if (!option(E2EFT_OPT_NARROW_CONV)) return -1;
-    if (d->dtype != E2EFT_F16 && d->dtype != E2EFT_BF16) return -1;
-    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->c2 != 0) return -1;
-    if (d->cout < 1 || d->cout > NR_CO || d->hl != d->hin || d->wl != d->win || d->hout != d->hin || d->wout != d->win) return -1;
-    if (d->c1 % 8 != 0 || d->ldx1 % 8 != 0 || d->ldw % 8 != 0 || ((uintptr_t)x1 & 15) || ((uintptr_t)w & 15)) return -1;
-    if ((long)d->batch * d->hout * d->wout < 16384) return -1;   // tiny problems: launch-bound either way, keep one code path
-    if (d->c1 > 128) return -1;   // measured: 320 -> 4 at 8 x 96^2 is 0.098 ms here vs 0.087 ms on the MFMA tile (five halo chunks per tile)
+bool conv3x3_narrow_eligible(const E2eftConvDesc* d, bool normed) {   // the descriptor's part of the test (pointers: 16-byte aligned)
+    if (!option(E2EFT_OPT_NARROW_CONV)) return false;
+    if (d->dtype != E2EFT_F16 && d->dtype != E2EFT_BF16) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->c2 != 0) return false;
+    if (d->cout < 1 || d->cout > NR_CO || d->hl != d->hin || d->wl != d->win || d->hout != d->hin || d->wout != d->win) return false;
+    if (d->c1 % 8 != 0 || d->ldx1 % 8 != 0 || d->ldw % 8 != 0) return false;
+    if ((long)d->batch * d->hout * d->wout < 16384) return false;   // tiny problems: launch-bound either way, keep one code path
+    if (d->c1 > 128) return false;   // measured: 320 -> 4 at 8 x 96^2 is 0.098 ms here vs 0.087 ms on the MFMA tile (five halo chunks per tile)
+    if (normed && !(option(E2EFT_OPT_NARROW_MFMA) && d->c1 % 32 == 0 && option(E2EFT_OPT_FUSED_NORM))) return false;   // the fused norm lives in the MFMA form
+    return true;
+}
+
+int launch_conv3x3_narrow(const E2eftConvDesc* d, const void* x1, const void* w, const void* bias, void* out, void* stream, const float* nrm_ad,
+                          const void* nrm_beta, int nrm_silu) {
+    if (!conv3x3_narrow_eligible(d, nrm_ad != nullptr) || ((uintptr_t)x1 & 15) || ((uintptr_t)w & 15)) return -1;
     NarrowParams p;
+    p.nrm_ad = nrm_ad; p.nrm_beta = nrm_beta; p.nrm_silu = nrm_silu;
     p.x = x1; p.w = w; p.bias = bias; p.out = out;
     p.H = d->hin; p.W = d->win; p.cin = d->c1; p.ldx = d->ldx1; p.ldw = d->ldw; p.cout = d->cout; p.ldo = d->ldo;
     p.tiles_x = cdiv(d->win, NR_T); p.tiles_y = cdiv(d->hin, NR_T);

@@ -77,8 +77,7 @@ class Encoder(nn.Module):
         for b in self.down_blocks:
             h = b.nhwc(h)
         h = self.mid_block.nhwc(h)
-        h = self.conv_norm_out.nhwc(h, silu=True)
-        return conv_nhwc(self.conv_out, h)
+        return conv_nhwc(self.conv_out, h, norm=(self.conv_norm_out, True))     # (inference: the norm is applied inside the convolution where the library can)
 
     @ops.device_scoped
     def forward(self, x):
@@ -105,8 +104,7 @@ class Decoder(nn.Module):
         h = self.mid_block.nhwc(h)
         for b in self.up_blocks:
             h = b.nhwc(h)
-        h = self.conv_norm_out.nhwc(h, silu=True)
-        return conv_nhwc(self.conv_out, h)
+        return conv_nhwc(self.conv_out, h, norm=(self.conv_norm_out, True))     # (inference: the norm is applied inside the convolution where the library can)
 
     @ops.device_scoped
     def forward(self, z):

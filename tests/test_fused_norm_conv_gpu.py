@@ -26,6 +26,7 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 _lib.set_option(_lib.OPT_PERSISTENT_GRID, 8)
 lib.e2eft_debug_patch_launches.restype = ctypes.c_long
+lib.e2eft_debug_last_kernel.restype = ctypes.c_char_p
 worst = 0.0
 # B, H, W, C, Co, silu, beta, bias, rowadd, residual, fused
 cases = [
@@ -73,6 +74,29 @@ for dtype in (torch.float16, torch.bfloat16):
         assert same and st
         assert e <= 2.0 * TOL[dtype], e      # (the reference rounds the normalised tensor once more than fp64 would: 2x the conv tolerance)
         worst = max(worst, e / TOL[dtype])
+# ---- conv_norm_out -> SiLU -> conv_out (3 output channels: the LDS-halo kernel of narrow.hip stages the normalised values)
+for dtype in (torch.float16, torch.bfloat16):
+    for (B, H, W, Cc, Co, silu) in [(2, 96, 128, 128, 3, True), (1, 160, 128, 64, 4, False)]:
+        g = torch.Generator().manual_seed(H + W + Cc + Co)
+        x = q(torch.randn(B, Cc, H, W, generator=g) * 2.0 - 0.4, dtype)
+        gamma = q(torch.randn(Cc, generator=g) * 0.3 + 1.0, dtype)
+        beta = q(torch.randn(Cc, generator=g) * 0.5, dtype)
+        w = q(torch.randn(Co, Cc, 3, 3, generator=g) / (Cc * 9) ** 0.5, dtype)
+        b = q(torch.randn(Co, generator=g), dtype)
+        xd, gd, bd = nhwc(x, dtype, dev), gamma.to(dtype).to(dev), beta.to(dtype).to(dev)
+        wd, biasd = pack_conv_weight(w, dtype, dev), b.to(dtype).to(dev)
+        y2 = ops.conv2d(ops.groupnorm(xd, gd, bd, 32, 1e-5, silu=silu), wd, biasd, Co, 3, 3, 1, (1, 1, 1, 1))
+        y1 = ops.conv2d(xd, wd, biasd, Co, 3, 3, 1, (1, 1, 1, 1), norm=(gd, bd, 32, 1e-5, silu))
+        torch.cuda.synchronize()
+        assert getattr(y1, "_e2eft_keep", None) is not None, "conv_out: the fused route was not taken"
+        assert lib.e2eft_debug_last_kernel().decode().startswith("conv3x3_narrow_mfma"), lib.e2eft_debug_last_kernel()
+        ref = F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)
+        if silu:
+            ref = F.silu(ref)
+        ref = F.conv2d(q(ref.float(), dtype).double(), w.double(), b.double(), padding=1).float()
+        e = rel_err(to_nchw(y1), ref)
+        print("%%s norm-conv_out %%s bit-equal=%%d rel err %%.2e" %% (str(dtype)[6:], (B, H, W, Cc, Co, silu), torch.equal(y1, y2), e), flush=True)
+        assert torch.equal(y1, y2) and e <= 2.0 * TOL[dtype]
 # the option switches the route off
 _lib.set_option(_lib.OPT_FUSED_NORM, 0)
 x = nhwc(q(torch.randn(2, 128, 32, 64), torch.float16), torch.float16, dev)
