@@ -466,7 +466,7 @@ def pmc_traffic(mix, want):
     if not want:
         return None, None, "no PMC profile for this workload", {}
     seen = []
-    names = {"igemm6_kernel": "igemm6", "igemm5_kernel": "igemm5", "igemm2_kernel": "igemm2", "conv3x3_narrow": "conv3x3_narrow"}
+    names = {"igemm6_kernel": "igemm6", "igemm5_kernel": "igemm5", "igemm2_kernel": "igemm2", "conv3x3_narrow": "conv3x3_narrow", "conv_thin_in_kernel": "conv_thin_in"}
     for fn in files:
         with open(os.path.join(prof, fn)) as f:
             pj = json.load(f)
@@ -637,7 +637,7 @@ def main():
                        "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world,
                        "launch_mode": "hipGraph replay (one captured graph per batch shape)" if args.graph else "host launches",
                        **({"options": args.set_option} if args.set_option else {})},
-            "roofline": {"bound": "mfma", "kernel": "igemm6_kernel (persistent, halo-patch 3x3 conv) + igemm5_kernel (persistent) + igemm2_kernel: implicit-GEMM conv/linear, all launches of the timed region",
+            "roofline": {"bound": "mfma", "kernel": "igemm6_kernel (persistent, halo-patch 3x3 conv; ten launches also apply the GroupNorm + SiLU of their input) + igemm5_kernel (persistent) + igemm2_kernel + conv_in / conv_out kernels: implicit-GEMM conv/linear, all launches of the timed region",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_over_algorithmic": (traffic / alg_bpl) if traffic else None,
                          "traffic_source": traffic_source, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg_bpl,

@@ -21,7 +21,7 @@ import sys
 
 # "igemm" = every kernel behind e2eft_conv2d_fwd / e2eft_gemm, the family bench.py times (the persistent igemm5 / igemm6 take the big launches,
 # igemm2 the rest, conv3x3_narrow the 3-channel conv_out); "igemm2" / "igemm5" / ... separately
-GROUPS = {"igemm": ("igemm2_kernel", "igemm5_kernel", "igemm6_kernel", "conv3x3_narrow"), "igemm6": ("igemm6_kernel",), "igemm5": ("igemm5_kernel",), "igemm2": ("igemm2_kernel",), "gn_apply": ("gn_apply_kernel",),
+GROUPS = {"igemm": ("igemm2_kernel", "igemm5_kernel", "igemm6_kernel", "conv3x3_narrow", "conv_thin_in_kernel"), "igemm6": ("igemm6_kernel",), "conv_thin_in": ("conv_thin_in_kernel",), "igemm5": ("igemm5_kernel",), "igemm2": ("igemm2_kernel",), "gn_apply": ("gn_apply_kernel",),
           "attn_fwd": ("attn_fwd_kernel",), "attn512_fwd": ("attn512_fwd_kernel",), "conv3x3_narrow": ("conv3x3_narrow",)}
 
 
