@@ -1,0 +1,71 @@
+"""bf16 576^2 micro-step gradients against the fp32 GPU run under a list of option sets (one process, same inputs): is the error a property of a
+kernel, of the timing, or of the rounding noise itself?"""
+import copy, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+import torch
+from diffusion_e2e_ft_amd import training, _lib, ops
+from diffusion_e2e_ft_amd.synth import init_synthetic_
+from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+from diffusion_e2e_ft_amd.vae import AutoencoderKL
+import _options
+dev = torch.device("cuda:0")
+with torch.device(dev):
+    unet = UNet2DConditionModel(in_channels=8)
+    vae = AutoencoderKL()
+init_synthetic_(unet, seed=1234)
+init_synthetic_(vae, seed=4321)
+g = torch.Generator().manual_seed(9)
+text = 0.5 * torch.randn((1, 77, 1024), generator=g)
+batch = {k: v.cpu() for k, v in training.synthetic_batch(1, 576, 576, dev, seed=3).items()}
+KEYS = ["conv_in.weight", "mid_block.resnets.1.conv2.weight", "up_blocks.3.resnets.2.norm2.weight", "conv_norm_out.bias", "conv_out.weight"]
+DEF = {"thin_input_conv": 1, "patch_conv": 1, "fused_norm": 1, "igemm2_waves": 0, "persistent_grid": 0, "persistent": 1}
+
+
+def run(dtype, opts, gn_stats=True, latent=None, vae_dtype=None, jitter=None):
+    """latent: 'fp32' = the UNet is fed the fp32 encoder's latent (the encoder's rounding noise removed), 'bf16' = an fp32 run fed the bf16 encoder's latent"""
+    d = dict(DEF); d.update(opts)
+    _options.take(["%s=%d" % kv for kv in d.items()])
+    ops.GN_STATS_ENABLED = gn_stats
+    u = copy.deepcopy(unet).train()
+    v = copy.deepcopy(vae).eval().requires_grad_(False)
+    if dtype != torch.float32:
+        u = u.set_compute_dtype(dtype); v = v.to(dtype)
+    orig = training.encode_image
+    if latent is not None:
+        ve = copy.deepcopy(vae).eval().requires_grad_(False)
+        if latent == "bf16":
+            ve = ve.to(torch.bfloat16)
+        def enc(_vae, rgb):
+            with torch.no_grad():
+                z = orig(ve, rgb.to(next(ve.parameters()).dtype)).float()
+                if jitter is not None:     # relative perturbation of the latent at rounding level
+                    gj = torch.Generator(device=z.device).manual_seed(jitter[1])
+                    z = z * (1.0 + jitter[0] * torch.randn(z.shape, generator=gj, device=z.device))
+                return z.to(rgb.dtype)
+        training.encode_image = enc
+    try:
+        loss = training.e2e_ft_loss(u, v, batch, text, "depth")
+    finally:
+        training.encode_image = orig
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(u.named_parameters())
+    return {k: named[k].grad.detach().double().cpu().flatten() for k in KEYS}
+
+
+ref = run(torch.float32, {})
+def rel(a, b): return ((a - b).norm() / b.norm()).item()
+for name, dt, lat, jit in [
+        ("bf16 everything, bf16-encoder latent (separate encoder copy), thin=0", torch.bfloat16, "bf16", None),
+        ("  + latent jitter 1e-3, seed 1", torch.bfloat16, "bf16", (1e-3, 1)),
+        ("  + latent jitter 1e-3, seed 2", torch.bfloat16, "bf16", (1e-3, 2)),
+        ("  + latent jitter 1e-3, seed 3", torch.bfloat16, "bf16", (1e-3, 3)),
+        ("  + latent jitter 1e-4, seed 4", torch.bfloat16, "bf16", (1e-4, 4)),
+        ("bf16 UNet + decoder, fp32-encoder latent", torch.bfloat16, "fp32", None),
+        ("  + latent jitter 1e-3, seed 1", torch.bfloat16, "fp32", (1e-3, 1)),
+        ("  + latent jitter 1e-3, seed 2", torch.bfloat16, "fp32", (1e-3, 2)),
+        ("  + latent jitter 4e-3 (a bf16 ulp), seed 3", torch.bfloat16, "fp32", (4e-3, 3)),
+        ("fp32 everything, fp32 latent + jitter 4e-3, seed 3", torch.float32, "fp32", (4e-3, 3))]:
+    gq = run(dt, {"thin_input_conv": 0}, True, latent=lat, jitter=jit)
+    print("%-72s max rel L2 vs fp32 %.3e  %s" % (name, max(rel(gq[k], ref[k]) for k in KEYS), {k.split(".")[0]: "%.3f" % rel(gq[k], ref[k]) for k in KEYS}), flush=True)

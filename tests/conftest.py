@@ -64,4 +64,8 @@ def dev():
         _lib.set_option(_lib.OPT_PERSISTENT, int(os.environ["E2EFT_TEST_PERSISTENT"]))
     if "E2EFT_TEST_PATCH_CONV" in os.environ:
         _lib.set_option(_lib.OPT_PATCH_CONV, int(os.environ["E2EFT_TEST_PATCH_CONV"]))
+    for item in filter(None, os.environ.get("E2EFT_TEST_OPTIONS", "").split(",")):     # e.g. "fused_norm=0,thin_input_conv=0" (names: scripts/_options.py)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+        import _options
+        assert not _options.take([item]), "unknown option %s" % item
     return torch.device("cuda:0")
