@@ -25,6 +25,10 @@
 // the exact 2x nearest upsample fused into the read (the patch is built in the upsampled geometry), no zero insertion, width a multiple
 // of 32, height of 8, channels (each concat part) multiples of 64 and at least 128, the vector epilogue, at least two tiles per
 // workgroup.  e2eft_set_option(E2EFT_OPT_PATCH_CONV, 0) disables it.
+// Measured (profiles/r03h_patch_conv_ab.txt, one box, igemm5 -> igemm6, TF/s): 128->128 @768^2 896 -> 1011, 256->256 @384^2 1007 -> 1115, 512->512 @192^2
+// 1065 -> 1182, 256->128 @768^2 1011 -> 1138: +10.7 ... +13.8 %; the step of BASELINE configs[1] 107.0 -> 99.1 ms.
+// NORM variant (inference, cout <= 128; template flag): the input is read through a GroupNorm(+SiLU) that was never applied — see the kernel's comment.
+// LDS: 2 x 43 KiB patch buffers + 3 x 16 KiB weight ring + 6 KiB statistics deposits + 8 KiB dump = 148 KiB (+ 7.5 KiB coefficient table with NORM).
 // Summation order: per output element k runs (chunk, tap) instead of (tap, chunk) — fp32 accumulation, results differ from igemm5 in the
 // last bits (documented in include/e2eft.h; deterministic run to run).
 #include "igemm.h"
