@@ -135,9 +135,10 @@ int e2eft_conv2d_fwd_gnstats(const E2eftConvDesc* d, const void* x1, const void*
  * GroupNorm -> SiLU -> conv3x3 pairs of ResnetBlock2D (resnet.py: norm1 / conv1, norm2 / conv2) without the normalised tensor's round trip through
  * HBM.  coeff: the (a, mean) pairs of e2eft_groupnorm_fwd_stats for x1 ([batch][c1][2] fp32), beta: the norm's bias [c1] or NULL, silu != 0: SiLU.
  * The values that enter the convolution are those e2eft_groupnorm_fwd would have written (same arithmetic, same rounding to the 16-bit type), so the
- * result equals e2eft_groupnorm_fwd followed by e2eft_conv2d_fwd_gnstats bit for bit.  Served by the halo-patch kernel only (inference): ask
- * e2eft_conv2d_fwd_normed_supported(d) (pure host arithmetic; 1 = yes) before skipping the apply pass — 16-bit, 3x3 / stride 1 / pad 1, one source,
- * 128 <= c1 <= 640, cout <= 128, width % 32 == 0, height % 8 == 0, at least two 256-pixel tiles per CU; otherwise E2EFT_ERR_UNSUPPORTED. */
+ * result equals e2eft_groupnorm_fwd followed by e2eft_conv2d_fwd_gnstats bit for bit.  Inference only, served by two kernels: ask
+ * e2eft_conv2d_fwd_normed_supported(d) (pure host arithmetic; 1 = yes) before skipping the apply pass — 16-bit, 3x3 / stride 1 / pad 1, one source, and
+ * either 128 <= c1 <= 640, cout <= 128, width % 32 == 0, height % 8 == 0, at least two 256-pixel tiles per CU (igemm6.hip) or cout <= 4, c1 <= 128,
+ * c1 % 32 == 0, at least 16384 output pixels (conv_norm_out -> conv_out: narrow.hip); otherwise E2EFT_ERR_UNSUPPORTED. */
 int e2eft_conv2d_fwd_normed_supported(const E2eftConvDesc* d);
 int e2eft_conv2d_fwd_normed(const E2eftConvDesc* d, const void* x1, const float* coeff, const void* beta, int32_t silu, const void* w,
                             const void* bias, const void* rowadd, const void* residual, void* out, float* gn_partial,
