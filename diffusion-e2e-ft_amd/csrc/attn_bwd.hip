@@ -1,7 +1,9 @@
 // attn_bwd.hip — fused attention backward for head dim 64 (fp16 / bf16), gfx950.  Nothing of size Nq x Nk touches HBM:
 // the probabilities are recomputed from q, k and the forward's log-sum-exp (e2eft_attn_fwd_lse), exactly as in the forward.
 //
-//   P  = 2^(c * q k^T - lse2)            c = scale * log2(e), lse2 from the forward
+//   P  = 2^(q' k^T - lse2)               q' = round_T(c q), c = scale * log2(e): the forward (attn.hip) multiplies its Q fragments by c ONCE and rounds them,
+//                                        so the recomputation does the same — with c applied to the fp32 score instead, P would differ from the
+//                                        forward's by the rounding of q' (2^-9 relative per element in bf16) and its rows would not sum to one; lse2 from the forward
 //   dV = P^T dO
 //   dP = dO V^T,   dS = P o (dP - D),     D[q] = sum_d dO[q,d] O[q,d]
 //   dQ = scale * dS K,   dK = scale * dS^T Q
@@ -156,7 +158,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
         float* sl = reinterpret_cast<float*>(sdt + BTTILE);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<u32x4*>(sq + (r_r0 + 32 * i) * BROW + r_kc * 16) = gq[i];
+            Vec16<T> qs;                       // the score operand is q' = round(c q) as in the forward; the transposed image below (dK's operand) stays q
+            qs.raw = gq[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qs.e[e] = from_f<T>(to_f(qs.e[e]) * p.c);
+            *reinterpret_cast<u32x4*>(sq + (r_r0 + 32 * i) * BROW + r_kc * 16) = qs.raw;
             *reinterpret_cast<u32x4*>(sd + (r_r0 + 32 * i) * BROW + r_kc * 16) = gd[i];
         }
 #pragma unroll
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
                 float pe[4], de[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    pe[e] = __builtin_amdgcn_exp2f(fmaf(s[4 * g + e], p.c, -l4[e]));
+                    pe[e] = __builtin_amdgcn_exp2f(s[4 * g + e] - l4[e]);
                     de[e] = pe[e] * (dp[4 * g + e] - d4[e]);
                 }
                 pw[2 * g] = packb<T>(pe[0], pe[1]); pw[2 * g + 1] = packb<T>(pe[2], pe[3]);
@@ -288,7 +294,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
         const T* ds_ = (const T*)p.dout + row * p.lddo + head * 64 + 8 * hh;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
-            qf[ds] = *reinterpret_cast<const u32x4*>(qs + 16 * ds);
+            Vec16<T> qv;                       // q' = round(c q): the forward's score operand
+            qv.raw = *reinterpret_cast<const u32x4*>(qs + 16 * ds);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv.e[e] = from_f<T>(to_f(qv.e[e]) * p.c);
+            qf[ds] = qv.raw;
             dof[ds] = *reinterpret_cast<const u32x4*>(ds_ + 16 * ds);
         }
         if (qvalid) {
@@ -376,8 +386,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
             uint32_t dw[8];
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[2 * w], p.c, -lse2));
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(s[2 * w + 1], p.c, -lse2));
+                const float p0 = __builtin_amdgcn_exp2f(s[2 * w] - lse2);
+                const float p1 = __builtin_amdgcn_exp2f(s[2 * w + 1] - lse2);
                 dw[w] = packb<T>(p0 * (dp[2 * w] - dsum), p1 * (dp[2 * w + 1] - dsum));
             }
             // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
