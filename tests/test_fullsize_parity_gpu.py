@@ -271,7 +271,9 @@ def test_config2_576_bf16_compute_micro_step_gradients(dev, models, oracle_576):
     relative jitter of the latent (0.036 -> 0.048 / 0.050 / 0.074; 0.149 -> 0.059 / 0.060 / 0.091 / 0.165), GroupNorm statistics fused or not —
     while each half alone is benign and stable: bf16 UNet + decoder on the fp32 encoder's latent 0.026 under four kernel selections, the fp32 path
     on the bf16 encoder's latent 0.026-0.038, the fp32 path under a 4e-3 jitter 0.014 (linear response), and the fp32 test above holds 4-9e-5.
-    (Random-init weights make the network far more chaotic than a trained one: the bound says what THIS fixture can hold.)  So the bar is stated on
+    Plain torch, everything bf16, on the CPU (tests/calibrate_bf16_oracle.py 576: the oracle with a bf16 state dict against its own fp32 run, three
+    draws): 0.030 ... 0.058 — the same order; its tail was not sampled.  (Random-init weights make the network far more chaotic than a trained one:
+    the bound says what THIS fixture can hold.)  So the bar is stated on
     the distribution: five draws (the plain run and four with a 1e-3 jitter of the latent, different seeds) — loss within 1e-2 in every draw, MEDIAN
     of the per-draw worst gradient error <= 0.15, no draw beyond 0.30 / cosine below 0.95.  A wrong kernel moves every draw, not the tail."""
     import copy
