@@ -285,3 +285,28 @@ def test_aa_bilinear_tables_are_atens_weights():
         assert np.abs(out - want).max() <= 2e-4, ((H, W, h, w), np.abs(out - want).max())        # 0..255 scale: fp32 summation order only
         bad = np.rint(out) != np.rint(want)          # a value within fp32 round-off of k + 0.5 may land on either side
         assert bad.mean() < 2e-3 and (np.abs(want[bad] - np.floor(want[bad]) - 0.5) < 1e-3).all()
+
+
+def test_bench_prints_pmc_traffic_only_for_the_profiled_kernel_population():
+    """bench.py's roofline.traffic comes from a committed PMC profile: it must be attached only when the profile's launch counts per kernel of the igemm
+    family equal the run's (the committed bench line of the final build is the example), and the fraction over the launches without a fused GroupNorm
+    must exclude exactly igemm6's NORM symbols"""
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.loads(open(os.path.join(root, "profiles", "r03s_bench_default.json")).read().strip().splitlines()[-1])
+    symbols = line["roofline"]["by_symbol"]
+    mix = bench.kernel_mix(symbols)
+    assert mix == {"igemm6_kernel": 62.0, "igemm5_kernel": 74.0, "igemm2_kernel": 126.0, "conv3x3_narrow": 1.0, "conv_thin_in_kernel": 3.0}, mix
+    traffic, source, note, others = bench.pmc_traffic(mix, True)
+    assert source and "r03s_pmc_hbm_traffic.json" in source and abs(traffic - line["roofline"]["traffic"]) < 1.0
+    assert "attn_fwd" in others and "gn_apply" in others
+    for changed in (dict(mix, igemm6_kernel=61.0, igemm5_kernel=75.0), dict(mix, conv_thin_in_kernel=2.0, igemm2_kernel=127.0), {k: v for k, v in mix.items() if k != "conv3x3_narrow"}):
+        t2, s2, n2, _ = bench.pmc_traffic(changed, True)      # same total, another population / one launch missing: no figure
+        assert t2 is None and s2 is None and "no committed PMC profile" in n2, (changed, n2)
+    assert bench.pmc_traffic(mix, False)[0] is None           # another workload: never
+    extra = bench.plain_launch_fraction(symbols, 2500.0)
+    nrm = [k for k in symbols if k.startswith("igemm6") and k.endswith(", true>")]
+    assert len(nrm) == 2 and abs(extra["ms_per_step_of_launches_with_fused_groupnorm"] - sum(symbols[k]["ms_per_step"] for k in nrm)) < 1e-9
+    assert extra["frac_launches_without_fused_groupnorm"] > line["roofline"]["frac"]
+    assert bench.plain_launch_fraction({k: v for k, v in symbols.items() if k not in nrm}, 2500.0) == {}
