@@ -26,9 +26,9 @@
 namespace e2eft {
 
 namespace wg {
-constexpr int BM = 128, BN = 256, BK = 64, NW = 8;
+constexpr int BK = 64, NW = 8;             // tile: 64 NA output channels x 64 (6 - NA) columns, NA = 2 (128 x 256) or 4 (256 x 128)
 constexpr int PANEL = 64 * 128;            // [64 pixels][64 channels] of 16-bit
-constexpr int STAGE = 6 * PANEL;           // dY panels 0, 1; X panels 0 .. 3
+constexpr int STAGE = 6 * PANEL;           // dY panels 0 .. NA - 1, then the X panels
 constexpr int NSTAGE = 3;
 constexpr int LDS = NSTAGE * STAGE;        // 147,456 B: one 8-wave workgroup per CU
 }  // namespace wg
@@ -82,14 +82,17 @@ __device__ __forceinline__ int fdiv_w(int n, int d) {   // float estimate + one 
 // `vmcnt(6)` in front of the barrier is exact because every wave issues six pieces per k-tile, out-of-range ones fetch zeros), a lane's pixel is
 // carried incrementally (one division per k-tile), one 8-wave workgroup per CU with a 128 x 256 tile (weights of a chunk's four (tap, channel)
 // windows share the dY panels: 1.5 operand bytes per MFMA instead of 2).
-template <typename T>
+// NA: dY panels per stage.  2: 128 output channels x 256 columns (two dY, four X panels); 4: 256 x 128 (four dY, two X) for Cout >> the column count
+// of a 1x1 layer — the host picks the shape that multiplies less padding (wgrad_plan).
+template <typename T, int NA>
 __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
     using namespace wg;
+    constexpr int NB = 6 - NA, BM = 64 * NA, BN = 64 * NB;
     __shared__ __attribute__((aligned(16))) char smem[LDS];
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = NA == 2 ? wave >> 2 : wave >> 1, wn = NA == 2 ? wave & 3 : wave & 1;
     const int l31 = lane & 31, hh = lane >> 5;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int k_begin = blockIdx.z * p.kchunk, k_end = min(p.P, k_begin + p.kchunk);
@@ -97,10 +100,10 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
 
     // ---- the four 64-column chunks of this tile: (tap, first channel, source).  A chunk never straddles a tap or a concat source.
     const int cpt = p.cin >> 6;                        // chunks per tap
-    int ci0[4], ky[4], kx[4];
-    bool cok[4], src2[4];
+    int ci0[NB], ky[NB], kx[NB];
+    bool cok[NB], src2[NB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NB; ++j) {
         const int q = (n0 >> 6) + j;
         cok[j] = q * 64 < p.N;
         const int tap = cok[j] ? q / cpt : 0;
@@ -124,9 +127,9 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
     int pix = k_begin + r_kt;                                          // this lane's output pixel in the NEXT k-tile to issue
     int bimg = fdiv_w(pix, hw_out);
     int rem = pix - bimg * hw_out;
-    unsigned ycol[2];                                                  // dY byte offsets of the lane's columns (OOB beyond M)
+    unsigned ycol[NA];                                                 // dY byte offsets of the lane's columns (OOB beyond M)
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < NA; ++a) {
         const int col = m0 + 64 * a + sc8;
         ycol[a] = col < p.M ? (unsigned)col * (unsigned)sizeof(T) : OOB;
     }
@@ -136,19 +139,19 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(stage * STAGE + wave * 1024)));
         const unsigned yrow = (unsigned)pix * ldyb;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) dma_piece_w(rsy, (pok && ycol[a] != OOB) ? yrow + ycol[a] : OOB, dst + (unsigned)(a * PANEL));
+        for (int a = 0; a < NA; ++a) dma_piece_w(rsy, (pok && ycol[a] != OOB) ? yrow + ycol[a] : OOB, dst + (unsigned)(a * PANEL));
         const int oy = fdiv_w(rem, p.wout), ox = rem - oy * p.wout;
         const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
         const int irow0 = bimg * p.hin;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NB; ++c) {
             const int iy = iy0 + ky[c], ix = ix0 + kx[c];
             const bool ok = pok && cok[c] && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
             const unsigned ipix = (unsigned)((irow0 + iy) * p.win + ix);
             if (src2[c]) {      // (uniform branch: a descriptor select would leave the SGPRs)
-                dma_piece_w(rs2, ok ? (ipix * (unsigned)p.ldx2 + (unsigned)(ci0[c] - p.c1 + sc8)) * (unsigned)sizeof(T) : OOB, dst + (unsigned)((2 + c) * PANEL));
+                dma_piece_w(rs2, ok ? (ipix * (unsigned)p.ldx2 + (unsigned)(ci0[c] - p.c1 + sc8)) * (unsigned)sizeof(T) : OOB, dst + (unsigned)((NA + c) * PANEL));
             } else {
-                dma_piece_w(rs1, ok ? (ipix * (unsigned)p.ldx1 + (unsigned)(ci0[c] + sc8)) * (unsigned)sizeof(T) : OOB, dst + (unsigned)((2 + c) * PANEL));
+                dma_piece_w(rs1, ok ? (ipix * (unsigned)p.ldx1 + (unsigned)(ci0[c] + sc8)) * (unsigned)sizeof(T) : OOB, dst + (unsigned)((NA + c) * PANEL));
             }
         }
         pix += BK;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
         for (int kt = 0; kt < nkt; ++kt) {
             issue(st2);                                          // (beyond the split's end: zeros into a stage nobody reads — the count stays six)
             const char* pa = smem + st * STAGE + wm * PANEL;
-            const char* pb = smem + st * STAGE + (2 + wn) * PANEL;
+            const char* pb = smem + st * STAGE + (NA + wn) * PANEL;
             // fragments one k-step ahead of their MFMAs; the synchronisation that opens k-tile kt + 1 sits in front of the LAST MFMA group (every
             // LDS read of this k-tile has returned by then): the barrier skew of the eight waves runs under four MFMAs (igemm5.hip's placement)
             u32x4 fa[2][2], fb[2][2];
@@ -239,8 +242,12 @@ int device_cus();   // api.hip
 // pixel split: one workgroup per CU and round.  Among the split counts that leave >= 8 k-tiles per workgroup the one with the best product of
 // (filled fraction of the last round) x (k-tiles / (k-tiles + 3): the pipeline fill of a workgroup) — e.g. conv 320 -> 320 3x3 at 32 x 72^2:
 // 36 tiles x 14 splits = 504 workgroups = 1.97 rounds, not 36 x 22 = 3.09.
-static void wgrad_plan(long M, long N, long P, int& nsplit, int& kchunk) {
-    const long tiles = cdiv(M, wg::BM) * cdiv(N, wg::BN);
+static void wgrad_plan(long M, long N, long P, int& nsplit, int& kchunk, int& na) {
+    // tile shape: the one whose grid multiplies less padding (a 1x1 layer with 320 input and 2560 output channels: 10 x 3 tiles of 256 x 128 = 83 % useful
+    // against 20 x 2 tiles of 128 x 256 = 62 %); ties keep 128 x 256
+    const long area2 = cdiv(M, 128) * 128L * cdiv(N, 256) * 256L, area4 = cdiv(M, 256) * 256L * cdiv(N, 128) * 128L;
+    na = area4 < area2 ? 4 : 2;
+    const long tiles = na == 2 ? (long)cdiv(M, 128) * cdiv(N, 256) : (long)cdiv(M, 256) * cdiv(N, 128);
     int cus = device_cus();
     if (cus <= 0) cus = 256;
     const long ktiles = cdiv(P, wg::BK);
@@ -283,9 +290,9 @@ static int wgrad_check(const E2eftConvDesc* d, int lddy) {
 
 extern "C" size_t e2eft_conv2d_wgrad_workspace_bytes(const E2eftConvDesc* d, int32_t lddy) {
     if (wgrad_check(d, lddy) != E2EFT_OK) return 0;
-    int nsplit, kchunk;
+    int nsplit, kchunk, na;
     const long N = (long)d->kh * d->kw * (d->c1 + d->c2);
-    wgrad_plan(d->cout, N, (long)d->batch * d->hout * d->wout, nsplit, kchunk);
+    wgrad_plan(d->cout, N, (long)d->batch * d->hout * d->wout, nsplit, kchunk, na);
     return (size_t)nsplit * d->cout * N * sizeof(float);
 }
 
@@ -301,15 +308,21 @@ extern "C" int e2eft_conv2d_wgrad(const E2eftConvDesc* d, const void* dy, int32_
     p.batch = d->batch; p.hin = d->hin; p.win = d->win; p.hout = d->hout; p.wout = d->wout;
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
     p.M = d->cout; p.N = d->kh * d->kw * p.cin; p.P = d->batch * d->hout * d->wout;
-    wgrad_plan(p.M, p.N, p.P, p.nsplit, p.kchunk);
+    int na;
+    wgrad_plan(p.M, p.N, p.P, p.nsplit, p.kchunk, na);
     p.alpha = d->alpha;
     const size_t need = (size_t)p.nsplit * p.M * p.N * sizeof(float);
     if (partial_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "wgrad: partial buffer %zu < %zu bytes", partial_bytes, need);
     *nsplit_out = p.nsplit;
-    dim3 grid(cdiv(p.N, wg::BN), cdiv(p.M, wg::BM), p.nsplit);
+    dim3 grid(cdiv(p.N, na == 2 ? 256 : 128), cdiv(p.M, na == 2 ? 128 : 256), p.nsplit);
     E2EFT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "wgrad: grid");
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == E2EFT_F16) hipLaunchKernelGGL((wgrad_kernel<f16>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((wgrad_kernel<bf16>), grid, dim3(512), 0, s, p);
+    if (d->dtype == E2EFT_F16) {
+        if (na == 2) hipLaunchKernelGGL((wgrad_kernel<f16, 2>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((wgrad_kernel<f16, 4>), grid, dim3(512), 0, s, p);
+    } else {
+        if (na == 2) hipLaunchKernelGGL((wgrad_kernel<bf16, 2>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((wgrad_kernel<bf16, 4>), grid, dim3(512), 0, s, p);
+    }
     return check_launch("wgrad");
 }

@@ -40,6 +40,8 @@ def _conv_case(dev, dtype, B, H, W, c1, c2, Co, k, stride, seed):
     (2, 32, 32, 64, 0, 128, 3, 2),         # stride 2
     (4, 20, 20, 256, 0, 192, 1, 1),        # 1x1
     (1, 72, 72, 64, 0, 64, 3, 1),          # 5184 pixels: several pixel splits
+    (2, 24, 24, 128, 0, 640, 1, 1),        # 1x1 with Cout >> Cin: the 256 x 128 tile shape (640 = 2.5 row tiles of 256)
+    (2, 16, 16, 64, 64, 320, 1, 1),        # 256 x 128 tiles, two sources, ragged rows (320 = 256 + 64)
 ])
 def test_conv_wgrad_against_autograd(dev, dtype, B, H, W, c1, c2, Co, k, stride):
     e = _conv_case(dev, dtype, B, H, W, c1, c2, Co, k, stride, seed=H * 7 + Co + k)
