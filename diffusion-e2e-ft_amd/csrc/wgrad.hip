@@ -9,7 +9,7 @@
 // fragments are produced by the transpose read ds_read_b64_tr_b16 (a lane of a 16-lane group supplies the address of 4 consecutive channels of one
 // pixel and receives 4 pixels of one channel): no transposed or im2col'ed tensor exists anywhere.
 //
-//   * workgroup = 128 output channels x 256 columns (four 64-channel chunks of (tap, ci) space: a chunk never straddles a tap or a concat source, so
+//   * workgroup = 128 output channels x 256 columns, or 256 x 128 where that grid multiplies less padding (64-channel chunks of (tap, ci) space: a chunk never straddles a tap or a concat source, so
 //     its rows are one shifted window of ONE input tensor) x a range of pixels (split-K over the grid's z: a weight gradient has a handful of output
 //     tiles and 10^4 - 10^5 pixels); 8 waves, 64 x 64 each, one workgroup per CU;
 //   * k-tile = 64 pixels: six [64 pixels][64 channels] panels (two of dY, four of X) of 8 KB, filled by LDS-DMA in 1-KiB pieces of 8 pixel rows
