@@ -310,3 +310,44 @@ def test_bench_prints_pmc_traffic_only_for_the_profiled_kernel_population():
     assert len(nrm) == 2 and abs(extra["ms_per_step_of_launches_with_fused_groupnorm"] - sum(symbols[k]["ms_per_step"] for k in nrm)) < 1e-9
     assert extra["frac_launches_without_fused_groupnorm"] > line["roofline"]["frac"]
     assert bench.plain_launch_fraction({k: v for k, v in symbols.items() if k not in nrm}, 2500.0) == {}
+
+
+def test_wgrad_pixel_split_fills_whole_rounds_of_the_machine():
+    """e2eft_conv2d_wgrad_workspace_bytes is pure host arithmetic (wgrad_plan): the number of pixel splits it reserves partial buffers for must fill whole
+    rounds of one workgroup per CU (256 CUs assumed without a device) and leave every workgroup at least 8 k-tiles — the conv 320 -> 320 of the 576^2 recipe
+    (32 x 72^2 pixels) used to be cut 36 x 22 = 3.09 rounds"""
+    import ctypes as C
+    from diffusion_e2e_ft_amd import _lib
+    lib = _lib.load()
+
+    def splits(batch, hw, cin, cout, k):
+        d = _lib.ConvDesc()
+        d.dtype = 1
+        d.batch, d.hin, d.win, d.hl, d.wl, d.hout, d.wout = batch, hw, hw, hw, hw, hw, hw
+        d.c1, d.ldx1, d.c2, d.ldx2 = cin, cin, 0, 0
+        d.kh, d.kw, d.stride, d.pad_t, d.pad_l = k, k, 1, k // 2, k // 2
+        d.cout, d.ldo, d.ldw, d.alpha = cout, cout, k * k * cin, 1.0
+        nbytes = lib.e2eft_conv2d_wgrad_workspace_bytes(C.byref(d), cout)
+        assert nbytes > 0, lib.e2eft_last_error()
+        n = k * k * cin
+        assert nbytes % (cout * n * 4) == 0
+        ns = nbytes // (cout * n * 4)
+        area2 = -(-cout // 128) * 128 * -(-n // 256) * 256
+        area4 = -(-cout // 256) * 256 * -(-n // 128) * 128
+        tiles = (-(-cout // 256)) * (-(-n // 128)) if area4 < area2 else (-(-cout // 128)) * (-(-n // 256))
+        return ns, tiles, batch * hw * hw
+
+    for (b, hw, cin, cout, k) in [(32, 72, 320, 320, 3), (32, 72, 320, 2560, 1), (32, 36, 640, 640, 3), (32, 18, 1280, 1280, 3), (32, 72, 320, 320, 1), (1, 72, 64, 64, 3)]:
+        ns, tiles, pix = splits(b, hw, cin, cout, k)
+        w = ns * tiles
+        rounds = -(-w // 256)
+        ktiles_per_split = -(-(-(-pix // 64)) // ns)
+        assert ns == 1 or ktiles_per_split >= 8, (ns, ktiles_per_split)
+        too_small = (-(-pix // 64) // 8) * tiles < 256          # even at 8 k-tiles per workgroup the problem does not fill one round
+        assert w / (rounds * 256) >= 0.85 or too_small, ((b, hw, cin, cout, k), ns, tiles, rounds)
+    assert splits(32, 72, 320, 320, 3)[:2] == (14, 36)
+    # fp32 and channel counts that are not multiples of 64 are not this kernel's: 0 bytes, the caller keeps the transpose + GEMM route
+    d = _lib.ConvDesc()
+    d.dtype, d.batch, d.hin, d.win, d.hl, d.wl, d.hout, d.wout = 0, 1, 8, 8, 8, 8, 8, 8
+    d.c1, d.ldx1, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.cout, d.ldo, d.ldw, d.alpha = 64, 64, 3, 3, 1, 1, 1, 64, 64, 576, 1.0
+    assert lib.e2eft_conv2d_wgrad_workspace_bytes(C.byref(d), 64) == 0
