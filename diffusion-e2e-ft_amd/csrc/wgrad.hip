@@ -241,7 +241,7 @@ int device_cus();   // api.hip
 
 // pixel split: one workgroup per CU and round.  Among the split counts that leave >= 8 k-tiles per workgroup the one with the best product of
 // (filled fraction of the last round) x (k-tiles / (k-tiles + 3): the pipeline fill of a workgroup) — e.g. conv 320 -> 320 3x3 at 32 x 72^2:
-// 36 tiles x 14 splits = 504 workgroups = 1.97 rounds, not 36 x 22 = 3.09.
+// 36 tiles x 7 splits = 252 workgroups = 0.98 rounds, not 36 x 22 = 3.09.
 static void wgrad_plan(long M, long N, long P, int& nsplit, int& kchunk, int& na) {
     // tile shape: the one whose grid multiplies less padding (a 1x1 layer with 320 input and 2560 output channels: 10 x 3 tiles of 256 x 128 = 83 % useful
     // against 20 x 2 tiles of 128 x 256 = 62 %); ties keep 128 x 256
