@@ -60,9 +60,13 @@ def run(dtype, opts, gn_stats=True, latent=None, vae_dtype=None, jitter=None, un
 
 ref = run(torch.float32, {})
 def rel(a, b): return ((a - b).norm() / b.norm()).item()
-B, F = torch.bfloat16, torch.float32
-for name, ud, vd, jit in [
-        ("bf16 UNet, fp32 decoder, fp32-encoder latent", B, F, None), ("  + jitter 1e-3 seed 1", B, F, (1e-3, 1)), ("  + jitter 1e-3 seed 2", B, F, (1e-3, 2)), ("  + jitter 1e-3 seed 3", B, F, (1e-3, 3)),
-        ("fp32 UNet, bf16 decoder, fp32-encoder latent", F, B, None), ("  + jitter 1e-3 seed 1", F, B, (1e-3, 1)), ("  + jitter 1e-3 seed 2", F, B, (1e-3, 2)), ("  + jitter 1e-3 seed 3", F, B, (1e-3, 3))]:
-    gq = run(B, {}, True, latent="fp32", jitter=jit, unet_dtype=ud, vae_dtype=vd)
-    print("%-60s max rel L2 vs fp32 %.3e  %s" % (name, max(rel(gq[k], ref[k]) for k in KEYS), {k.split(".")[0]: "%.3f" % rel(gq[k], ref[k]) for k in KEYS}), flush=True)
+import statistics
+draws = []
+for seed in [None] + list(range(1, 13)):
+    jit = None if seed is None else (1e-3, seed)
+    gq = run(torch.bfloat16, {}, True, latent="bf16", jitter=jit)
+    e = max(rel(gq[k], ref[k]) for k in KEYS)
+    draws.append(e)
+    print("bf16 everything, default kernels, latent jitter 1e-3 seed %-4s max rel L2 vs fp32 %.3e" % (seed, e), flush=True)
+draws.sort()
+print("13 draws: min %.3f  quartiles %.3f / %.3f / %.3f  max %.3f" % (draws[0], draws[3], statistics.median(draws), draws[9], draws[-1]))
