@@ -235,6 +235,7 @@ class FlatAdamW(torch.optim.Optimizer):
             start = self.offsets[lo]
             end = self.offsets[hi] if hi < len(self.params) else n
             self.slices.append(dict(lo=lo, hi=hi, start=start, end=end, ready=0, work=None, done=False))
+        self._index_of = {id(p): i for i, p in enumerate(self.params)}
         self._slice_of = {}
         for si, sl in enumerate(self.slices):
             for i in range(sl["lo"], sl["hi"]):
@@ -272,10 +273,11 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def state_dict(self):
         sd = super().state_dict()
-        for st in sd["state"].values():          # torch's format wants per-parameter tensors that survive on their own
-            st["step"] = st["step"].detach().to(torch.float32).clone()
-            st["exp_avg"] = st["exp_avg"].detach().clone()
-            st["exp_avg_sq"] = st["exp_avg_sq"].detach().clone()
+        # torch's format wants per-parameter tensors that survive on their own.  super().state_dict() hands out the SAME per-parameter
+        # dicts self.state holds, so build new ones: rebinding entries in place would cut state[p] loose from the flat moment buffers
+        # and every later checkpoint would be stale.
+        sd["state"] = {k: {"step": st["step"].detach().to(torch.float32).clone(), "exp_avg": st["exp_avg"].detach().clone(),
+                           "exp_avg_sq": st["exp_avg_sq"].detach().clone()} for k, st in sd["state"].items()}
         sd["flat_adamw"] = {"skipped_steps": self.skipped_steps(), "max_grad_norm": self.max_grad_norm}
         return sd
 
@@ -304,6 +306,7 @@ class FlatAdamW(torch.optim.Optimizer):
     def _on_grad(self, p):
         if not self.sync_grads:
             return
+        self._adopt_one(p, self.offsets[self._index_of[id(p)]])      # a re-bound .grad goes back into its slot BEFORE the slice is exchanged
         sl = self.slices[self._slice_of[id(p)]]
         sl["ready"] += 1
         if sl["ready"] == sl["hi"] - sl["lo"]:
@@ -326,20 +329,24 @@ class FlatAdamW(torch.optim.Optimizer):
         for sl in self.slices:
             sl["done"] = False
 
+    def _adopt_one(self, p, o):
+        g = p.grad
+        if g is not None and g.data_ptr() == self.flat_grad.data_ptr() + 4 * o and g.is_contiguous():
+            return
+        slot = self.flat_grad[o:o + p.numel()].view(p.shape)
+        if g is None:
+            slot.zero_()
+        else:
+            slot.copy_(g)
+        p.grad = slot
+
     def _adopt_grads(self):
         """A caller may have re-bound .grad (zero_grad(set_to_none=True) of a generic training loop, then autograd created fresh tensors;
-        a DDP wrap handing out its bucket views): bring every gradient back into its slot of the flat buffer.  No-op in the normal case."""
-        base = self.flat_grad.data_ptr()
+        a DDP wrap handing out its bucket views): bring every gradient back into its slot of the flat buffer.  No-op in the normal case.
+        Runs BEFORE the exchange (the hooks adopt the parameter they fire for; `step()` adopts the rest, i.e. parameters that got no
+        gradient, whose slice no hook completed and which is therefore exchanged afterwards by `_finish_exchange`)."""
         for p, o in zip(self.params, self.offsets):
-            g = p.grad
-            if g is not None and g.data_ptr() == base + 4 * o and g.is_contiguous():
-                continue
-            slot = self.flat_grad[o:o + p.numel()].view(p.shape)
-            if g is None:
-                slot.zero_()
-            else:
-                slot.copy_(g)
-            p.grad = slot
+            self._adopt_one(p, o)
 
     @torch.no_grad()
     def step(self, closure=None, lr_scale=1.0, grad_scale=1.0):
@@ -349,8 +356,8 @@ class FlatAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         with ops.on_device_of(self.flat_param):
-            self._finish_exchange()
             self._adopt_grads()
+            self._finish_exchange()
             g = self.param_groups[0]
             sumsq = ops.sumsq(self.flat_grad, out=self._sumsq)     # always: the non-finite guard needs it even without clipping
             ops.adamw_step_guarded_(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, float(g["lr"]) * lr_scale, g["betas"][0], g["betas"][1],
@@ -361,15 +368,21 @@ class FlatAdamW(torch.optim.Optimizer):
         return loss
 
     def grad_norm(self):
-        """global L2 norm of the (averaged) gradient — host value, synchronises"""
+        """global L2 norm of the (averaged) gradient — host value, synchronises.  With world > 1 this completes the exchange (each slice
+        is summed once per optimizer step, so a following `step()` does not exchange again)."""
         with ops.on_device_of(self.flat_param):
             self._adopt_grads()
+            self._finish_exchange()
             return math.sqrt(float(ops.sumsq(self.flat_grad, out=self._sumsq).item())) / self.world
 
     @torch.no_grad()
     def zero_grad(self, set_to_none=False):
         """Gradients are zeroed in ONE memset of the flat buffer and stay bound to it (also with set_to_none=True: a fresh `.grad` tensor
         per parameter would take the gradient out of the exchange buffer; `step()` would copy it back, at a price)."""
+        for sl in self.slices:                           # a backward without a step() (skipped iteration): drain its exchange first,
+            if sl["work"] is not None:                   # the memset below must not race an in-flight all-reduce
+                sl["work"].wait()
+            sl["work"], sl["ready"] = None, 0
         self.flat_grad.zero_()
         self._rearm_exchange()
         for p, o in zip(self.params, self.offsets):      # autograd may have re-bound .grad (e.g. set_to_none by a caller)

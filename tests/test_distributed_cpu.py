@@ -63,6 +63,30 @@ def _worker(rank, world, port, q):
         assert torch.allclose(p.grad / world, (a + b) / 2, atol=1e-6)
     opt.zero_grad()
     assert opt.flat_grad.abs().max().item() == 0
+    # a generic loop's model.zero_grad(set_to_none=True): autograd creates fresh .grad tensors OUTSIDE the flat buffer.  They must be
+    # adopted BEFORE their slice is exchanged (the exchange used to run on the stale slots, then the local gradient overwrote them)
+    for p in net.parameters():
+        p.grad = None
+    net(xs[rank]).sum().backward()
+    assert all(sl["work"] is not None for sl in opt.slices)
+    opt._adopt_grads()
+    opt._finish_exchange()
+    for p, a, b, o in zip(net.parameters(), refs[0], refs[1], opt.offsets):
+        assert p.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * o
+        assert torch.allclose(p.grad / world, (a + b) / 2, atol=1e-6)
+    opt._rearm_exchange()
+    # a backward WITHOUT a step (skipped iteration) followed by zero_grad(): the outstanding exchange is drained, the counters re-armed,
+    # and the next backward's hooks launch again
+    opt.zero_grad()
+    net(xs[rank]).sum().backward()
+    assert all(sl["work"] is not None for sl in opt.slices)
+    opt.zero_grad()
+    assert all(sl["work"] is None and sl["ready"] == 0 and not sl["done"] for sl in opt.slices) and opt.flat_grad.abs().max().item() == 0
+    net(xs[rank]).sum().backward()
+    assert all(sl["work"] is not None for sl in opt.slices)
+    opt._finish_exchange()
+    for p, a, b in zip(net.parameters(), refs[0], refs[1]):
+        assert torch.allclose(p.grad / world, (a + b) / 2, atol=1e-6)
     dist.destroy_process_group()
     q.put(rank)
 

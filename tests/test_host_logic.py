@@ -242,6 +242,14 @@ def test_flat_adamw_is_a_torch_optimizer_with_live_lr_and_torch_format_state():
     ropt2 = torch.optim.AdamW(ref.parameters(), lr=1.0)
     ropt2.load_state_dict({k: v for k, v in sd.items() if k != "flat_adamw"})
     assert ropt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"] and float(ropt2.state[next(ref.parameters())]["step"]) == 1.0
+    # a SECOND checkpoint must see what happened since the first (state_dict() used to re-bind state[p] to its clones)
+    opt.exp_avg.fill_(5.0)
+    opt._steps[0] = 7
+    sd2 = opt.state_dict()
+    for i, (p, o) in enumerate(zip(opt.params, opt.offsets)):
+        assert opt.state[p]["exp_avg"].data_ptr() == opt.exp_avg.data_ptr() + 4 * o
+        assert sd2["state"][i]["exp_avg"].eq(5.0).all() and float(sd2["state"][i]["step"]) == 7.0
+        assert sd["state"][i]["exp_avg"].data_ptr() != sd2["state"][i]["exp_avg"].data_ptr() and float(sd["state"][i]["step"]) == 1.0
     # zero_grad keeps .grad bound to the flat buffer, also with set_to_none=True; a re-bound .grad is adopted back
     opt.zero_grad(set_to_none=True)
     p0 = opt.params[0]
