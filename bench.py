@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--geowizard", action="store_true", help="time GeoWizard joint depth+normals 1-step inference (BASELINE.json configs[4]: "
                     "dual-latent UNet with cross-domain attention, 2 images per GPU by default) instead of Marigold depth")
     ap.add_argument("--no-latency-leg", action="store_true", help="inference mode at N=1: skip the one-image 576x768 latency measurement (`latency_b1_576x768`)")
+    ap.add_argument("--no-geowizard-leg", action="store_true", help="inference mode at N=1: skip the GeoWizard measurement (`geowizard`: configs[4]'s per-GPU share, "
+                    "2 images at 768x768 with the CLIP image tower inside)")
     ap.add_argument("--no-train-leg", action="store_true", help="inference mode at N=1: skip the E2E-FT training-step measurements "
                     "that are appended to the JSON line as `train_step` (bf16 compute) and `train_step_fp32` (the reference recipe)")
     ap.add_argument("--plumbing-check", action="store_true", help="launcher / rendezvous / timing-reduction check without GPU work (gloo, CPU): "
@@ -295,6 +297,7 @@ def run_train(args, rank, world, dev):
     torch.cuda.synchronize()
     timer = ops.KernelTimer()
     ops.TIMER = timer
+    opt.profile_exchange = world > 1
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -306,6 +309,7 @@ def run_train(args, rank, world, dev):
     assert torch.isfinite(loss).all(), "non-finite loss"
     elapsed = D.max_over_ranks(elapsed, device=dev)
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    exposed = opt.exchange_exposed_ms() if world > 1 else []
     ksum = timer.summary()
     if args.detail and rank == 0:
         write_detail(args.detail, timer, args.steps)
@@ -327,6 +331,8 @@ def run_train(args, rank, world, dev):
                                                                                          "per-block activation recompute (UNet + decoder)" if getattr(args, "grad_ckpt", False) else "no activation recompute",
                                                                                          " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
                        "images_per_step": n_img, "resolution": R, "parallelism": "dp%d (RCCL all-reduce of the flat fp32 gradient, overlapped)" % world},
+            "gradient_exchange": {"slices": exposed, "note": "rank 0, mean over the timed steps: time the compute stream waited in step() for each slice's "
+                                                            "all-reduce (HIP events either side of the wait) = the part of the exchange the backward did not hide"} if world > 1 else None,
             "roofline": {"bound": "mfma", "kernel": "igemm kernels (fwd, dgrad, wgrad GEMMs, attention-backward GEMMs)", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches_per_step": ig["launches"] / args.steps,
                          "kernel_ms_per_step": ig["ms"] / args.steps, "algorithmic_gflop_per_step": ig["flops"] / args.steps / 1e9, "other_kernels": others},
@@ -336,8 +342,25 @@ def run_train(args, rank, world, dev):
 
 
 def geowizard_main(args):
-    """GeoWizard joint depth + normals, one step: VAE encode -> UNet on the doubled batch (cross-domain joint self-attention, class
-    embedding, CLIP image embedding as an input tensor) -> two VAE decodes (geowizard_pipeline.py:252-344)."""
+    from diffusion_e2e_ft_amd import dist as D
+    rank, local_rank, world = D.init_from_env()
+    check_world(args, world)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ranks = rank_table(rank, local_rank, world, dev)
+    line = run_geowizard(args, rank, world, dev)
+    if rank == 0:
+        line["world"], line["ranks"], line["rccl_ranks"] = world, ranks, (world if world > 1 else 0)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def run_geowizard(args, rank, world, dev):
+    """GeoWizard joint depth + normals, one step: (CLIP ViT-L/14 image embedding ->) VAE encode -> UNet on the doubled batch (cross-domain joint
+    self-attention, class embedding) -> two VAE decodes (geowizard_pipeline.py:232-248,252-344).  Returns the JSON line (rank 0) or None."""
     from diffusion_e2e_ft_amd import dist as D
     from diffusion_e2e_ft_amd import ops
     from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
@@ -345,12 +368,6 @@ def geowizard_main(args):
     from diffusion_e2e_ft_amd.scheduler import DDIMScheduler
     from diffusion_e2e_ft_amd.pipeline import DepthNormalEstimationPipeline
     from diffusion_e2e_ft_amd.synth import init_synthetic_
-    rank, local_rank, world = D.init_from_env()
-    check_world(args, world)
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ranks = rank_table(rank, local_rank, world, dev)
     dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     with torch.device(dev):
@@ -403,8 +420,7 @@ def geowizard_main(args):
         achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         at = ksum.get("attn", dict(launches=0, ms=0.0, flops=0.0))
         line = {"metric": "images/sec (768x768, GeoWizard joint depth+normals, 1-step dual-latent UNet fwd) full path",
-                "value": B * world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "world": world, "ranks": ranks,
-                "rccl_ranks": world if world > 1 else 0, "steps": args.steps, "warmup": args.warmup,
+                "value": B * world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f16" if args.dtype == "fp16" else args.dtype, "data": "synthetic",
                 "config": {"workload": "GeoWizard joint depth+normals 1-step (dual-latent UNet, cross-domain joint attention, class embedding), batch=%d/GPU at "
@@ -415,10 +431,8 @@ def geowizard_main(args):
                              "frac": achieved / PEAK_TF[args.dtype], "traffic": None, "launches_per_step": ig["launches"] / args.steps,
                              "kernel_ms_per_step": ig["ms"] / args.steps,
                              "other_kernels": {"attn": {"ms_per_step": at["ms"] / args.steps, "tflops": at["flops"] / (at["ms"] * 1e-3) / 1e12 if at["ms"] else 0.0}}}}
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        return line
+    return None
 
 
 def write_detail(path, timer, steps):
@@ -678,6 +692,19 @@ def main():
                 line["latency_b1_576x768"] = latency_leg(pipe, dev, dtype)
             except Exception as e:
                 line["latency_b1_576x768"] = {"value": None, "error": repr(e)}
+        if world == 1 and not args.no_geowizard_leg and not args.tiny:
+            # BASELINE.json configs[4]'s per-GPU share (batch 16 on 8 GPUs = 2 images per GPU at 768x768): GeoWizard joint depth + normals with the
+            # CLIP image tower inside the timed region, so that the driver's default run times it too
+            try:
+                _mark(timeline, "geowizard leg start")
+                gargs = argparse.Namespace(**vars(args))
+                gargs.batch, gargs.res, gargs.res_h, gargs.res_w, gargs.steps, gargs.warmup, gargs.graph, gargs.no_image_encoder = 2, 768, 768, 768, 10, 3, False, False
+                gw = run_geowizard(gargs, 0, 1, dev)
+                line["geowizard"] = {k: gw[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "warmup")}
+                line["geowizard"]["workload"] = gw["config"]["workload"]
+                line["geowizard"]["roofline"] = {k: gw["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "other_kernels")}
+            except Exception as e:
+                line["geowizard"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_train_leg and not args.tiny:
             # second part of BASELINE.json's metric ("...; E2E-FT step time"): configs[2], batch 32 at 576x576, one GPU - in the reference
             # recipe's precision (`--mixed_precision no`, training/scripts/train_marigold_e2e_ft_depth.sh:15) AND with bf16 compute over

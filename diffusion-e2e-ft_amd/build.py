@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libe2eft.so")
 SOURCES = ["api.hip", "igemm.hip", "igemm2.hip", "igemm5.hip", "igemm6.hip", "convin.hip", "norm.hip", "attn.hip", "attn512.hip", "attn_bwd.hip", "elementwise.hip", "loss.hip", "bwd.hip", "wgrad.hip", "ensemble.hip", "dataprep.hip", "narrow.hip", "dataaug.hip", "evalmetrics.hip", "prepost.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]   # exports = what include/*.h declares
 # Per-file flags.  The implicit-GEMM files are built without the SLP vectorizer: it turns the epilogue's per-column fp32
 # arithmetic into v_pk_add_f32 with operand swizzles (op_sel:[0,1] — the low result lane reads the HIGH dword of src1), and on
 # gfx950 that form sporadically read 0.0 in lanes 48-63 while a wave of ANOTHER workgroup on the same SIMD was inside its
@@ -33,7 +33,7 @@ def _hipcc():
 
 
 def _newest_source_mtime():
-    paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "e2eft.h"), os.path.abspath(__file__)]
+    paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "e2eft.h"), os.path.join(HERE, "..", "include", "e2eft_debug.h"), os.path.abspath(__file__)]
     return max(os.path.getmtime(p) for p in paths)
 
 
@@ -51,7 +51,7 @@ def build(force=False, verbose=True):
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
-        deps = [srcp, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm.h"), os.path.join(CSRC, "attn512_regs.inc"), os.path.join(CSRC, "igemm_persistent_epilogue.inc"), os.path.join(HERE, "..", "include", "e2eft.h"), os.path.abspath(__file__)]
+        deps = [srcp, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm.h"), os.path.join(CSRC, "attn512_regs.inc"), os.path.join(CSRC, "igemm_persistent_epilogue.inc"), os.path.join(HERE, "..", "include", "e2eft.h"), os.path.join(HERE, "..", "include", "e2eft_debug.h"), os.path.abspath(__file__)]
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(d) for d in deps):
             return obj
         cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", srcp, "-o", obj]

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include "../../include/e2eft.h"
+#include "../../include/e2eft_debug.h"
 
 namespace e2eft {
 

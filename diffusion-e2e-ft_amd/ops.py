@@ -774,27 +774,40 @@ WGRAD_DIRECT = True   # tests / A-B: False keeps every weight gradient on the tr
 
 def conv2d_wgrad(dy, x, x2, cout, kh, kw, stride, pad, alpha):
     """Weight gradient straight from the NHWC tensors (csrc/wgrad.hip): dy [B,hout,wout,>=cout] (pixel-dense), x [B,H,W,c1], x2 optional second
-    concat source -> fp32 [cout, kh*kw*(c1+c2)] (OHWI rows), or None when the kernel does not serve the problem (the caller falls back)."""
+    concat source -> fp32 [cout, kh*kw*(c1+c2)] (OHWI rows), or None when the kernel does not serve the problem (the caller falls back).
+    The kernel addresses each operand through ONE 32-bit buffer descriptor, so tensors of 4 GB and more (configs[2] as benchmarked: 32 images of
+    576^2 x 256 channels = 5.4 GB) are cut along the batch into launches below that limit; every launch adds its split partials to the same reduction."""
     if not WGRAD_DIRECT or dy.dtype == torch.float32:
         return None
     _check_cuda(dy, x, x2)
-    d = _conv_desc(x, x2, cout, kh, kw, stride, pad, None, alpha)
-    assert tuple(dy.shape[:3]) == (d.batch, d.hout, d.wout), (dy.shape, d.batch, d.hout, d.wout)
+    B = x.shape[0]
     lddy = _nhwc_ld(dy)
+    es = dy.element_size()
+    per_img = max(dy.shape[1] * dy.shape[2] * lddy, x.shape[1] * x.shape[2] * max(_nhwc_ld(x), _nhwc_ld(x2) if x2 is not None else 0)) * es
+    pix_img = max(dy.shape[1] * dy.shape[2], 1)
+    step = max(1, min(B, (0xFFFF0000 - 1) // max(per_img, 1), ((1 << 24) - 1) // pix_img))
     lib = _lib.load()
-    nbytes = lib.e2eft_conv2d_wgrad_workspace_bytes(C.byref(d), lddy)
-    if nbytes == 0:
-        return None
-    cin = d.c1 + d.c2
+    parts = []
+    cin = x.shape[3] + (x2.shape[3] if x2 is not None else 0)
     N = kh * kw * cin
-    part = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
-    ns = C.c_int32(0)
-    P = d.batch * d.hout * d.wout
-    with _timed("wgrad", 2.0 * P * cout * N, (P * (cout + cin)) * dy.element_size(), label="wgrad %dx%ds%d P%d %d->%d" % (kh, kw, stride, P, cin, cout)):
-        check(lib.e2eft_conv2d_wgrad(C.byref(d), _ptr(dy), lddy, _ptr(x), _ptr(x2), _ptr(part), nbytes, C.byref(ns), _stream()))
-    if ns.value == 1:
-        return part.view(cout, N)
-    return colsum(part.view(ns.value, cout * N), groups=1).view(cout, N)
+    for b0 in range(0, B, step):
+        b1 = min(B, b0 + step)
+        xs, x2s, dys = x[b0:b1], (x2[b0:b1] if x2 is not None else None), dy[b0:b1]
+        d = _conv_desc(xs, x2s, cout, kh, kw, stride, pad, None, alpha)
+        assert tuple(dys.shape[:3]) == (d.batch, d.hout, d.wout), (dys.shape, d.batch, d.hout, d.wout)
+        nbytes = lib.e2eft_conv2d_wgrad_workspace_bytes(C.byref(d), lddy)
+        if nbytes == 0:
+            return None
+        part = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
+        ns = C.c_int32(0)
+        P = d.batch * d.hout * d.wout
+        with _timed("wgrad", 2.0 * P * cout * N, (P * (cout + cin)) * es, label="wgrad %dx%ds%d P%d %d->%d" % (kh, kw, stride, P, cin, cout)):
+            check(lib.e2eft_conv2d_wgrad(C.byref(d), _ptr(dys), lddy, _ptr(xs), _ptr(x2s), _ptr(part), nbytes, C.byref(ns), _stream()))
+        parts.append(part.view(ns.value, cout * N))
+    if len(parts) == 1 and parts[0].shape[0] == 1:
+        return parts[0].view(cout, N)
+    allp = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+    return colsum(allp, groups=1).view(cout, N)
 
 
 def linear_wgrad(dy2d, x2d, alpha=1.0):

@@ -49,7 +49,7 @@ class DDIMScheduler:
         import os
         os.makedirs(save_directory, exist_ok=True)
         cfg = dict(self.config)
-        cfg["_class_name"] = "DDIMScheduler"
+        cfg["_class_name"] = type(self).__name__
         with open(os.path.join(save_directory, self.config_name), "w") as f:
             json.dump(cfg, f, indent=2)
 
@@ -117,3 +117,16 @@ class DDIMScheduler:
             raise NotImplementedError("clip_sample / thresholding are not implemented (SD-v2 / Marigold / GeoWizard schedulers set neither)")
         prev = a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
         return SchedulerOutput(prev, x0)
+
+
+class DDPMScheduler(DDIMScheduler):
+    """The name the training script loads, reads and saves (training/train.py:25,292,461,480,511-524,613-617): `DDPMScheduler.from_pretrained(ckpt,
+    subfolder="scheduler"[, timestep_spacing="trailing"])`, `.alphas_cumprod`, `.config.num_train_timesteps / prediction_type / thresholding /
+    clip_sample`, and at the end of training `StableDiffusionPipeline(..., scheduler=DDPMScheduler.from_pretrained(..., timestep_spacing="trailing"))
+    .save_pretrained(out)` which writes scheduler/scheduler_config.json.  The E2E-FT step never calls the scheduler's stochastic `step()`: it only
+    needs the noise schedule (identical to DDIM's: scaled_linear betas, diffusers scheduling_ddpm.py) and the config, so this is the same object
+    under the reference's class name; `save_pretrained` records `_class_name: DDPMScheduler` as diffusers would.  SD-v2 ships `clip_sample: false`;
+    a checkpoint that sets it (DDPM's diffusers default is true) is refused by the fused single-step path exactly like DDIM's (zero_latent_x0_scale)."""
+
+    def step(self, *a, **kw):
+        raise NotImplementedError("ancestral DDPM sampling is not on the E2E-FT path (training/train.py reads the schedule only; inference uses DDIMScheduler)")

@@ -241,6 +241,8 @@ class FlatAdamW(torch.optim.Optimizer):
             for i in range(sl["lo"], sl["hi"]):
                 self._slice_of[id(self.params[i])] = si
         self.sync_grads = True          # set False on non-final gradient-accumulation micro-steps
+        self.profile_exchange = False   # bench.py --gpus N: time what step() waits for, per slice (exchange_exposed_ms)
+        self._exposed = []
         self._hooks = []
         if self.world > 1:
             for p in self.params:
@@ -320,10 +322,31 @@ class FlatAdamW(torch.optim.Optimizer):
         for sl in self.slices:
             if sl["work"] is None and not sl["done"]:
                 sl["work"] = dist.all_reduce(self.flat_grad[sl["start"]:sl["end"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        for sl in self.slices:
+        prof = self.profile_exchange and self.flat_grad.is_cuda
+        for si, sl in enumerate(self.slices):
             if sl["work"] is not None:
-                sl["work"].wait()
+                if prof:     # how long the compute stream stands still for this slice: events on it either side of the wait
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    sl["work"].wait()
+                    e1.record()
+                    self._exposed.append((si, e0, e1))
+                else:
+                    sl["work"].wait()
             sl["work"], sl["ready"], sl["done"] = None, 0, True
+
+    def exchange_exposed_ms(self):
+        """profile_exchange = True: per slice, the mean time (ms) the compute stream waited for that slice's all-reduce in `step()` since the last
+        call — the part of the exchange the backward did not hide.  Synchronises."""
+        if not self._exposed:
+            return []
+        torch.cuda.synchronize(self.flat_grad.device)
+        acc = [[0.0, 0] for _ in self.slices]
+        for si, e0, e1 in self._exposed:
+            acc[si][0] += e0.elapsed_time(e1)
+            acc[si][1] += 1
+        self._exposed = []
+        return [{"slice": i, "mbytes": (sl["end"] - sl["start"]) * 4 / 1e6, "exposed_ms": a[0] / max(a[1], 1)} for i, (sl, a) in enumerate(zip(self.slices, acc))]
 
     def _rearm_exchange(self):
         for sl in self.slices:

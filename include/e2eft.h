@@ -31,8 +31,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header (and e2eft_debug.h) declares is ALL it exports (tests/test_abi.py) */
+#pragma GCC visibility push(default)
 
-#define E2EFT_VERSION 115 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
+#define E2EFT_VERSION 116 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
 
 enum {
     E2EFT_OK = 0,
@@ -469,6 +471,7 @@ int e2eft_adamw_step_guarded(int64_t n, float* param, const float* grad, float* 
  * accumulated into the fp32 flat gradient buffer) */
 int e2eft_cast(int32_t dt_in, int32_t dt_out, int64_t n, float mul, int32_t accumulate, const void* x, void* y, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,27 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "libe2eft.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.e2eft_version() == 115
+    assert lib.e2eft_version() == 116
+
+
+def test_library_exports_nothing_the_headers_do_not_declare():
+    """four `e2eft_debug_*` exports (process-global counters) sat next to a header that promised no such state, and every internal C++
+    launcher was a dynamic symbol.  The library is built with -fvisibility=hidden; the dynamic symbol table must be exactly include/e2eft.h (the
+    contract) + the e2eft_debug_* subset of include/e2eft_debug.h this build defines (instrumentation, documented there)."""
+    import subprocess
+    from diffusion_e2e_ft_amd import _lib
+    _lib.load()
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.lib_path()], capture_output=True, text=True, check=True).stdout
+    # functions (T) only: the data objects in the table are the kernel handles hipcc emits for every __global__ function (its registration protocol)
+    exported = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T")
+    exported = [e for e in exported if e not in ("_init", "_fini")]
+    dbg = open(os.path.join(ROOT, "include", "e2eft_debug.h")).read()
+    dbg_names = set(re.findall(r"\b(e2eft_debug_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", dbg, flags=re.S)))
+    contract = set(_declared())
+    stray = [e for e in exported if e not in contract and e not in dbg_names]
+    assert not stray, "exports outside include/*.h: %s" % stray[:10]
+    assert contract <= set(exported)
+    assert {"e2eft_debug_last_kernel", "e2eft_debug_patch_launches", "e2eft_debug_persistent_launches", "e2eft_debug_thin_launches"} <= set(exported)
 
 
 def test_options_are_the_only_global_state_and_the_library_never_reads_the_environment():

@@ -93,6 +93,30 @@ def test_scheduler_config_tolerates_unknown_keys(tmp_path):
     assert s.timesteps_host == [999]
 
 
+def test_ddpm_scheduler_name_as_train_py_uses_it(tmp_path):
+    """training/train.py:25,292,461,480,511,613-617: `DDPMScheduler.from_pretrained(ckpt, subfolder="scheduler")`, the schedule and config reads of the
+    step body, and the final `DDPMScheduler.from_pretrained(..., timestep_spacing="trailing", revision=, variant=)` that is saved with the pipeline"""
+    from diffusion_e2e_ft_amd.scheduler import DDIMScheduler, DDPMScheduler
+    d = str(tmp_path / "ckpt")
+    os.makedirs(os.path.join(d, "scheduler"))
+    json.dump({"_class_name": "PNDMScheduler", "_diffusers_version": "0.8.0", "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear",
+               "num_train_timesteps": 1000, "prediction_type": "v_prediction", "steps_offset": 1, "clip_sample": False, "set_alpha_to_one": False,
+               "skip_prk_steps": True, "trained_betas": None}, open(os.path.join(d, "scheduler", "scheduler_config.json"), "w"))
+    ns = DDPMScheduler.from_pretrained(d, subfolder="scheduler")
+    assert ns.config.num_train_timesteps - 1 == 999 and ns.config.prediction_type == "v_prediction" and not ns.config.thresholding and not ns.config.clip_sample
+    ap = ns.alphas_cumprod
+    assert ap.shape == (1000,) and abs(float(ap[999]) - 0.00466010) < 1e-8 and abs(float(ap[0]) - 0.99914998) < 1e-7       # SURVEY.md A.3
+    assert abs(ns.zero_latent_x0_scale(999) + float((1 - ap[999]) ** 0.5)) < 1e-7                                            # train.py:511-512 at x_t = 0
+    out = DDPMScheduler.from_pretrained(d, subfolder="scheduler", timestep_spacing="trailing", revision=None, variant=None)
+    o = str(tmp_path / "out" / "scheduler")
+    out.save_pretrained(o)
+    saved = json.load(open(os.path.join(o, "scheduler_config.json")))
+    assert saved["_class_name"] == "DDPMScheduler" and saved["timestep_spacing"] == "trailing"
+    inf = DDIMScheduler.from_pretrained(o)            # what Marigold/run.py:272 then loads for inference
+    inf.set_timesteps(1)
+    assert inf.timesteps_host == [999]
+
+
 def test_unet_config_json_is_validated_and_bin_files_load(tmp_path):
     """a config.json of the SD-v2 family (every diffusers key present, at its default) loads; one that asks for an unimplemented feature is
     refused instead of loading into the wrong architecture; diffusion_pytorch_model.bin is read when no .safetensors exists"""

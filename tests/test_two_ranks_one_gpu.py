@@ -46,16 +46,19 @@ def _shards():
     return [{k: v[i:i + 1] for k, v in batch.items()} for i in range(2)], text
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
+    """backend "gloo": both ranks on cuda:0; "nccl" (= RCCL): rank r on cuda:r, the exchange on RCCL's own stream"""
     try:
         sys.path.insert(0, HERE)
         sys.path.insert(0, os.path.join(HERE, ".."))
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        local = rank if backend == "nccl" else 0
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
         from diffusion_e2e_ft_amd import training
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda:0")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
         probe = torch.ones(4, device=dev) * (rank + 1)
         try:
             dist.all_reduce(probe)
@@ -92,11 +95,23 @@ def _worker(rank, world, port, q):
 
 
 def test_two_ranks_share_one_gpu_hooks_exchange_and_update(dev):
+    _two_ranks(dev, "gloo")
+
+
+def test_two_ranks_two_gpus_rccl_hooks_exchange_and_update(dev):
+    """The same step with backend "nccl" = RCCL over xGMI, one rank per GPU (training/scripts/multi_gpu.yaml:1-15; train.py:369,559,563): FlatAdamW's
+    hook-launched slices run on RCCL's stream while the backward continues on the compute stream.  Needs two visible GPUs; a one-GPU box skips."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank: %d visible" % torch.cuda.device_count())
+    _two_ranks(dev, "nccl")
+
+
+def _two_ranks(dev, backend):
     from diffusion_e2e_ft_amd import training
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(2)]
