@@ -26,10 +26,12 @@ SIDE = sys.argv[1]
 NDRAWS = int(sys.argv[2]) if len(sys.argv) > 2 else 13
 RES = int(sys.argv[3]) if len(sys.argv) > 3 else 576
 OUT = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "gpurun_out", "bf16_localise")
+VARIANTS = sys.argv[5].split(",") if len(sys.argv) > 5 else ["default"]      # hip side only: default, nostats, nopatch, nothin, nopersist, noflashbwd, nowgrad, vaeattn_fp32, vae_fp32, unet_fp32
 GRAD_KEYS = ["conv_in.weight", "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight", "down_blocks.1.resnets.0.conv1.weight",
              "mid_block.attentions.0.proj_in.weight", "mid_block.resnets.1.conv2.weight", "up_blocks.1.resnets.0.conv_shortcut.weight",
              "up_blocks.2.attentions.1.transformer_blocks.0.attn2.to_k.weight", "up_blocks.3.resnets.2.norm2.weight", "conv_norm_out.bias", "conv_out.weight"]
 JITTER = 1e-3
+INSTANCE = os.environ.get("BF16_INSTANCE", "oracle")     # "oracle": the oracle's seeded network + CPU-generated sample (runs anywhere); "gpuseeded": see below
 
 
 def rel(a, r):
@@ -37,7 +39,43 @@ def rel(a, r):
     return ((a - r).norm() / r.norm().clamp_min(1e-300)).item()
 
 
-def report(side, order, ref_f, ref_b, draws):
+DUMP = os.environ.get("BF16_DUMP")          # path: save the decoder output (est) and the gradient w.r.t. it of the fp32 run and of every draw
+DUMPED = {"draws": []}
+
+
+def dump_draw(fw, bw, ref=False):
+    if not DUMP:
+        return
+    f, b = fw["decoder.conv_out"], bw["decoder.conv_out"]
+    if f.shape[-1] != f.shape[-2]:          # NHWC (hip side, channel-padded) -> NCHW
+        f, b = f[..., :3].permute(0, 3, 1, 2), b[..., :3].permute(0, 3, 1, 2)
+    rec = (f.detach().float().cpu().contiguous(), b.detach().float().cpu().contiguous())
+    if ref:
+        DUMPED["ref"] = rec
+    else:
+        DUMPED["draws"].append((rec[0].to(torch.bfloat16), rec[1].to(torch.bfloat16)))
+    torch.save(DUMPED, DUMP)
+
+
+SYS = {}       # name -> [sum over draws of (forward activation - reference with bf16-ROUNDED WEIGHTS in fp32 arithmetic), count]
+
+
+def sys_add(fw, ref2_f, cut=None):
+    for k, v in fw.items():
+        if k in ref2_f:
+            a, r = v.float(), ref2_f[k].float()
+            if a.shape != r.shape:
+                c = min(a.shape[-1], r.shape[-1])
+                a, r = a[..., :c], r[..., :c]
+            d = a - r
+            if k in SYS:
+                SYS[k][0] += d
+                SYS[k][1] += 1
+            else:
+                SYS[k] = [d.clone(), 1]
+
+
+def report(side, order, ref_f, ref_b, draws, ref2_f=None, draws2=None):
     """draws: list of (fwd dict, bwd dict) of relative errors"""
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open("%s_%s.tsv" % (OUT, side), "w") as f:
@@ -48,6 +86,20 @@ def report(side, order, ref_f, ref_b, draws):
                 vals = [dr[which][name] for dr in draws if name in dr[which]]
                 if vals:
                     f.write("%s\t%s\t%.4e\t%.4e\t%.4e\t%s\n" % (name, d, statistics.median(vals), min(vals), max(vals), " ".join("%.3e" % v for v in vals)))
+        if ref2_f is not None:
+            f.write("# --- against fp32 ARITHMETIC ON THE bf16-ROUNDED WEIGHTS (the rounding of the weights is common to every bf16 implementation: what is left is the arithmetic)\n")
+            f.write("# probe\tdir\tmedian rel L2 error vs that reference\tsystematic part: |mean over draws of the error field| / |reference|\n")
+            for name in order:
+                vals = [dr[0][name] for dr in (draws2 or []) if name in dr[0]]
+                if vals and name in SYS:
+                    r = ref2_f[name].float()
+                    m = SYS[name][0] / SYS[name][1]
+                    if m.shape != r.shape:
+                        r = r[..., :m.shape[-1]]
+                    f.write("#2 %s\tfwd\t%.4e\t%.4e\n" % (name, statistics.median(vals), (m.double().norm() / r.double().norm()).item()))
+                vals = [dr[1][name] for dr in (draws2 or []) if name in dr[1]]
+                if vals:
+                    f.write("#2 %s\tbwd\t%.4e\n" % (name, statistics.median(vals)))
         worst = [max(dr[1][k] for k in dr[1] if k.startswith("param:")) for dr in draws]
         q = statistics.quantiles(worst, n=4) if len(worst) >= 4 else [float("nan")] * 3
         f.write("# worst sampled parameter-gradient error per draw: %s\n" % " ".join("%.3e" % w for w in worst))
@@ -59,11 +111,23 @@ if SIDE == "cpu":
     torch.set_num_threads(os.cpu_count())
     from oracle import config, pipeline_ref, unet_ref, vae_ref, synth
     from diffusion_e2e_ft_amd import training
-    usd = synth.synth_state_dict(unet_ref.unet_param_shapes(config.SD2_UNET), seed=1234)
-    vsd = synth.synth_state_dict(vae_ref.vae_param_shapes(config.SD_VAE), seed=4321)
     g = torch.Generator().manual_seed(9)
     text = 0.5 * torch.randn((1, 77, 1024), generator=g)
-    batch = {k: v.cpu() for k, v in training.synthetic_batch(1, RES, RES, torch.device("cpu"), seed=3).items()}
+    if INSTANCE == "gpuseeded":      # the instance tests/test_fullsize_parity_gpu.py used through round 3: network and sample drawn by the DEVICE generator (needs the GPU box)
+        from diffusion_e2e_ft_amd import unet as unet_mod, vae as vae_mod
+        from diffusion_e2e_ft_amd.synth import init_synthetic_
+        dev = torch.device("cuda:0")
+        with torch.device(dev):
+            un, va = unet_mod.UNet2DConditionModel(in_channels=8), vae_mod.AutoencoderKL()
+        init_synthetic_(un, seed=1234); init_synthetic_(va, seed=4321)
+        usd = {k: v.detach().float().cpu() for k, v in un.state_dict().items()}
+        vsd = {k: v.detach().float().cpu() for k, v in va.state_dict().items()}
+        batch = {k: v.cpu() for k, v in training.synthetic_batch(1, RES, RES, dev, seed=3).items()}
+        del un, va
+    else:
+        usd = synth.synth_state_dict(unet_ref.unet_param_shapes(config.SD2_UNET), seed=1234)
+        vsd = synth.synth_state_dict(vae_ref.vae_param_shapes(config.SD_VAE), seed=4321)
+        batch = {k: v.cpu() for k, v in training.synthetic_batch(1, RES, RES, torch.device("cpu"), seed=3).items()}
     PROBES, ORDER = {}, []
 
     def pname(name):
@@ -103,13 +167,14 @@ if SIDE == "cpu":
         return z
     pipeline_ref.encode_rgb_ref = enc
 
-    def run(dt, jitter):
+    def run(dt, jitter, round_weights=False):
         PROBES.clear()
         STATE["jitter"] = jitter
-        sd = {k: v.to(dt) for k, v in usd.items()}
+        rw = (lambda v: v.to(torch.bfloat16).to(dt)) if round_weights else (lambda v: v.to(dt))
+        sd = {k: rw(v) for k, v in usd.items()}
         for k in GRAD_KEYS:
-            sd[k] = usd[k].to(dt).clone().requires_grad_(True)
-        vs = {k: v.to(dt) for k, v in vsd.items()}
+            sd[k] = rw(usd[k]).clone().requires_grad_(True)
+        vs = {k: rw(v) for k, v in vsd.items()}
         b = dict(batch)
         b["rgb"] = batch["rgb"].to(dt)
         t0 = time.time()
@@ -124,13 +189,18 @@ if SIDE == "cpu":
         return fw, bw
 
     ref_f, ref_b = run(torch.float32, None)
+    dump_draw(ref_f, ref_b, ref=True)
+    ref2_f, ref2_b = run(torch.float32, None, round_weights=True)
     order = list(ORDER) + ["param:" + k for k in GRAD_KEYS]
-    draws = []
+    draws, draws2 = [], []
     for s in range(NDRAWS):
         fw, bw = run(torch.bfloat16, None if s == 0 else s)
+        dump_draw(fw, bw)
         draws.append(({k: rel(fw[k], ref_f[k]) for k in fw}, {k: rel(bw[k], ref_b[k]) for k in bw}))
+        draws2.append(({k: rel(fw[k], ref2_f[k]) for k in fw}, {k: rel(bw[k], ref2_b[k]) for k in bw}))
+        sys_add(fw, ref2_f)
         del fw, bw
-        report("cpu", order, ref_f, ref_b, draws)
+        report("cpu", order, ref_f, ref_b, draws, ref2_f, draws2)
         print("draw %d: worst sampled parameter gradient %.3e" % (s, max(v for k, v in draws[-1][1].items() if k.startswith("param:"))), flush=True)
 
 # =====================================================================================================================================
@@ -141,11 +211,20 @@ elif SIDE == "hip":
     with torch.device(dev):
         unet = unet_mod.UNet2DConditionModel(in_channels=8)
         vae = vae_mod.AutoencoderKL()
-    init_synthetic_(unet, seed=1234)
-    init_synthetic_(vae, seed=4321)
+    # the SAME network and the SAME sample as the cpu side: the oracle's seeded state dicts (per-key CPU generators) loaded into the product modules, inputs from
+    # the CPU generator.  (The error of a bf16 run depends strongly on the instance — L1 loss: every prediction error that flips the sign of a residual flips
+    # that pixel's gradient — so two sides on different random networks cannot be compared.)
     g = torch.Generator().manual_seed(9)
     text = 0.5 * torch.randn((1, 77, 1024), generator=g)
-    batch = {k: v.cpu() for k, v in training.synthetic_batch(1, RES, RES, dev, seed=3).items()}
+    if INSTANCE == "gpuseeded":
+        init_synthetic_(unet, seed=1234)
+        init_synthetic_(vae, seed=4321)
+        batch = {k: v.cpu() for k, v in training.synthetic_batch(1, RES, RES, dev, seed=3).items()}
+    else:
+        from oracle import config, unet_ref, vae_ref, synth
+        unet.load_state_dict(synth.synth_state_dict(unet_ref.unet_param_shapes(config.SD2_UNET), seed=1234))
+        vae.load_state_dict(synth.synth_state_dict(vae_ref.vae_param_shapes(config.SD_VAE), seed=4321))
+        batch = {k: v.cpu() for k, v in training.synthetic_batch(1, RES, RES, torch.device("cpu"), seed=3).items()}
     NAMES, FW, BW, ORDER = {}, {}, {}, []
 
     def rec(mod, out, suffix=""):
@@ -183,20 +262,26 @@ elif SIDE == "hip":
         m.conv_nhwc = conv_w
     orig_enc = training.encode_image
 
-    def run(dt, jitter):
+    def run(dt, jitter, udt=None, vdt=None, round_weights=False):
         FW.clear(); BW.clear(); NAMES.clear()
         u = copy.deepcopy(unet).train()
         v = copy.deepcopy(vae).eval().requires_grad_(False)
-        if dt != torch.float32:
-            u = u.set_compute_dtype(dt)
-            v = v.to(dt)
+        if round_weights:
+            with torch.no_grad():
+                for prm in list(u.parameters()) + list(v.parameters()):
+                    prm.copy_(prm.to(torch.bfloat16).float())
+        udt, vdt = udt or dt, vdt or dt
+        if udt != torch.float32:
+            u = u.set_compute_dtype(udt)
+        if vdt != torch.float32:
+            v = v.to(vdt)
         for n, m in u.named_modules():
             NAMES[id(m)] = "unet." + n
         for n, m in v.named_modules():
             NAMES[id(m)] = n
 
         def enc(vae_, rgb):
-            z = orig_enc(vae_, rgb)
+            z = orig_enc(vae_, rgb.to(vdt)).to(udt)
             if jitter is None:
                 return z
             gj = torch.Generator(device=z.device).manual_seed(jitter)
@@ -220,13 +305,68 @@ elif SIDE == "hip":
         return rel(a[..., :c], r[..., :c])
 
     ref_f, ref_b = run(torch.float32, None)
+    dump_draw(ref_f, ref_b, ref=True)
+    ref2_f, ref2_b = run(torch.float32, None, round_weights=True)
     order = list(ORDER) + ["param:" + k for k in GRAD_KEYS]
-    draws = []
-    for s in range(NDRAWS):
-        fw, bw = run(torch.bfloat16, None if s == 0 else s)
-        draws.append(({k: relc(fw[k], ref_f[k]) for k in fw if k in ref_f}, {k: relc(bw[k], ref_b[k]) for k in bw if k in ref_b}))
-        del fw, bw
-        report("hip", order, ref_f, ref_b, draws)
-        print("draw %d: worst sampled parameter gradient %.3e" % (s, max(v for k, v in draws[-1][1].items() if k.startswith("param:"))), flush=True)
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import _options
+    from diffusion_e2e_ft_amd import ops, autograd
+    DEF = {"thin_input_conv": 1, "patch_conv": 1, "persistent": 1}
+    _vae_train_attn = modules.VaeAttention.nhwc
+
+    def vae_attn_fp32(self, x):
+        """diagnostic: the decoder's 512-wide head under autograd computed by torch in fp32 from the bf16 q | k | v (the product runs bgemm + softmax_rows in bf16)"""
+        import torch.nn.functional as TF
+        from diffusion_e2e_ft_amd import autograd as F
+        B, H, W, C = x.shape
+        if not F.needs_grad(x, self.to_q.weight):
+            return _vae_train_attn(self, x)
+        n, x = self.group_norm.nhwc(x, split=True)
+        n = n.view(B, H * W, C)
+        bias = torch.cat([self.to_q.bias, self.to_k.bias, self.to_v.bias])
+        qkv = F.linear(n, (self.to_q.weight, self.to_k.weight, self.to_v.weight), bias, owner=self, name="wqkv")
+        q, k, v = (t.float()[:, None] for t in (qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]))
+        a = TF.scaled_dot_product_attention(q, k, v)[:, 0].to(qkv.dtype)
+        out = self.to_out[0](a, residual=x.reshape(B, H * W, C)).view(B, H, W, C)
+        rec(self, out)
+        return out
+
+    for var in VARIANTS:
+        opts = dict(DEF)
+        ops.GN_STATS_ENABLED, autograd.FLASH_BACKWARD, ops.WGRAD_DIRECT = True, True, True
+        modules.VaeAttention.nhwc = _vae_train_attn
+        udt = vdt = torch.bfloat16
+        if var == "nostats":
+            ops.GN_STATS_ENABLED = False
+        elif var == "nopatch":
+            opts["patch_conv"] = 0
+        elif var == "nothin":
+            opts["thin_input_conv"] = 0
+        elif var == "nopersist":
+            opts["persistent"] = 0
+        elif var == "noflashbwd":
+            autograd.FLASH_BACKWARD = False
+        elif var == "nowgrad":
+            ops.WGRAD_DIRECT = False
+        elif var == "vaeattn_fp32":
+            modules.VaeAttention.nhwc = vae_attn_fp32
+        elif var == "vae_fp32":
+            vdt = torch.float32
+        elif var == "unet_fp32":
+            udt = torch.float32
+        elif var != "default":
+            raise SystemExit("unknown variant %s" % var)
+        _options.take(["%s=%d" % kv for kv in opts.items()])
+        draws, draws2 = [], []
+        SYS.clear()
+        for s in range(NDRAWS):
+            fw, bw = run(torch.bfloat16, None if s == 0 else s, udt, vdt)
+            dump_draw(fw, bw)
+            draws.append(({k: relc(fw[k], ref_f[k]) for k in fw if k in ref_f}, {k: relc(bw[k], ref_b[k]) for k in bw if k in ref_b}))
+            draws2.append(({k: relc(fw[k], ref2_f[k]) for k in fw if k in ref2_f}, {k: relc(bw[k], ref2_b[k]) for k in bw if k in ref2_b}))
+            sys_add(fw, ref2_f)
+            del fw, bw
+            report("hip" if var == "default" else "hip_" + var, order, ref_f, ref_b, draws, ref2_f, draws2)
+            print("%s draw %d: worst sampled parameter gradient %.3e" % (var, s, max(v for k, v in draws[-1][1].items() if k.startswith("param:"))), flush=True)
 else:
     raise SystemExit(__doc__)

@@ -81,7 +81,7 @@ def test_groupnorm_silu_256_fwd_bwd_past_4gib(dev, cpu_threads, dtype, B):
     dg_ref, db_ref = torch.zeros(C), torch.zeros(C)
     for i in (0, last):
         xi = _nchw(x.detach()[i:i + 1]).requires_grad_(True)
-        gr, br = ga.float().requires_grad_(True), be.float().requires_grad_(True)
+        gr, br = ga.float().clone().requires_grad_(True), be.float().clone().requires_grad_(True)     # (clone: .float() of an fp32 tensor is the tensor itself)
         ref = TF.silu(TF.group_norm(xi, 32, gr, br, 1e-6))
         ref.backward(_nchw(dy[i:i + 1]))
         ef, eb = _errs(y.detach()[i:i + 1], ref.detach()), _errs(x.grad[i:i + 1], xi.grad)
@@ -258,17 +258,27 @@ def test_config2_fp32_batch16_step_is_the_weighted_sum_of_its_single_image_steps
 def test_config2_bf16_batch32_step_equals_its_mirrored_batch(dev, models):
     """configs[2] as bench.py's `train_step` leg runs it (bf16 compute over fp32 master weights, bf16 frozen VAE, one micro-batch of 32 at 576^2): the
     batch and its mirror (sample i <-> 31 - i) hold the same samples at opposite ends of the > 4 GiB tensors, so their gradients must agree to the
-    accumulation order of the weight-gradient reductions — unless some kernel computes a sample differently depending on where it lies."""
+    accumulation order of the weight-gradient reductions — unless some kernel computes a sample differently depending on where it lies.
+    One kernel does, by design: the fused d = 512 attention of the (no-grad) encoder cuts the LAST, partial round of its workgroups along the keys
+    (attn512.hip, tail balancing) and which samples fall into that round depends on the slot — a different summation order, i.e. a re-draw of the bf16
+    rounding noise of everything downstream (measured: 2.2-3.5e-2 between the batch and its mirror, scripts/slot_dependence.py names the probe).  That
+    balancing is switched off here (ops.ATTN512_SPLIT_TAIL); what is left must be slot-independent."""
+    from diffusion_e2e_ft_amd import ops
     unet, vae, text = models
     B = 32
     batch = _batch(dev, B, torch.bfloat16)
     mirror = {k: v.flip(0).contiguous() for k, v in batch.items()}
-    la, ga = _grads(unet, vae, batch, text, torch.bfloat16)
-    lb, gb = _grads(unet, vae, mirror, text, torch.bfloat16)
+    keep = ops.ATTN512_SPLIT_TAIL
+    ops.ATTN512_SPLIT_TAIL = False
+    try:
+        la, ga = _grads(unet, vae, batch, text, torch.bfloat16)
+        lb, gb = _grads(unet, vae, mirror, text, torch.bfloat16)
+    finally:
+        ops.ATTN512_SPLIT_TAIL = keep
     errs = {k: ((ga[k] - gb[k]).norm() / ga[k].norm()).item() for k in KEYS}
-    print("configs[2] bf16 batch 32 @576: loss %.6f / mirrored %.6f; gradient rel L2 difference %s"
+    print("configs[2] bf16 batch 32 @576: loss %.8f / mirrored %.8f; gradient rel L2 difference %s"
           % (la, lb, {k.split(".")[0] + ".." + k.split(".")[-2]: "%.1e" % e for k, e in errs.items()}))
-    assert abs(la - lb) / abs(la) <= 1e-5, (la, lb)
+    assert abs(la - lb) / abs(la) <= 1e-6, (la, lb)
     assert max(errs.values()) <= 1e-3, errs
     # and against the fp32 step on the two valid samples (the bf16 rounding-noise bar of tests/test_fullsize_parity_gpu.py, as a sanity bound only)
     sub = {k: torch.cat([v[:1], v[B - 1:]]) for k, v in batch.items()}
