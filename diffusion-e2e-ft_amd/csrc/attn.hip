@@ -81,6 +81,16 @@ __device__ __forceinline__ u32x2 tr_read(const char* p) {
 // launch_bounds(256, 2): two workgroups per CU caps the wave at 256 registers, which makes the compiler keep the MFMA
 // accumulators in VGPRs — with the 512-register budget it parks O^T / S^T in AGPRs and pays a v_accvgpr_read + write per
 // element per tile for the online-softmax rescale (measured: 255 of ~600 VALU instructions per tile).
+// -DE2EFT_ATTN_PROBE=n (scripts/experiments/attn_probe.hip only; never defined in the library build): ceiling probes, WRONG results by construction.
+// 1: K / V tile 0 pinned in LDS (no global loads, LDS stores or barrier in the loop); 2: 1 + no softmax VALU; 3: 1 + no LDS fragment reads in the loop;
+// 4: production traffic without the softmax VALU.
+#ifdef E2EFT_ATTN_PROBE
+constexpr int PROBE = E2EFT_ATTN_PROBE;
+#else
+constexpr int PROBE = 0;
+#endif
+constexpr bool PROBE_PINNED = PROBE >= 1 && PROBE <= 3, PROBE_NOSM = PROBE == 2 || PROBE == 4, PROBE_NOLDS = PROBE == 3;
+
 template <typename T, bool JOINT, int QB>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KVBUF];
@@ -200,10 +210,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     load_tile(0);
     store_tile(0);
     __syncthreads();
+    u32x4 hk[2][4], hv[2][2][2];     // PROBE 3 only: the fragments of tile 0, read once
+    if constexpr (PROBE_NOLDS) {
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) hk[kt2][ds] = *reinterpret_cast<const u32x4*>(smem + (kt2 * 32 + l31) * KROW + hh * 16 + ds * 32);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* vb = smem + KTILE + vfrag + (kt2 * 32 + 16 * s2) * VROW;
+                    const u32x2 v0 = tr_read(vb + dt * 64), v1 = tr_read(vb + 8 * VROW + dt * 64);
+                    hv[kt2][s2][dt] = u32x4{v0[0], v0[1], v1[0], v1[1]};
+                }
+        }
+    }
 
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        const bool more = t + 1 < nt;
+        const int buf = PROBE_PINNED ? 0 : (t & 1);
+        const bool more = t + 1 < nt && !PROBE_PINNED;
         if (more) load_tile(t + 1);
 
         const char* sk = smem + buf * KVBUF;
@@ -212,11 +238,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         // ---- S'^T = K Q'^T - m_ref : two 32-key sub-tiles ----
         floatx16 s[2];
 #pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2) {
+        for (int kt2 = 0; kt2 < 2; ++kt2) {     // (round 4: alternating the two blocks' MFMAs — no dependent neighbours — measured 781 against 795 TF/s this way round)
             const char* row = sk + (kt2 * 32 + l31) * KROW + hh * 16;
-            s[kt2] = MmaA<T>::run(*reinterpret_cast<const u32x4*>(row), qf[0][0], cinit);
+            if constexpr (PROBE_NOLDS) {
+                s[kt2] = MmaA<T>::run(hk[kt2][0], qf[0][0], cinit);
 #pragma unroll
-            for (int ds = 1; ds < 4; ++ds) s[kt2] = MmaA<T>::run(*reinterpret_cast<const u32x4*>(row + ds * 32), qf[0][ds], s[kt2]);
+                for (int ds = 1; ds < 4; ++ds) s[kt2] = MmaA<T>::run(hk[kt2][ds], qf[0][ds], s[kt2]);
+            } else {
+                s[kt2] = MmaA<T>::run(*reinterpret_cast<const u32x4*>(row), qf[0][0], cinit);
+#pragma unroll
+                for (int ds = 1; ds < 4; ++ds) s[kt2] = MmaA<T>::run(*reinterpret_cast<const u32x4*>(row + ds * 32), qf[0][ds], s[kt2]);
+            }
         }
         // ---- mask keys beyond nk_total (last tile only) ----
         if (t * 64 + 64 > p.nk_total) {
@@ -228,6 +260,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                     if (key >= p.nk_total) s[kt2][r] = -INFINITY;
                 }
         }
+        uint32_t pw[2][8];
+        if constexpr (PROBE_NOSM) {
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) pw[kt2][w] = (__float_as_uint(s[kt2][2 * w]) & 0x3fff3fffu) ^ (__float_as_uint(s[kt2][2 * w + 1]) >> 18);
+        } else {
         // ---- tile maximum relative to the reference (v_max3_f32: 16 instructions for 32 values) ----
         float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
 #pragma unroll
@@ -253,12 +292,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             first = false;
         }
         // ---- probabilities: one v_exp_f32 per score, packed straight into the B operand of the second MFMA ----
-        uint32_t pw[2][8];
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
             for (int w = 0; w < 8; ++w)
                 pw[kt2][w] = Pk<T>::pack(__builtin_amdgcn_exp2f(s[kt2][2 * w]), __builtin_amdgcn_exp2f(s[kt2][2 * w + 1]));
+        }
 
         // ---- O^T += V^T P^T and l^T += 1 P^T ----
 #pragma unroll
@@ -270,17 +309,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
                 const char* vb = sv + vfrag + (kt2 * 32 + 16 * s2) * VROW;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const u32x2 v0 = tr_read(vb + dt * 64);
-                    const u32x2 v1 = tr_read(vb + 8 * VROW + dt * 64);
-                    const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
-                    o[dt] = MmaA<T>::run(vf, pf, o[dt]);
+                    if constexpr (PROBE_NOLDS) {
+                        o[dt] = MmaA<T>::run(hv[kt2][s2][dt], pf, o[dt]);
+                    } else {
+                        const u32x2 v0 = tr_read(vb + dt * 64);
+                        const u32x2 v1 = tr_read(vb + 8 * VROW + dt * 64);
+                        const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+                        o[dt] = MmaA<T>::run(vf, pf, o[dt]);
+                    }
                 }
                 lacc = MmaA<T>::run(ones_v, pf, lacc);
             }
         }
 
         if (more) store_tile(buf ^ 1);
-        __syncthreads();
+        if constexpr (!PROBE_PINNED) __syncthreads();
     }
 
     // ---- epilogue: O / l, 8-byte stores of 4 consecutive d (every accumulator register of lacc holds the query's full row sum) ----
@@ -303,6 +346,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         }
     }
 }
+
 
 }  // namespace e2eft
 

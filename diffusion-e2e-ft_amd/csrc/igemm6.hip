@@ -204,12 +204,13 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     u32x4 n_o;
     unsigned n_addr = 0, n_t = 0;
     bool n_on = false;
+    const bool n_silu = p.nrm_silu != 0;
     auto norm_issue = [&](auto ic, const int pbuf) {   // the patch unit and the coefficients of its first four channels
         constexpr int i = decltype(ic)::value;
         const int j = wave + 8 * i;
-        n_on = j < PPIECES;                                          // (wave-uniform)
-        if (!n_on) return;
-        n_addr = lds_base + (unsigned)(pbuf + j * 1024) + (unsigned)lane * 16u;
+        n_on = j < PPIECES;                                          // (wave-uniform) pieces beyond the 43rd: the arithmetic runs on the dump kilobyte and nothing is stored —
+        // no branch: a basic-block boundary would keep the arithmetic out of the MFMA shadow
+        n_addr = lds_base + (unsigned)(n_on ? pbuf + j * 1024 : OFF_DUMP + wave * 1024) + (unsigned)lane * 16u;
         n_t = lds_base + (unsigned)OFF_TAB + (unsigned)n_c0 * 4u;
         const unsigned ad = n_addr, ta = n_t;
         u32x4 x0;
@@ -221,7 +222,6 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         n_x = x0; n_a = t0; n_m = t1; n_b = t2;
     };
     auto norm_issue2 = [&]() {   // the coefficients of the unit's last four channels (into the registers the first half is done with)
-        if (!n_on) return;
         const unsigned ta = n_t;
         floatx4 t0, t1, t2;
         asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(t0) : "v"(ta) : "memory");
@@ -235,32 +235,55 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(t0), "+v"(t1), "+v"(t2) :: "memory");
         n_x = x0; n_a = t0; n_m = t1; n_b = t2;
     };
-    auto norm_half = [&](auto hc) {   // values 4 hf .. 4 hf + 3 of the unit: gn_apply_kernel's arithmetic (norm.hip) on natural fp32 pairs — packed sub / fma / mul / add, one v_exp + one v_rcp per value, one packed convert per pair
-        constexpr int hf = decltype(hc)::value;
-        if (!n_on) return;
+    // the four reads of norm_issue are the OLDEST of the (at most) twelve LDS reads in flight when this runs (eight fragment reads were requested behind them;
+    // LDS returns in order, LDS-DMA counts on vmcnt, the loop has no scalar loads): at most eight outstanding = they are back
+    auto norm_ready = [&]() {
+        u32x4 x0 = n_x;
+        floatx4 t0 = n_a, t1 = n_m, t2 = n_b;
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x0), "+v"(t0), "+v"(t1), "+v"(t2) :: "memory");
+        n_x = x0; n_a = t0; n_m = t1; n_b = t2;
+    };
+    auto norm_mark = [&]() {    // behind a wait that already covered norm_issue2's reads (the barrier's lgkmcnt(0)): only tells the compiler where the values exist
+        floatx4 t0 = n_a, t1 = n_m, t2 = n_b;
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2) :: "memory");
+        n_a = t0; n_m = t1; n_b = t2;
+    };
+    auto norm_pair = [&](auto hc, auto qc) {   // values 4 hf + 2 q2, + 1 of the unit: gn_apply_kernel's arithmetic (norm.hip) on a natural fp32 pair — packed sub / fma / mul, one v_exp + one v_rcp per value, one packed convert
+        constexpr int hf = decltype(hc)::value, q2 = decltype(qc)::value;
         typedef T T2 __attribute__((ext_vector_type(2)));
         Vec16<T> v;
         v.raw = n_x;
+        constexpr int e = 4 * hf + 2 * q2;
+        const f2 xx = {to_f(v.e[e]), to_f(v.e[e + 1])};
+        const f2 aa = {n_a[2 * q2], n_a[2 * q2 + 1]}, mu = {n_m[2 * q2], n_m[2 * q2 + 1]}, be = {n_b[2 * q2], n_b[2 * q2 + 1]};
+        f2 t = __builtin_elementwise_fma(xx - mu, aa, be);
+        {   // silu_f (common.h): t * rcp(1 + exp2(-log2(e) * t)).  The constant operands stay scalar instructions: a packed form would
+            // broadcast them with op_sel — the operand-swizzle family of DESIGN.md §3.6; sub / fma / the last mul run on natural pairs.
+            // Without SiLU the factor is selected to 1 (two v_cndmask instead of a branch: see norm_issue)
+            float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[0] * -1.4426950408889634f));
+            float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[1] * -1.4426950408889634f));
+            if (!n_silu) { r0 = 1.0f; r1 = 1.0f; }
+            t = t * f2{r0, r1};
+        }
+        n_o[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, T2));
+    };
+    auto norm_half = [&](auto hc) { norm_pair(hc, IC6<0>{}); norm_pair(hc, IC6<1>{}); };   // (prologue only: nothing to hide behind)
+    // one MFMA group with one value pair's arithmetic in its shadow: the matrix pipe takes 32 cycles per MFMA, the wave's VALU issues meanwhile — as long as
+    // the instructions alternate.  (Round 3 placed each half behind a whole group: the pipe idled while 30 VALU instructions ran, 806-861 TF/s against 1160-1190.)
+    auto interleave4 = [&]() {
 #pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {
-            const int e = 4 * hf + 2 * q2;
-            const f2 xx = {to_f(v.e[e]), to_f(v.e[e + 1])};
-            const f2 aa = {n_a[2 * q2], n_a[2 * q2 + 1]}, mu = {n_m[2 * q2], n_m[2 * q2 + 1]}, be = {n_b[2 * q2], n_b[2 * q2 + 1]};
-            f2 t = __builtin_elementwise_fma(xx - mu, aa, be);
-            if (p.nrm_silu) {   // silu_f (common.h): t * rcp(1 + exp2(-log2(e) * t)).  The constant operands stay scalar instructions: a packed form would
-                                // broadcast them with op_sel — the operand-swizzle family of DESIGN.md §3.6; sub / fma / the last mul run on natural pairs
-                const float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[0] * -1.4426950408889634f));
-                const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[1] * -1.4426950408889634f));
-                t = t * f2{r0, r1};
-            }
-            n_o[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, T2));
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four VALU
         }
     };
     auto norm_store = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const unsigned ad = n_addr;
+        // padding rows (zeros from the out-of-range fetch) stay zero and pieces beyond the 43rd do not exist: their results go to the dump kilobyte.  An address
+        // select, not a branch: the compiler sinks the whole arithmetic into a conditional block around the store, i.e. out of the MFMA shadow
+        const unsigned ad = (n_on && pix[i] >= 0) ? n_addr : lds_base + (unsigned)(OFF_DUMP + wave * 1024) + (unsigned)lane * 16u;
         const u32x4 ov = n_o;
-        if (n_on && pix[i] >= 0) asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(ov) : "memory");   // padding rows (zeros from the out-of-range fetch) stay zero
+        asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(ov) : "memory");
     };
 
     floatx16 acc[2][2];
@@ -324,9 +347,14 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
             b0[sl] = *reinterpret_cast<const u32x4*>(smem + sb + bofs[g]);
             b1[sl] = *reinterpret_cast<const u32x4*>(smem + sb + bofs[g] + 32 * 128);
         };
+        constexpr bool NRM = NORM && t >= 2 && t <= 7;      // this k-tile normalises piece t - 2 of the next patch (landed since the previous k-tile's wait)
+        // the unit and the coefficients of its first four channels are requested FIRST: LDS returns in order, so the wait the compiler puts in front of group 0's
+        // first MFMA (for fragments requested after these) covers them
+        if constexpr (NRM) norm_issue(IC6<t - 2>{}, pnext);
         rd(IC6<0>{}, IC6<0>{});
         rd(IC6<1>{}, IC6<1>{});
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NRM) norm_ready();
         rd(IC6<2>{}, IC6<2>{});
         if constexpr (!(CK == 2 && t == 7)) fire_b(bs_dst, kofs);
         __builtin_amdgcn_sched_barrier(0);
@@ -339,6 +367,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         } else {
             mma_group(a0[0], a1[0], b0[0], b1[0]);
         }
+        if constexpr (NRM) { norm_pair(IC6<0>{}, IC6<0>{}); interleave4(); }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (CK == 1 && t == 0) enter_tile();
         if constexpr (t == 0) {
@@ -368,8 +397,9 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         if constexpr (t < 6) fire_a(IC6<t>{}, pnext);   // k-tiles 6-8 of a chunk issue the two weight pieces only
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[1], a1[1], b0[1], b1[1]);
+        if constexpr (NRM) { norm_pair(IC6<0>{}, IC6<1>{}); interleave4(); }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NORM && t >= 2 && t <= 7) norm_issue(IC6<t - 2>{}, pnext);   // piece t - 2 of the next patch: landed since the previous k-tile's wait
+        if constexpr (NRM) norm_issue2();                // coefficients of the last four channels: back before the barrier (its lgkmcnt(0))
         // lgkmcnt(0): this wave's reads of the current stage have RETURNED before the barrier lets others overwrite it
         if constexpr (CK == 2 && t == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else if constexpr (CK == 2 && t == 7) {   // younger than the previous k-tile's pieces: this k-tile's operand requests + its two weight pieces
@@ -383,11 +413,12 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (NRM) norm_mark();
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[2], a1[2], b0[2], b1[2]);
-        if constexpr (NORM && t >= 2 && t <= 7) { __builtin_amdgcn_sched_barrier(0); norm_half(IC6<0>{}); norm_issue2(); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (NRM) { norm_pair(IC6<1>{}, IC6<0>{}); interleave4(); __builtin_amdgcn_sched_barrier(0); }
         mma_group(a0[0], a1[0], b0[0], b1[0]);
-        if constexpr (NORM && t >= 2 && t <= 7) { __builtin_amdgcn_sched_barrier(0); norm_wait(); norm_half(IC6<1>{}); norm_store(IC6<t - 2>{}); }
+        if constexpr (NRM) { norm_pair(IC6<1>{}, IC6<1>{}); interleave4(); __builtin_amdgcn_sched_barrier(0); norm_store(IC6<t - 2>{}); }
         asm volatile("" ::: "memory");
         { const int x = bs_cur; bs_cur = bs_nxt; bs_nxt = bs_dst; bs_dst = x; }
         if constexpr (t == 8) { const int x = pcur; pcur = pnext; pnext = x; }

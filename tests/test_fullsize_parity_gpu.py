@@ -219,36 +219,52 @@ def test_vae_midblock_attention_512_wide_9216_tokens(dev, dtype, cpu_threads):
 
 
 # ---- (iv) training micro-step at the configs[2] resolution ------------------------------------------------------------------------
+# (the list scripts/bf16_localise.py samples: the torch-bf16 calibration below is the worst error over exactly these ten tensors)
 GRAD_KEYS = ["conv_in.weight", "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight", "down_blocks.1.resnets.0.conv1.weight",
-             "mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj.weight", "mid_block.resnets.1.conv2.weight",
-             "up_blocks.1.resnets.0.conv_shortcut.weight", "up_blocks.3.attentions.2.transformer_blocks.0.attn2.to_k.weight",
-             "up_blocks.3.resnets.2.norm2.weight", "conv_norm_out.bias", "conv_out.weight"]
+             "mid_block.attentions.0.proj_in.weight", "mid_block.resnets.1.conv2.weight", "up_blocks.1.resnets.0.conv_shortcut.weight",
+             "up_blocks.2.attentions.1.transformer_blocks.0.attn2.to_k.weight", "up_blocks.3.resnets.2.norm2.weight", "conv_norm_out.bias", "conv_out.weight"]
 
 
+# ---- (iv) configs[2] resolution: the E2E-FT micro-step ------------------------------------------------------------------------------------------
+# The instance is the one the torch-bf16 calibration was taken on (profiles/r04_bf16_*): the ORACLE's seeded network (oracle.synth.synth_state_dict, per-key CPU
+# generators) loaded into the product modules, the sample from the CPU generator.  Round 4 found that the gradient error of a bf16 run is a property of the
+# instance first and of the implementation second (profiles/r04_bf16_gradient_noise.md): the reference's loss is an L1 over a least-squares-aligned prediction
+# (training/util/loss.py:13-47), every prediction error that moves a residual through zero flips that pixel's gradient, and the smooth part of the gradient has
+# coefficients that are differences of nearly cancelling sums of signs — so two random networks differ by 5x in how much gradient error the same 3 % forward
+# error produces (0.05 on this instance, 0.04 ... 0.17 and 0.14 ... 0.31 on the two device-seeded instances of round 3), for torch's own bf16 as for the HIP path.
 @pytest.fixture(scope="module")
-def oracle_576(dev, models, cpu_threads):
-    """torch autograd over the fp32 CPU oracle of ONE 576x576 micro-step (training/train.py:470-556): loss and the ten sampled gradients.
-    Computed once (1-2 minutes of host time) and shared by the fp32 and the bf16-compute tests below."""
+def calibrated_576(dev, cpu_threads):
+    """product modules carrying the oracle's network + torch autograd over the fp32 CPU oracle of ONE 576x576 micro-step (training/train.py:470-556): loss and the
+    ten sampled gradients.  Computed once (1-2 minutes of host time) and shared by the fp32 and the bf16-compute tests below."""
+    from oracle import synth, vae_ref
     from diffusion_e2e_ft_amd import training
-    _, _, usd, vsd, _ = models
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    from diffusion_e2e_ft_amd.vae import AutoencoderKL
+    usd = synth.synth_state_dict(unet_ref.unet_param_shapes(config.SD2_UNET), seed=1234)
+    vsd = synth.synth_state_dict(vae_ref.vae_param_shapes(config.SD_VAE), seed=4321)
+    with torch.device(dev):
+        unet = UNet2DConditionModel(in_channels=8)
+        vae = AutoencoderKL()
+    unet.load_state_dict(usd)
+    vae.load_state_dict(vsd)
     g = torch.Generator().manual_seed(9)
     text = 0.5 * torch.randn((1, 77, 1024), generator=g)
-    batch = {k: v.cpu() for k, v in training.synthetic_batch(1, 576, 576, dev, seed=3).items()}
+    batch = {k: v.cpu() for k, v in training.synthetic_batch(1, 576, 576, torch.device("cpu"), seed=3).items()}
     sd = dict(usd)
     for k in GRAD_KEYS:
         sd[k] = usd[k].clone().requires_grad_(True)
     loss_ref, _ = pipeline_ref.train_forward_ref(sd, config.SD2_UNET, vsd, config.SD_VAE, batch, text, "depth")
     loss_ref.backward()
-    return batch, text, loss_ref.item(), {k: sd[k].grad.detach().clone() for k in GRAD_KEYS}
+    assert abs(loss_ref.item() - 0.396215) < 2e-5, loss_ref.item()        # the instance of the calibration (its fp32 loss)
+    return unet.eval(), vae.eval(), batch, text, loss_ref.item(), {k: sd[k].grad.detach().clone() for k in GRAD_KEYS}
 
 
-def test_config2_576_fp32_micro_step_gradients(dev, models, oracle_576):
+def test_config2_576_fp32_micro_step_gradients(dev, calibrated_576):
     """BASELINE configs[2] resolution (576x576, 77-token context, `--mixed_precision no`): loss and sampled UNet gradients of one
     micro-step (training/train.py:470-556) against torch autograd over the oracle"""
     import copy
     from diffusion_e2e_ft_amd import training
-    unet, vae, _, _, _ = models
-    batch, text, loss_ref, grads_ref = oracle_576
+    unet, vae, batch, text, loss_ref, grads_ref = calibrated_576
     u = copy.deepcopy(unet).train()
     v = vae.requires_grad_(False)
     loss = training.e2e_ft_loss(u, v, batch, text, "depth")
@@ -262,26 +278,23 @@ def test_config2_576_fp32_micro_step_gradients(dev, models, oracle_576):
     assert max(errs.values()) <= 5e-3, errs
 
 
-def test_config2_576_bf16_compute_micro_step_gradients(dev, models, oracle_576):
-    """The training leg bench.py reports first (`train_step`: bf16 compute over fp32 master weights, bf16 frozen VAE) at the configs[2]
-    resolution against the SAME fp32 oracle.  The error of a bf16 run is a RANDOM VARIABLE, not a number: which way each of ~10^9 roundings
-    goes decides it, and a perturbation of the latent far below one bf16 ulp re-draws them all.  Measured on the final build
-    (scripts/diag_bf16_step2.py, profiles/r03t_bf16_grad_diag_step*.txt): relative L2 error of the sampled gradients 0.024 ... 0.165 (cosine 0.9997 ...
-    0.989) over rounding-equivalent runs — the conv_in kernel (bit-identical output, statistics merged in another order: 0.036 <-> 0.149), a 1e-3
-    relative jitter of the latent (0.036 -> 0.048 / 0.050 / 0.074; 0.149 -> 0.059 / 0.060 / 0.091 / 0.165), GroupNorm statistics fused or not —
-    while each half alone is benign and stable: bf16 UNet + decoder on the fp32 encoder's latent 0.026 under four kernel selections, the fp32 path
-    on the bf16 encoder's latent 0.026-0.038, the fp32 path under a 4e-3 jitter 0.014 (linear response), and the fp32 test above holds 4-9e-5.
-    Thirteen draws on the final build (step6): min 0.039, quartiles 0.057 / 0.079 / 0.105, max 0.165.
-    Plain torch, everything bf16, on the CPU (tests/calibrate_bf16_oracle.py 576: the oracle with a bf16 state dict against its own fp32 run, three
-    draws): 0.030 ... 0.058 — the same order; its tail was not sampled.  (Random-init weights make the network far more chaotic than a trained one:
-    the bound says what THIS fixture can hold.)  So the bar is stated on
-    the distribution: five draws (the plain run and four with a 1e-3 jitter of the latent, different seeds) — loss within 1e-2 in every draw, MEDIAN
-    of the per-draw worst gradient error <= 0.15, no draw beyond 0.30 / cosine below 0.95.  A wrong kernel moves every draw, not the tail."""
+# torch bf16 on this instance (the CPU oracle with a bf16 state dict and bf16 activations against its own fp32 run, 13 draws: profiles/r04b_bf16_localise_cpu.tsv):
+# worst sampled parameter-gradient error per draw min 0.044, quartiles 0.046 / 0.049 / 0.054, max 0.065
+TORCH_BF16_Q75, TORCH_BF16_MAX = 0.054, 0.065
+
+
+def test_config2_576_bf16_compute_micro_step_gradients(dev, calibrated_576):
+    """The training leg bench.py reports first (`train_step`: bf16 compute over fp32 master weights, bf16 frozen VAE) at the configs[2] resolution against the
+    SAME fp32 oracle, on the instance the torch-bf16 calibration was taken on.  The error of a bf16 run is a random variable (a perturbation of the latent far
+    below one bf16 ulp re-draws the roundings), so the bar is on the distribution, and it is DERIVED FROM TORCH'S: five draws (the plain run
+    and four with a 1e-3 jitter of the latent) — loss within 1e-3 in every draw, the MEDIAN of the per-draw worst gradient error <= 1.25 x torch-bf16's 75th
+    percentile, no draw beyond 1.25 x torch-bf16's maximum.  Measured on the round-4 build, 13 draws (profiles/r04b_bf16_localise_hip.tsv): min 0.051, quartiles
+    0.057 / 0.060 / 0.066, max 0.074 — 1.2 x torch at the median with the same spread; the forward activations are CLOSER to fp32 than torch's at every block
+    boundary (0.93-0.95 x), the excess enters at the loss gradient (profiles/r04_bf16_gradient_noise.md)."""
     import copy
     import statistics
     from diffusion_e2e_ft_amd import training
-    unet, vae, _, _, _ = models
-    batch, text, loss_ref, grads_ref = oracle_576
+    unet, vae, batch, text, loss_ref, grads_ref = calibrated_576
     short = lambda k: k.split(".")[0] + ".." + k.split(".")[-2]
     orig = training.encode_image
 
@@ -313,12 +326,12 @@ def test_config2_576_bf16_compute_micro_step_gradients(dev, models, oracle_576):
             cos[k] = torch.nn.functional.cosine_similarity(gq, r, dim=0).item()
         print("576^2 bf16-compute micro-step (latent jitter seed %s): loss rel err %.3e; gradient rel L2 errs %s; cosines %s"
               % (seed, el, {short(k): "%.2e" % e for k, e in l2.items()}, {short(k): "%.4f" % c for k, c in cos.items()}))
-        assert el <= 1e-2, el
+        assert el <= 1e-3, el
         return max(l2.values()), min(cos.values())
 
     draws = [draw(s) for s in (None, 1, 2, 3, 4)]
     med = statistics.median(d[0] for d in draws)
-    print("576^2 bf16-compute micro-step: worst gradient error per draw %s, median %.3e; worst cosine per draw %s"
-          % (["%.3e" % d[0] for d in draws], med, ["%.4f" % d[1] for d in draws]))
-    assert med <= 0.15, draws
-    assert max(d[0] for d in draws) <= 0.30 and min(d[1] for d in draws) >= 0.95, draws
+    print("576^2 bf16-compute micro-step: worst gradient error per draw %s, median %.3e (bar %.4f = 1.25 x torch-bf16's 75th percentile); worst cosine per draw %s"
+          % (["%.3e" % d[0] for d in draws], med, 1.25 * TORCH_BF16_Q75, ["%.4f" % d[1] for d in draws]))
+    assert med <= 1.25 * TORCH_BF16_Q75, draws
+    assert max(d[0] for d in draws) <= 1.25 * TORCH_BF16_MAX and min(d[1] for d in draws) >= 0.995, draws
