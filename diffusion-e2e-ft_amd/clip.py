@@ -177,8 +177,14 @@ class CLIPVisionModelWithProjection(_HubIO, nn.Module):
 def preprocess_for_clip(rgb, size=224, mean=CLIP_IMAGE_MEAN, std=CLIP_IMAGE_STD):
     """geowizard_pipeline.py:236-245: rgb in [-1, 1] [B,3,H,W] -> bicubic antialiased resize of (rgb+1)/2 to size x size, then
     (x - mean) / std in float32 (torchvision TF.resize(antialias=True) == F.interpolate(mode="bicubic", antialias=True))."""
-    x = torch.nn.functional.interpolate((rgb + 1) / 2, size=(size, size), mode="bicubic", antialias=True, align_corners=False)
     as_t = lambda v: v if isinstance(v, torch.Tensor) else torch.tensor(v, device=rgb.device, dtype=torch.float32)[:, None, None]
+    if rgb.is_cuda:      # the table-driven resampler of csrc/prepost.hip with aten's antialiased-bicubic tables; (x + 1) / 2 rides on its store
+        from .pipeline import resize_device
+        B, C3, H, W = rgb.shape
+        with ops.on_device_of(rgb):
+            x = resize_device(rgb.reshape(B * C3, H, W), (size, size), mul=0.5, add=0.5, kind="bicubic").view(B, C3, size, size)
+    else:
+        x = torch.nn.functional.interpolate((rgb + 1) / 2, size=(size, size), mode="bicubic", antialias=True, align_corners=False)
     return ((x.float() - as_t(mean)) / as_t(std)).to(rgb.dtype)
 
 

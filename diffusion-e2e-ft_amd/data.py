@@ -49,6 +49,7 @@ class MixedDataLoader:
         return int(len(self.loader1) * self.frac1) + int(len(self.loader2) * self.frac2)
 
 
+@ops.tensor_scoped
 def hflip_sample(rgb01, depth, normal01=None):
     """synchronised horizontal flip of [..., H, W] tensors; the normal map's x channel (index 0 of dim -3) becomes 1 - x, the float
     form of `255 - x` on the uint8 image (load.py:79-84)."""
@@ -61,6 +62,7 @@ def hflip_sample(rgb01, depth, normal01=None):
 
 
 @torch.no_grad()
+@ops.tensor_scoped
 def prepare_batch(rgb01, depth, normal01, dataset="hypersim", near_plane=None, far_plane=None):
     """rgb01, normal01: [B,3,H,W] in [0,1] (ToTensor of the decoded images); depth: [B,1,H,W] metres -> the batch dict train.py consumes
     (train.py:470-475): rgb [-1,1], depth [B,3,H,W] in [-1,1], metric [B,1,H,W], normals unit / zero, val_mask bool, domain."""
@@ -141,6 +143,7 @@ def _flip_flags(flip, batch, device):
 
 
 @torch.no_grad()
+@ops.tensor_scoped
 def augment_hypersim(rgb_u8, depth, normal_u8=None, size=(480, 640), flip=None):
     """SynchronizedTransform_Hyper (load.py:67-101) on a batch: rgb_u8 / normal_u8 uint8 [B,H0,W0,3] as decoded, depth fp32 [B,H0,W0]; flip:
     per-image booleans (the reference draws `random.random() > 0.5` per sample).  Returns rgb01 [B,3,h,w], depth [B,1,h,w], normal01 or None
@@ -160,6 +163,7 @@ KB_CROP = (352, 1216)     # KITTI benchmark crop (load.py:112-131)
 
 
 @torch.no_grad()
+@ops.tensor_scoped
 def augment_vkitti(rgb_u8, depth, normal_u8=None, flip=None):
     """SynchronizedTransform_VKITTI (load.py:104-152): h-flip, ToTensor, crop the bottom 352 rows / centred 1216 columns"""
     dev = rgb_u8.device

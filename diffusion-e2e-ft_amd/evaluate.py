@@ -29,6 +29,7 @@ def _b(t):
 
 
 @torch.no_grad()
+@ops.tensor_scoped
 def align_depth_least_square(gt_arr, pred_arr, valid_mask_arr, return_scale_shift=True, max_resolution=None):
     """alignment.py:8-56: returns pred * scale + shift (no clipping) [, scale, shift]; inputs [H,W] or [B,H,W] device tensors"""
     gt, pred, mask = _b(gt_arr).float(), _b(pred_arr).float(), _b(valid_mask_arr)
@@ -41,6 +42,7 @@ def align_depth_least_square(gt_arr, pred_arr, valid_mask_arr, return_scale_shif
 
 
 @torch.no_grad()
+@ops.tensor_scoped
 def depth_metrics(pred, gt, valid_mask, alignment="least_square", min_depth=1e-3, max_depth=80.0, alignment_max_res=None, return_aligned=False):
     """pred (affine-invariant prediction), gt (metric depth), valid_mask: [B,H,W] (or [H,W]) device tensors.  alignment: "least_square" |
     "least_square_disparity" (eval.py:172-201).  Returns {metric name: tensor [B]} plus "scale" / "shift" (and "aligned" when asked)."""

@@ -64,6 +64,24 @@ def to_nchw_view(y):
 
 
 # ------------------------------------------------------------------------------------------------------------
+class TimeCond:
+    """SiLU(time embedding) plus, in inference, the `time_emb_proj` outputs of every ResnetBlock2D computed by ONE GEMM (unet.py::_batch_small_gemms): the
+    blocks receive it as the ARGUMENT they receive the embedding in and pick their slice by identity — per-call state travels with the call (round 3 parked
+    the slices in the modules' __dict__: not re-entrant)."""
+    __slots__ = ("act", "rows")
+
+    def __init__(self, act, rows=None):
+        self.act, self.rows = act, (rows or {})
+
+
+class CtxCond:
+    """encoder_hidden_states plus the k | v projections of it for every cross-attention layer from one GEMM (same idea as TimeCond)"""
+    __slots__ = ("ctx", "kv")
+
+    def __init__(self, ctx, kv=None):
+        self.ctx, self.kv = ctx, (kv or {})
+
+
 class Conv2d(nn.Conv2d):
     @ops.device_scoped
     def forward(self, x):  # public NCHW-logical surface (vae.quant_conv(h) etc.)
@@ -71,6 +89,7 @@ class Conv2d(nn.Conv2d):
 
 
 class Linear(nn.Linear):
+    @ops.device_scoped
     def forward(self, x, residual=None, gn_rows_per_image=0):
         # K that is not a 16-byte multiple (GeoWizard's 10-dim class-embedding input) is zero padded inside F.linear
         return F.linear(x, self.weight, self.bias, residual=residual, owner=self, gn_rows_per_image=gn_rows_per_image)
@@ -81,11 +100,13 @@ class GroupNorm(nn.GroupNorm):
         """split=True -> (y, x_skip): x_skip is x for the residual path (its gradient is folded into this norm's backward)"""
         return F.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2, split=split)
 
+    @ops.device_scoped
     def forward(self, x):
         return to_nchw_view(self.nhwc(to_nhwc(x)))
 
 
 class LayerNorm(nn.LayerNorm):
+    @ops.device_scoped
     def forward(self, x):
         return F.layernorm(x, self.weight, self.bias, self.eps)
 
@@ -119,9 +140,10 @@ class ResnetBlock2D(nn.Module):
 
     def nhwc(self, x, temb_act=None, x2=None):
         """x2: second source of a fused channel concat (skip connection, unet_2d_blocks.py:2328,2456)."""
-        rowadd = self.__dict__.pop("_rowadd_pre", None)     # inference: projected for all blocks at once (unet.py::_batch_small_gemms)
-        if torch.is_grad_enabled():
-            rowadd = None                                    # never under autograd: the slice carries no graph
+        rowadd = None
+        if isinstance(temb_act, TimeCond):                   # inference: projected for all blocks at once (unet.py::_batch_small_gemms)
+            rowadd = None if torch.is_grad_enabled() else temb_act.rows.get(id(self))     # never under autograd: the slice carries no graph
+            temb_act = temb_act.act
         if rowadd is None and self.time_emb_proj is not None:
             rowadd = self.time_emb_proj(temb_act)
         if not torch.is_grad_enabled() and x2 is None:
@@ -226,6 +248,10 @@ class Attention(nn.Module):
         B, N, C = x.shape
         d = C // self.heads
         out = self.to_out[0]
+        kv_pre = None
+        if isinstance(ctx, CtxCond):
+            kv_pre = ctx.kv.get(id(self))
+            ctx = ctx.ctx
         if F.needs_grad(x, ctx, self.to_q.weight, self.to_k.weight, self.to_v.weight, out.weight):
             return out(self._forward_train(x, ctx), residual=residual)
         fused = x.dtype != torch.float32 and d == 64
@@ -236,7 +262,7 @@ class Attention(nn.Module):
                 q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
             else:
                 q = self.to_q(x)
-                kv = self.__dict__.pop("_kv_pre", None)         # inference: keys / values of the (shared) context for all layers at once
+                kv = kv_pre                                     # inference: keys / values of the (shared) context for all layers at once
                 if kv is None or torch.is_grad_enabled():
                     kv = F.linear(ctx, (self.to_k.weight, self.to_v.weight), owner=self, name="wkv")
                 k, v = kv[..., :C], kv[..., C:]

@@ -162,6 +162,22 @@ def device_scoped(fn):
     return wrapper
 
 
+def tensor_scoped(fn):
+    """the free-function twin of device_scoped (evaluate / data / ensemble entry points): the call runs with the device of its first HIP tensor argument as
+    the current device — a model on cuda:1 can be evaluated from a thread whose current device is cuda:0 (these raised since _check_cuda stopped switching)"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        t = next((a for a in list(args) + list(kwargs.values()) if isinstance(a, torch.Tensor) and a.is_cuda), None)
+        if t is None:
+            return fn(*args, **kwargs)
+        with on_device_of(t):
+            return fn(*args, **kwargs)
+
+    return wrapper
+
+
 def _nhwc_ld(t):
     """pixel stride of an NHWC view [B,H,W,C]; validates that pixels are densely strided"""
     assert t.dim() == 4, t.shape
@@ -272,11 +288,14 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
     coeff = None
     if norm is not None:
         gamma, beta, groups, eps, silu = norm
-        if NORM_FUSION_ENABLED and x2 is None and not sk and lib.e2eft_conv2d_fwd_normed_supported(C.byref(d)) == 1:
+        # (the <= 4-output-channel route of the supported query, narrow.hip, takes neither a row vector nor a residual nor statistics: ADVICE r3)
+        narrow_ok = cout > 4 or (rowadd is None and residual is None and not want)
+        if NORM_FUSION_ENABLED and x2 is None and not sk and narrow_ok and lib.e2eft_conv2d_fwd_normed_supported(C.byref(d)) == 1:
             ws, coeff = groupnorm_stats(x, gamma, groups, eps)     # (a, mean) pairs; the apply pass is the convolution's operand fetch
         else:
-            x = groupnorm(x, gamma, beta, groups, eps, silu=silu)
-            d.ldx1 = _nhwc_ld(x)
+            x = groupnorm(x, gamma, beta, groups, eps, silu=silu, x2=x2)      # the norm of the CONCATENATED input; its output is one tensor
+            x2 = None
+            d.c1, d.ldx1, d.c2, d.ldx2 = x.shape[3], _nhwc_ld(x), 0, 0
     with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2), nb,
                 label="conv%dx%ds%d%s%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", "n" if coeff is not None else "", B, hout, wout, d.c1 + d.c2, cout)):
         if coeff is not None:

@@ -372,13 +372,31 @@ def _scaled(x, mul):
     return out.permute(0, 3, 1, 2)
 
 
-def aa_bilinear_tables(in_size, out_size, device):
-    """aten `_compute_indices_min_size_weights_aa` (UpSampleKernel.cpp) for the bilinear (triangle) filter, align_corners = False, in aten's
-    float32 arithmetic: (bounds int32 [out, 2] = (first tap, tap count), weights fp32 [out, ksize]) — what `F.interpolate(mode="bilinear",
-    antialias=True)` applies along one dimension.  Built on the host (a few hundred numbers), consumed by e2eft_resample_bilinear_aa."""
+def aa_tables(in_size, out_size, device, kind="bilinear"):
+    """aten `_compute_indices_min_size_weights_aa` (UpSampleKernel.cpp), align_corners = False, in aten's float32 arithmetic: (bounds int32 [out, 2] = (first tap,
+    tap count), weights fp32 [out, ksize]) — what `F.interpolate(mode=kind, antialias=True)` applies along one dimension.  kind "bilinear": the triangle filter
+    (support 1); "bicubic": Keys' cubic with a = -0.5 (support 2) — aten's antialiased bicubic is Pillow's resize (`Image.resize` of a float image, default
+    BICUBIC: the resize-back of GeoWizard's `__call__`, geowizard_pipeline.py:201-203) and torchvision's `resize(..., BICUBIC, antialias=True)` (the CLIP image
+    preprocessing, geowizard_pipeline.py:236-245); "nearest": one tap at floor(i * scale) (cv2.INTER_NEAREST / torch "nearest", geowizard_pipeline.py:205).
+    Built on the host (a few hundred numbers), consumed by e2eft_resample_bilinear_aa (a separable table-driven resampler: the filter lives in the table)."""
     f32 = np.float32
     scale = f32(in_size) / f32(out_size)
-    support = f32(scale) if scale >= 1.0 else f32(1.0)
+    if kind == "nearest":
+        idx = np.minimum(np.floor(np.arange(out_size, dtype=np.float32) * scale).astype(np.int32), in_size - 1)
+        bounds = np.stack([idx, np.ones_like(idx)], axis=1).astype(np.int32)
+        return torch.from_numpy(bounds).to(device), torch.ones((out_size, 1), dtype=torch.float32, device=device)
+    base = {"bilinear": f32(1.0), "bicubic": f32(2.0)}[kind]
+
+    def filt(x):
+        x = np.abs(x)
+        if kind == "bilinear":
+            return np.maximum(f32(0.0), f32(1.0) - x).astype(np.float32)
+        a = f32(-0.5)
+        near = ((a + f32(2.0)) * x - (a + f32(3.0))) * x * x + f32(1.0)
+        far = (((x - f32(5.0)) * x + f32(8.0)) * x - f32(4.0)) * a
+        return np.where(x < 1.0, near, np.where(x < 2.0, far, f32(0.0))).astype(np.float32)
+
+    support = f32(base * scale) if scale >= 1.0 else base
     invscale = f32(1.0) / scale if scale >= 1.0 else f32(1.0)
     ksize = int(np.ceil(support)) * 2 + 1
     bounds = np.zeros((out_size, 2), dtype=np.int32)
@@ -388,7 +406,7 @@ def aa_bilinear_tables(in_size, out_size, device):
         xmin = max(int(center - support + f32(0.5)), 0)
         xsize = min(int(center + support + f32(0.5)), in_size) - xmin
         j = np.arange(xsize, dtype=np.float32)
-        wv = np.maximum(f32(0.0), f32(1.0) - np.abs((j + f32(xmin) - center + f32(0.5)) * invscale)).astype(np.float32)
+        wv = filt((j + f32(xmin) - center + f32(0.5)) * invscale)
         tot = f32(0.0)
         for v in wv:                       # aten sums sequentially in float32
             tot = f32(tot + v)
@@ -399,12 +417,17 @@ def aa_bilinear_tables(in_size, out_size, device):
     return torch.from_numpy(bounds).to(device), torch.from_numpy(weights).to(device)
 
 
-def resize_device(img, size, round_u8=False, mul=1.0, add=0.0):
-    """antialiased bilinear resize of a planar [P,H,W] device tensor (uint8 or fp32) by libe2eft (csrc/prepost.hip) -> fp32 [P,h,w]"""
+def aa_bilinear_tables(in_size, out_size, device):
+    return aa_tables(in_size, out_size, device, "bilinear")
+
+
+def resize_device(img, size, round_u8=False, mul=1.0, add=0.0, kind="bilinear"):
+    """antialiased bilinear (default) / antialiased bicubic / nearest resize of a planar [P,H,W] device tensor (uint8 or fp32) by libe2eft (csrc/prepost.hip)
+    -> fp32 [P,h,w]"""
     H, W = img.shape[-2:]
     h, w = size
     x = img.contiguous() if img.dtype == torch.uint8 else img.float().contiguous()
-    return ops.resample_bilinear_aa(x, (h, w), aa_bilinear_tables(W, w, img.device), aa_bilinear_tables(H, h, img.device), round_u8=round_u8, mul=mul, add=add)
+    return ops.resample_bilinear_aa(x, (h, w), aa_tables(W, w, img.device, kind), aa_tables(H, h, img.device, kind), round_u8=round_u8, mul=mul, add=add)
 
 
 def resize_max_res(img, max_edge_resolution, resample_method="bilinear"):
@@ -648,8 +671,14 @@ class DepthNormalEstimationPipeline:
             depth_pred = (depth_pred - mn) / (mx - mn)
         hwc = False
         if match_input_res and tuple(depth_pred.shape[-2:]) != (H0, W0):
-            depth_pred = torch.nn.functional.interpolate(depth_pred[None, None], size=(H0, W0), mode="bicubic", align_corners=False)[0, 0]
-            normal_pred = torch.nn.functional.interpolate(normal_pred[None], size=(H0, W0), mode="nearest")[0]
+            # geowizard_pipeline.py:201-205: Pillow's resize of the float depth (default BICUBIC = the antialiased Keys cubic, a = -0.5) and cv2.INTER_NEAREST for
+            # the normals — on the device through the table-driven resampler of csrc/prepost.hip; host tensors (CPU plumbing runs) take torch's own kernels
+            if depth_pred.is_cuda:
+                depth_pred = resize_device(depth_pred[None], (H0, W0), kind="bicubic")[0]
+                normal_pred = resize_device(normal_pred, (H0, W0), kind="nearest")
+            else:
+                depth_pred = torch.nn.functional.interpolate(depth_pred[None, None], size=(H0, W0), mode="bicubic", antialias=True, align_corners=False)[0, 0]
+                normal_pred = torch.nn.functional.interpolate(normal_pred[None], size=(H0, W0), mode="nearest")[0]
         if match_input_res:
             normal_pred, hwc = normal_pred.permute(1, 2, 0), True      # the reference returns HWC normals after its cv2 resize (:205)
         return DepthNormalPipelineOutput(depth_np=depth_pred.clamp(0, 1).cpu().numpy().astype(np.float32), depth_colored=None,

@@ -15,7 +15,7 @@ from torch import nn
 
 from . import ops
 from . import autograd as F
-from .modules import (Conv2d, GroupNorm, ResnetBlock2D, Transformer2DModel, Downsample2D, Upsample2D, TimestepEmbedding,
+from .modules import (Conv2d, GroupNorm, ResnetBlock2D, Transformer2DModel, Downsample2D, Upsample2D, TimestepEmbedding, TimeCond, CtxCond,
                       checkpointed, conv_nhwc, to_nhwc, to_nchw_view)
 
 
@@ -282,52 +282,42 @@ class UNet2DConditionModel(nn.Module):
         element); the consumers pick up their slice (`ResnetBlock2D.nhwc`, `Attention.forward`)."""
         from .modules import ResnetBlock2D, Attention
         if not BATCHED_PROJECTIONS:    # A/B switch
-            return
+            return temb_act, ctx
         dt = temb_act.dtype
         fam = self.__dict__.get("_small_gemm_family")
         if fam is None:
             res = [m for m in self.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
             att = [m for m in self.modules() if isinstance(m, Attention) and m.to_k.in_features != m.to_q.in_features
                    and m.to_k.bias is None and m.to_q.in_features // m.heads == 64]
-            fam = self.__dict__["_small_gemm_family"] = (res, att)
+            fam = self.__dict__["_small_gemm_family"] = (res, att)       # (which modules take part: structure, not per-call state)
         res, att = fam
+        tc, cc = temb_act, ctx
         if res:
             ws = tuple(m.time_emb_proj.weight for m in res)
             bs = tuple(m.time_emb_proj.bias for m in res)
             bias = F.cached(self, "b_time_proj_all_%s" % dt, bs, lambda: torch.cat([b.detach().to(dt) for b in bs]))
             out = F.linear(temb_act, ws, bias, owner=self, name="w_time_proj_all")
-            o = 0
+            rows, o = {}, 0
             for m in res:
                 c = m.time_emb_proj.out_features
-                m.__dict__["_rowadd_pre"] = out[:, o:o + c].contiguous()
+                rows[id(m)] = out[:, o:o + c].contiguous()
                 o += c
+            tc = TimeCond(temb_act, rows)
         if att and dt != torch.float32:
             ws = tuple(w for m in att for w in (m.to_k.weight, m.to_v.weight))
             kv = F.linear(ctx, ws, owner=self, name="w_ctx_kv_all")      # [B, L, sum 2C]
-            o = 0
+            kvs, o = {}, 0
             for m in att:
                 c2 = 2 * m.to_k.out_features
-                m.__dict__["_kv_pre"] = kv[..., o:o + c2]
+                kvs[id(m)] = kv[..., o:o + c2]
                 o += c2
-
-    def _drop_small_gemm_slices(self):
-        """forget every pre-projected slice `_batch_small_gemms` handed to a block: a forward that aborted midway (OOM in validation)
-        must not leave pre-update, grad-less projections behind for the next forward to pick up"""
-        fam = self.__dict__.get("_small_gemm_family")
-        if fam is not None:
-            for m in fam[0]:
-                m.__dict__.pop("_rowadd_pre", None)
-            for m in fam[1]:
-                m.__dict__.pop("_kv_pre", None)
+            cc = CtxCond(ctx, kvs)
+        return tc, cc
 
     # ---- forward ----
     @ops.device_scoped
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, return_dict=True, **unused):
-        self._drop_small_gemm_slices()
-        try:
-            return self._forward(sample, timestep, encoder_hidden_states, class_labels, return_dict)
-        finally:
-            self._drop_small_gemm_slices()
+        return self._forward(sample, timestep, encoder_hidden_states, class_labels, return_dict)
 
     def _forward(self, sample, timestep, encoder_hidden_states, class_labels, return_dict):
         cfg = self.config
@@ -349,7 +339,7 @@ class UNet2DConditionModel(nn.Module):
         temb_act = F.silu(emb)  # every ResnetBlock2D applies SiLU before its time_emb_proj
         ctx = encoder_hidden_states.to(dt).contiguous()
         if not torch.is_grad_enabled():
-            self._batch_small_gemms(temb_act, ctx)
+            temb_act, ctx = self._batch_small_gemms(temb_act, ctx)
         n_up = len(cfg.block_out_channels) - 1
         forward_upsample_size = any(s % (2 ** n_up) != 0 for s in sample.shape[-2:])
         # 2-3. conv_in, down

@@ -196,11 +196,14 @@ def test_small_gemm_families_of_the_sd2_unet():
     assert len(att) == 16 and all(a.to_k.in_features == 1024 for a in att)
     assert sum(r.time_emb_proj.out_features for r in res) == 20160
     assert sum(2 * a.to_k.out_features for a in att) == 24960
-    # the consumers pick their slices up through these two attribute names
+    # the slices travel as ARGUMENTS of the call (modules.TimeCond / CtxCond, picked by identity), nothing is parked on the modules (re-entrancy)
     import inspect
     from diffusion_e2e_ft_amd import modules, unet
-    assert "_rowadd_pre" in inspect.getsource(modules.ResnetBlock2D.nhwc) and "_kv_pre" in inspect.getsource(modules.Attention.forward)
-    assert "_rowadd_pre" in inspect.getsource(unet.UNet2DConditionModel._batch_small_gemms)
+    assert "TimeCond" in inspect.getsource(modules.ResnetBlock2D.nhwc) and "CtxCond" in inspect.getsource(modules.Attention.forward)
+    src = inspect.getsource(unet.UNet2DConditionModel._batch_small_gemms)
+    assert "TimeCond(" in src and "CtxCond(" in src and "__dict__[\"_rowadd" not in src and "__dict__[\"_kv" not in src
+    tc = modules.TimeCond(torch.zeros(2, 4), {1: "a"})
+    assert tc.rows[1] == "a" and modules.CtxCond(torch.zeros(1)).kv == {}
 
 
 def test_flat_adamw_is_a_torch_optimizer_with_live_lr_and_torch_format_state():
@@ -359,3 +362,39 @@ def test_wgrad_pixel_split_fills_whole_rounds_of_the_machine():
     d.dtype, d.batch, d.hin, d.win, d.hl, d.wl, d.hout, d.wout = 0, 1, 8, 8, 8, 8, 8, 8
     d.c1, d.ldx1, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.cout, d.ldo, d.ldw, d.alpha = 64, 64, 3, 3, 1, 1, 1, 64, 64, 576, 1.0
     assert lib.e2eft_conv2d_wgrad_workspace_bytes(C.byref(d), 64) == 0
+
+
+def _apply_tables(x, xt, yt):
+    """numpy model of csrc/prepost.hip: horizontal pass, then vertical pass, fp32"""
+    import numpy as np
+    (xb, xw), (yb, yw) = xt, yt
+    P, H, W = x.shape
+    w, h = xb.shape[0], yb.shape[0]
+    mid = np.zeros((P, H, w), np.float32)
+    for o in range(w):
+        a, n = int(xb[o, 0]), int(xb[o, 1])
+        mid[:, :, o] = (x[:, :, a:a + n] * xw[o, :n].numpy()).sum(-1, dtype=np.float32)
+    out = np.zeros((P, h, w), np.float32)
+    for o in range(h):
+        a, n = int(yb[o, 0]), int(yb[o, 1])
+        out[:, o, :] = (mid[:, a:a + n, :] * yw[o, :n].numpy()[None, :, None]).sum(1, dtype=np.float32)
+    return out
+
+
+def test_aa_bicubic_and_nearest_tables_match_torch_and_pillow():
+    """pipeline.aa_tables(kind="bicubic") = aten's antialiased bicubic (the CLIP preprocessing of geowizard_pipeline.py:236-245 through torchvision) = Pillow's
+    `Image.resize` of a float image with its default BICUBIC (the depth resize-back of geowizard_pipeline.py:201-203); kind="nearest" = cv2.INTER_NEAREST / torch
+    "nearest" (:205)."""
+    import numpy as np
+    from PIL import Image
+    from diffusion_e2e_ft_amd.pipeline import aa_tables
+    g = torch.Generator().manual_seed(1)
+    for (H, W, h, w) in [(768, 576, 224, 224), (96, 128, 480, 640), (61, 45, 224, 224), (576, 768, 1000, 1333)]:
+        img = torch.rand((2, H, W), generator=g)
+        out = _apply_tables(img.numpy(), aa_tables(W, w, "cpu", "bicubic"), aa_tables(H, h, "cpu", "bicubic"))
+        want = torch.nn.functional.interpolate(img[None], size=(h, w), mode="bicubic", antialias=True, align_corners=False)[0].numpy()
+        assert np.abs(out - want).max() <= 2e-6, ((H, W, h, w), np.abs(out - want).max())
+        pil = np.asarray(Image.fromarray(img[0].numpy()).resize((w, h)))                 # mode "F", default resample
+        assert np.abs(out[0] - pil).max() <= 2e-4, ((H, W, h, w), np.abs(out[0] - pil).max())       # (Pillow builds its coefficients in double precision)
+        near = _apply_tables(img.numpy(), aa_tables(W, w, "cpu", "nearest"), aa_tables(H, h, "cpu", "nearest"))
+        assert np.array_equal(near, torch.nn.functional.interpolate(img[None], size=(h, w), mode="nearest")[0].numpy())

@@ -27,6 +27,23 @@ def test_resize_device_equals_torch_antialiased_bilinear(dev, H, W, h, w):
     assert (resize_device(f.to(dev), (h, w)).cpu() - want_f).abs().max().item() <= 2e-6
 
 
+@pytest.mark.parametrize("H,W,h,w", [(768, 576, 224, 224), (96, 128, 480, 640), (61, 45, 224, 224)])
+def test_resize_device_bicubic_antialiased_and_nearest(dev, H, W, h, w):
+    """GeoWizard's resize-back (Pillow BICUBIC of the float depth, cv2.INTER_NEAREST of the normals: geowizard_pipeline.py:201-205) and the CLIP image
+    preprocessing (torchvision BICUBIC antialias, :236-245) through the same table-driven kernels"""
+    from diffusion_e2e_ft_amd.pipeline import resize_device
+    from diffusion_e2e_ft_amd.clip import preprocess_for_clip
+    g = torch.Generator().manual_seed(H + w)
+    f = torch.rand(3, H, W, generator=g)
+    want = TF.interpolate(f[None], size=(h, w), mode="bicubic", antialias=True, align_corners=False)[0]
+    assert (resize_device(f.to(dev), (h, w), kind="bicubic").cpu() - want).abs().max().item() <= 4e-6
+    assert torch.equal(resize_device(f.to(dev), (h, w), kind="nearest").cpu(), TF.interpolate(f[None], size=(h, w), mode="nearest")[0])
+    rgb = f[None] * 2 - 1
+    a = preprocess_for_clip(rgb.to(dev)).cpu()
+    b = preprocess_for_clip(rgb)
+    assert a.shape == (1, 3, 224, 224) and (a - b).abs().max().item() <= 2e-5
+
+
 def test_minmax_unit(dev):
     from diffusion_e2e_ft_amd import ops
     g = torch.Generator().manual_seed(1)
