@@ -372,7 +372,21 @@ def _scaled(x, mul):
     return out.permute(0, 3, 1, 2)
 
 
+_AA_TABLES = {}       # (in, out, kind, device) -> device tables: a handful of shapes per process; cached so that a hipGraph capture (whose eager warm-up pass fills
+                       # this like the packed-weight caches) contains no host -> device copy
+
+
 def aa_tables(in_size, out_size, device, kind="bilinear"):
+    key = (int(in_size), int(out_size), kind, str(device))
+    hit = _AA_TABLES.get(key)
+    if hit is None:
+        if len(_AA_TABLES) > 256:
+            _AA_TABLES.clear()
+        hit = _AA_TABLES[key] = _aa_tables(in_size, out_size, device, kind)
+    return hit
+
+
+def _aa_tables(in_size, out_size, device, kind="bilinear"):
     """aten `_compute_indices_min_size_weights_aa` (UpSampleKernel.cpp), align_corners = False, in aten's float32 arithmetic: (bounds int32 [out, 2] = (first tap,
     tap count), weights fp32 [out, ksize]) — what `F.interpolate(mode=kind, antialias=True)` applies along one dimension.  kind "bilinear": the triangle filter
     (support 1); "bicubic": Keys' cubic with a = -0.5 (support 2) — aten's antialiased bicubic is Pillow's resize (`Image.resize` of a float image, default
