@@ -30,7 +30,51 @@ def bump_param_epoch():
 
 
 def _key(*params):
-    return (PARAM_EPOCH,) + tuple((p._version, p.data_ptr(), p.dtype, str(p.device)) for p in params)
+    # the epoch only concerns parameters a flat-buffer optimizer updates behind torch's version counters (training.FlatAdamW marks them); everything else — the frozen
+    # VAE, the text / image encoders — keeps its derived tensors across optimizer steps
+    ep = PARAM_EPOCH if any(getattr(p, "_e2eft_flat", None) is not None for p in params) else -1
+    return (ep,) + tuple((p._version, p.data_ptr(), p.dtype, str(p.device)) for p in params)
+
+
+# ---- compute-dtype SHADOW of a flat master buffer --------------------------------------------------------------------------------------------------------
+# training.FlatAdamW keeps every trainable parameter in ONE flat fp32 buffer, convolution weights in the order the kernels read them (OHWI: the parameter is a
+# channels_last view).  With 16-bit compute the whole buffer is cast ONCE per parameter state by one e2eft_cast launch into a flat 16-bit twin; packed convolution
+# weights, (concatenated) Linear weights, biases and norm parameters are then VIEWS of that twin — no per-tensor cast / permute / cat launches (round 3: ~1100
+# `bfloat16_copy`, 214 `direct_copy` and 84 `flip` ATen launches per step, 12 ms).
+class FlatShadow:
+    def __init__(self, flat):
+        self.flat, self.twins, self.state = flat, {}, {}
+
+    def twin(self, dtype):
+        key = (PARAM_EPOCH, self.flat._version)          # in-place writes through any parameter view bump the base's version; the optimizer kernel bumps the epoch
+        t = self.twins.get(dtype)
+        if t is None:
+            t = self.twins[dtype] = torch.empty(self.flat.shape, dtype=dtype, device=self.flat.device)
+            self.state[dtype] = None
+        if self.state[dtype] != key:
+            with torch.no_grad(), ops.on_device_of(self.flat):
+                ops.cast_(self.flat, t)
+            self.state[dtype] = key
+        return t
+
+
+FLAT_SHADOW_ENABLED = True    # tests / A-B: False sends every derived tensor through the per-tensor cast / pack / cat path of round 3
+
+
+def shadow_view(p, dtype):
+    """p lives in a flat master buffer (FlatAdamW): the view of the buffer's `dtype` twin with p's shape and strides; else None"""
+    tag = getattr(p, "_e2eft_flat", None)
+    if tag is None or p.dtype == dtype or not FLAT_SHADOW_ENABLED:
+        return None
+    sh, off = tag
+    if p.data_ptr() != sh.flat.data_ptr() + off * sh.flat.element_size() or p.device != sh.flat.device:
+        return None                                      # the parameter was re-bound since (.to(), a deepcopy's stale tag): the lazy per-tensor path serves it
+    return sh.twin(dtype).as_strided(p.shape, p.stride(), off)
+
+
+def _is_ohwi(w):
+    Co, Ci, kh, kw = w.shape
+    return w.dim() == 4 and w.stride() == (kh * kw * Ci, 1, kw * Ci, Ci)
 
 
 def cached(owner, name, params, builder):
@@ -48,13 +92,19 @@ def _vec(p, dtype):
     """bias / gamma / beta in the compute dtype"""
     if p is None:
         return None
-    p = p.detach()
-    return p if p.dtype == dtype else p.to(dtype)
+    if p.dtype == dtype:
+        return p.detach()
+    sv = shadow_view(p, dtype)           # (asked of the Parameter itself: the flat-buffer tag is a Python attribute, a detached alias does not carry it)
+    return sv if sv is not None else p.detach().to(dtype)
 
 
 def packed_conv_weight(conv, dtype):
     """[Co,Ci,kh,kw] -> OHWI rows [Co, kh*kw*Ci_pad] in `dtype` (Ci padded with zeros to a 16-byte multiple)."""
     w = conv.weight
+    if w.dtype != dtype and w.shape[1] % ops.epc(dtype) == 0 and _is_ohwi(w):
+        sv = shadow_view(w, dtype)
+        if sv is not None:                               # the master copy already lies in OHWI order: the packed weight IS the twin's slice
+            return sv.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
 
     def build():
         Co, Ci, kh, kw = w.shape
@@ -195,6 +245,9 @@ class _Conv2dFn(torch.autograd.Function):
             if kh == 1 and kw == 1:
                 dw = dwp[:, :Ci].reshape(Co, Ci, 1, 1)
                 dw = dw if dw.dtype == weight.dtype else dw.to(weight.dtype)
+            elif _is_ohwi(weight):     # the master weight lies in the kernels' order (FlatAdamW): the gradient is the reduction's output itself, no permuting copy
+                dw = dwp.view(Co, kh, kw, c1 + c2)[..., :Ci].permute(0, 3, 1, 2)
+                dw = dw if dw.dtype == weight.dtype else dw.to(weight.dtype)
             else:
                 dw = dwp.view(Co, kh, kw, c1 + c2)[..., :Ci].permute(0, 3, 1, 2).to(dtype=weight.dtype, memory_format=torch.contiguous_format)
         return dx, dx2, dw, dbias, drow, dres, None, None, None, None, None, None
@@ -232,6 +285,17 @@ def _cat_weight(owner, name, weights, dtype, kpad):
 
     if len(weights) == 1 and weights[0].dtype == dtype and kpad == weights[0].shape[1]:
         return weights[0].detach()
+    if kpad == weights[0].shape[1] and weights[0].dtype != dtype:
+        # q | k | v (k | v) of one attention lie back to back in the flat master buffer (module order, no padding between them when N K % 4 == 0): their
+        # concatenation is one contiguous slice of the twin
+        tags = [getattr(p, "_e2eft_flat", None) for p in weights]
+        if all(t is not None for t in tags) and all(t[0] is tags[0][0] for t in tags) and all(p.is_contiguous() and p.dim() == 2 for p in weights):
+            offs = [t[1] for t in tags]
+            if all(offs[i] + weights[i].numel() == offs[i + 1] for i in range(len(weights) - 1)):
+                first = shadow_view(weights[0], dtype)
+                if first is not None and all(shadow_view(p, dtype) is not None for p in weights[1:]):
+                    rows = sum(p.shape[0] for p in weights)
+                    return tags[0][0].twin(dtype).as_strided((rows, kpad), (kpad, 1), offs[0])
     return cached(owner, "%s_%s" % (name, dtype), tuple(weights), build)
 
 

@@ -194,6 +194,11 @@ class FlatAdamW(torch.optim.Optimizer):
             self.offsets.append(n)
             n += (p.numel() + 3) // 4 * 4                     # keep every view 16-byte aligned
         self.numel = n
+        # Convolution weights are stored in the order the kernels read them — OHWI, i.e. the Parameter becomes a channels_last view of its slot (same values, same
+        # logical OIHW shape: state_dict / save_pretrained / copy_ see no difference) — so that with 16-bit compute the packed weight of every convolution is a
+        # slice of ONE flat cast of this buffer (autograd.FlatShadow) and the weight gradient, which the kernels produce in OHWI order, is accumulated without a
+        # permuting copy.
+        self._ohwi = [p.dim() == 4 and p.shape[2] * p.shape[3] > 1 for p in plist]
         with ops.on_device_of(plist[0]):
             self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
             self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -203,11 +208,13 @@ class FlatAdamW(torch.optim.Optimizer):
             self._steps = torch.zeros(2, dtype=torch.int64, device=dev)      # {applied, skipped} — advanced by the update kernel itself
             self._coef = torch.zeros(4, dtype=torch.float32, device=dev)
             with torch.no_grad():
-                for p, o in zip(self.params, self.offsets):
-                    view = self.flat_param[o:o + p.numel()].view(p.shape)
+                self.shadow = F.FlatShadow(self.flat_param)
+                for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                    view = self._slot(self.flat_param, i)
                     view.copy_(p.data)
                     p.data = view
-                    p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+                    p.grad = self._slot(self.flat_grad, i)
+                    p._e2eft_flat = (self.shadow, o)
         self._bind_state()
         F.bump_param_epoch()
         self.group = process_group
@@ -248,13 +255,21 @@ class FlatAdamW(torch.optim.Optimizer):
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
+    def _slot(self, buf, i):
+        """parameter i's view of a flat buffer (parameters, gradients, both moments): its shape, OHWI-ordered for convolution weights"""
+        p, o = self.params[i], self.offsets[i]
+        flat = buf[o:o + p.numel()]
+        if self._ohwi[i]:
+            Co, Ci, kh, kw = p.shape
+            return flat.view(Co, kh, kw, Ci).permute(0, 3, 1, 2)
+        return flat.view(p.shape)
+
     # ---- torch.optim.Optimizer surface -------------------------------------------------------------------------------------------
     def _bind_state(self):
         """state[p]: views of the flat moment buffers; "step" is a view of the device-side applied-step counter shared by all parameters"""
         step = self._steps[0]
-        for p, o in zip(self.params, self.offsets):
-            n = p.numel()
-            self.state[p] = {"step": step, "exp_avg": self.exp_avg[o:o + n].view(p.shape), "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape)}
+        for i, p in enumerate(self.params):
+            self.state[p] = {"step": step, "exp_avg": self._slot(self.exp_avg, i), "exp_avg_sq": self._slot(self.exp_avg_sq, i)}
 
     @property
     def lr(self):
@@ -288,15 +303,15 @@ class FlatAdamW(torch.optim.Optimizer):
         extra = state_dict.get("flat_adamw", {})
         super().load_state_dict({k: v for k, v in state_dict.items() if k != "flat_adamw"})   # group hyper-parameters (lr, betas, ...) + per-parameter copies
         steps = set()
-        for p, o in zip(self.params, self.offsets):
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             st = self.state.get(p)
             n = p.numel()
             if not st:                            # parameter without saved state (fresh): zero moments
                 self.exp_avg[o:o + n].zero_()
                 self.exp_avg_sq[o:o + n].zero_()
                 continue
-            self.exp_avg[o:o + n].view(p.shape).copy_(st["exp_avg"])
-            self.exp_avg_sq[o:o + n].view(p.shape).copy_(st["exp_avg_sq"])
+            self._slot(self.exp_avg, i).copy_(st["exp_avg"])
+            self._slot(self.exp_avg_sq, i).copy_(st["exp_avg_sq"])
             steps.add(int(torch.as_tensor(st["step"]).item()))
         if len(steps) > 1:
             raise ValueError("FlatAdamW.load_state_dict: parameters carry different step counts %s; one flat buffer has one bias correction" % sorted(steps))
@@ -354,9 +369,9 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def _adopt_one(self, p, o):
         g = p.grad
-        if g is not None and g.data_ptr() == self.flat_grad.data_ptr() + 4 * o and g.is_contiguous():
+        slot = self._slot(self.flat_grad, self._index_of[id(p)])
+        if g is not None and g.data_ptr() == slot.data_ptr() and g.stride() == slot.stride():
             return
-        slot = self.flat_grad[o:o + p.numel()].view(p.shape)
         if g is None:
             slot.zero_()
         else:
@@ -408,9 +423,9 @@ class FlatAdamW(torch.optim.Optimizer):
             sl["work"], sl["ready"] = None, 0
         self.flat_grad.zero_()
         self._rearm_exchange()
-        for p, o in zip(self.params, self.offsets):      # autograd may have re-bound .grad (e.g. set_to_none by a caller)
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):      # autograd may have re-bound .grad (e.g. set_to_none by a caller)
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
-                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+                p.grad = self._slot(self.flat_grad, i)
 
 
 def train_step(unet, vae, optimizer, batches, empty_encoding, modality="depth", lr_scale=1.0):

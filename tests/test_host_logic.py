@@ -398,3 +398,43 @@ def test_aa_bicubic_and_nearest_tables_match_torch_and_pillow():
         assert np.abs(out[0] - pil).max() <= 2e-4, ((H, W, h, w), np.abs(out[0] - pil).max())       # (Pillow builds its coefficients in double precision)
         near = _apply_tables(img.numpy(), aa_tables(W, w, "cpu", "nearest"), aa_tables(H, h, "cpu", "nearest"))
         assert np.array_equal(near, torch.nn.functional.interpolate(img[None], size=(h, w), mode="nearest")[0].numpy())
+
+
+def test_flat_adamw_keeps_convolution_weights_in_kernel_order():
+    """FlatAdamW stores a convolution weight OHWI (the Parameter is a channels_last view of its slot): logical values / shape unchanged, gradients of torch's own
+    conv backward land in the flat gradient buffer, optimizer state round-trips, and the parameters are tagged for autograd.FlatShadow (host-side surface only;
+    the twin's cast and the packed-weight views are exercised on the GPU: tests/test_train_gpu.py)"""
+    from diffusion_e2e_ft_amd.training import FlatAdamW
+    from diffusion_e2e_ft_amd import autograd as F
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1), torch.nn.Conv2d(16, 4, 1), torch.nn.Flatten(), torch.nn.Linear(4 * 5 * 5, 3))
+    ref = [p.detach().clone() for p in net.parameters()]
+    opt = FlatAdamW(net.parameters())
+    w0, w1 = net[0].weight, net[1].weight
+    assert w0.shape == (16, 8, 3, 3) and w0.stride() == (72, 1, 24, 8) and F._is_ohwi(w0)            # OHWI storage, OIHW logical shape
+    assert w1.is_contiguous()                                                                          # 1x1: nothing to reorder
+    assert all(torch.equal(p.detach(), r) for p, r in zip(net.parameters(), ref))
+    o0 = opt.offsets[0]
+    assert torch.equal(opt.flat_param[o0:o0 + w0.numel()].view(16, 3, 3, 8), ref[0].permute(0, 2, 3, 1))    # the slot holds (co, ky, kx, ci)
+    assert all(p._e2eft_flat[0] is opt.shadow and p._e2eft_flat[1] == o for p, o in zip(opt.params, opt.offsets))
+    assert F.shadow_view(w0, torch.float32) is None                                                    # same dtype: no twin needed
+    x = torch.randn(2, 8, 5, 5)
+    net(x).sum().backward()
+    g0 = w0.grad
+    assert g0.data_ptr() == opt.flat_grad.data_ptr() + 4 * o0 and g0.stride() == w0.stride()
+    want = torch.autograd.grad(torch.nn.functional.conv2d(x, ref[0].requires_grad_(True), ref[1], padding=1).pow(1).sum() * 0 + net(x).sum(), [w0])[0]
+    assert torch.allclose(g0, want)
+    assert torch.allclose(opt.flat_grad[o0:o0 + w0.numel()].view(16, 3, 3, 8), want.permute(0, 2, 3, 1))
+    w0.grad = None                                                                                      # a generic loop's set_to_none
+    net(x).sum().backward()
+    opt._adopt_grads()
+    assert w0.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * o0 and torch.allclose(w0.grad, want)
+    opt.exp_avg.normal_()
+    sd = opt.state_dict()
+    assert sd["state"][0]["exp_avg"].shape == (16, 8, 3, 3) and torch.equal(sd["state"][0]["exp_avg"], opt.state[w0]["exp_avg"])
+    keep = [opt.state[p]["exp_avg"].clone() for p in opt.params]
+    opt.exp_avg.zero_()
+    opt.load_state_dict(sd)
+    assert all(torch.equal(opt.state[p]["exp_avg"], k) for p, k in zip(opt.params, keep))
+    assert opt.state[w0]["exp_avg"].data_ptr() == opt.exp_avg.data_ptr() + 4 * o0
+    assert torch.equal(net.state_dict()["0.weight"], ref[0].detach())

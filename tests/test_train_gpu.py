@@ -362,3 +362,54 @@ def test_flat_adamw_skips_a_non_finite_gradient_on_the_device_and_counts_it(dev)
         assert opt.step_count == 2 and opt.skipped_steps() == 1
         assert not any(torch.equal(a, b) for a, b in zip(before, net.parameters()))
         assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
+def test_bf16_weights_are_views_of_one_flat_cast_and_steps_are_bit_equal(dev):
+    """bf16 compute over fp32 master weights in a FlatAdamW buffer (round 4): convolution weights lie OHWI in the buffer, ONE e2eft_cast per parameter state
+    produces the 16-bit twin and the operands of the kernels are views of it.  (i) the views equal what the per-tensor pack / cat / cast path builds, element for
+    element; (ii) two optimizer steps with the twin equal two steps of an identical model with the twin switched off (the round-3 per-tensor path) bit for bit."""
+    import copy
+    from diffusion_e2e_ft_amd import training, autograd as F
+    batch, text = gc.train_batch()
+    bf = torch.bfloat16
+
+    def make():
+        unet, vae = _models(dev)
+        unet.set_compute_dtype(bf)
+        vae = vae.to(bf)
+        return unet, vae, training.FlatAdamW(unet.parameters(), lr=1e-3, max_grad_norm=1.0)
+
+    unet, vae, opt = make()
+    twin = opt.shadow.twin(bf)
+    lo, hi = twin.data_ptr(), twin.data_ptr() + twin.numel() * 2
+    conv = unet.down_blocks[0].resnets[0].conv1
+    pk = F.packed_conv_weight(conv, bf)
+    assert lo <= pk.data_ptr() < hi and pk.shape == (conv.weight.shape[0], 9 * conv.weight.shape[1]) and pk.is_contiguous()
+    assert torch.equal(pk, conv.weight.detach().to(bf).permute(0, 2, 3, 1).reshape(pk.shape))
+    att = unet.down_blocks[0].attentions[0].transformer_blocks[0].attn1
+    ws = (att.to_q.weight, att.to_k.weight, att.to_v.weight)
+    cat = F._cat_weight(att, "wqkv", ws, bf, ws[0].shape[1])
+    assert lo <= cat.data_ptr() < hi and torch.equal(cat, torch.cat([w.detach().to(bf) for w in ws]))
+    b = F._vec(conv.bias, bf)
+    assert lo <= b.data_ptr() < hi and torch.equal(b, conv.bias.detach().to(bf))
+    assert F.packed_conv_weight(vae.decoder.conv_in, bf).data_ptr() < lo or F.packed_conv_weight(vae.decoder.conv_in, bf).data_ptr() >= hi     # frozen: its own cache
+    vkey = F._key(vae.decoder.conv_in.weight)
+    losses = {}
+    for tagged in (True, False):
+        u, v, o = (unet, vae, opt) if tagged else make()
+        F.FLAT_SHADOW_ENABLED = tagged            # False: the per-tensor cast / pack / cat path of round 3
+        try:
+            ls = []
+            for _ in range(2):
+                loss = training.e2e_ft_loss(u, v, batch, text, "depth")
+                loss.backward()
+                o.step()
+                o.zero_grad()
+                ls.append(loss.item())
+            torch.cuda.synchronize()
+        finally:
+            F.FLAT_SHADOW_ENABLED = True
+        losses[tagged] = (ls, o.flat_param.detach().clone())
+    assert losses[True][0] == losses[False][0], (losses[True][0], losses[False][0])
+    assert torch.equal(losses[True][1], losses[False][1])
+    assert F._key(vae.decoder.conv_in.weight) == vkey           # the frozen decoder's packed weights survive optimizer steps (the epoch only concerns flat-resident parameters)
