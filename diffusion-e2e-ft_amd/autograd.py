@@ -77,6 +77,23 @@ def _is_ohwi(w):
     return w.dim() == 4 and w.stride() == (kh * kw * Ci, 1, kw * Ci, Ci)
 
 
+GRAD_SINK_ENABLED = True      # tests / A-B: False hands every parameter gradient to autograd as a fresh tensor (AccumulateGrad then adds it into the flat buffer)
+
+
+def grad_sink(*params):
+    """FlatAdamW(direct_grads=True): the slots of `params` in the flat fp32 gradient buffer, when THIS backward call is the first writer of their gradients since
+    zero_grad() (every .grad is None, nobody claimed a slot) and — for more than one parameter — the slots lie back to back.  Returns (flat, views): `flat` the dense
+    fp32 1-D view spanning the slots (what a reduction kernel writes), `views` one fresh view per parameter shaped and strided like it (what backward() returns:
+    autograd keeps such a tensor as .grad without a copy — AccumulateGrad's no-other-reference path — so the gradient is born in the exchange buffer).  Else None:
+    the caller produces an ordinary tensor and autograd accumulates it."""
+    if not GRAD_SINK_ENABLED:
+        return None
+    tags = [getattr(q, "_e2eft_gslot", None) for q in params]
+    if any(t is None for t in tags) or any(q.grad is not None for q in params) or any(t[0] is not tags[0][0] for t in tags):
+        return None
+    return tags[0][0]._claim([t[1] for t in tags], params)
+
+
 def cached(owner, name, params, builder):
     cache = owner.__dict__.setdefault("_e2eft_cache", {})
     k = _key(*params)
@@ -217,11 +234,21 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.has[1] and need[5]:
             dres = dy
         if (bias is not None and need[3]) or (ctx.has[0] and need[4]):
-            s = ops.colsum(ops._as_rows(dyp), groups=B, alpha=alpha)[:, :Co]       # [B, Co] fp32
-            if ctx.has[0] and need[4]:
-                drow = s.to(dt)
-            if bias is not None and need[3]:
-                dbias = s.sum(0).to(bias.dtype)
+            bsink = grad_sink(conv.bias) if (bias is not None and need[3] and conv.bias is not None and conv.bias.dtype == torch.float32) else None
+            if not (ctx.has[0] and need[4]) and cop == Co:
+                # bias only: ONE reduction over all rows (the same order with and without a gradient slot to write into)
+                s1 = ops.colsum(ops._as_rows(dyp), groups=1, alpha=alpha, out=None if bsink is None else bsink[0].view(1, Co))
+                dbias = bsink[1][0] if bsink is not None else s1[0].to(bias.dtype)
+            else:
+                s = ops.colsum(ops._as_rows(dyp), groups=B, alpha=alpha)[:, :Co]       # [B, Co] fp32
+                if ctx.has[0] and need[4]:
+                    drow = s.to(dt)
+                if bias is not None and need[3]:
+                    if bsink is not None:
+                        torch.sum(s, 0, out=bsink[0])
+                        dbias = bsink[1][0]
+                    else:
+                        dbias = s.sum(0).to(bias.dtype)
         if need[0] or (x2 is not None and need[1]):
             dxl = ops.conv2d_dgrad(dyp, packed_conv_weight_dgrad(conv, dt), (B, H, W, c1), c2, kh, kw, stride, pad, up_to, alpha)
             if up_to is not None:
@@ -233,7 +260,12 @@ class _Conv2dFn(torch.autograd.Function):
         if need[2]:
             # straight from the NHWC tensors (csrc/wgrad.hip: transpose reads, no dY^T / im2col copies); None -> the GEMM path below (fp32, fused
             # upsample, channel counts that are not multiples of 64)
-            dwp = ops.conv2d_wgrad(dyp, xp, x2, Co, kh, kw, stride, pad, alpha) if up_to is None else None
+            # FlatAdamW's slot of this weight's gradient (None unless this call is its first writer): the reduction's result lands there when the slot has the
+            # kernels' layout — OHWI rows without channel padding (1x1: OIHW is the same order)
+            wsink = None
+            if weight.dtype == torch.float32 and c1 + c2 == Ci and ((kh == 1 and kw == 1 and weight.is_contiguous()) or _is_ohwi(weight)):
+                wsink = grad_sink(conv.weight)
+            dwp = ops.conv2d_wgrad(dyp, xp, x2, Co, kh, kw, stride, pad, alpha, out=None if wsink is None else wsink[0]) if up_to is None else None
             if dwp is None:
                 P = dyp.shape[0] * dyp.shape[1] * dyp.shape[2]
                 nsplit, kc = ops.splitk_plan(Co, kh * kw * (c1 + c2), P)
@@ -242,7 +274,11 @@ class _Conv2dFn(torch.autograd.Function):
                 dwp = ops.gemm_splitk(dyT[:Co], col, nsplit, kc, alpha=alpha)       # [Co, kh*kw*cin] = OHWI
             # the gradient is handed to autograd in the PARAMETER's stride order (OIHW contiguous): AccumulateGrad then adds / stores it
             # without a strided pass, and a DistributedDataParallel wrap finds "grad strides == bucket view strides"
-            if kh == 1 and kw == 1:
+            if wsink is not None:
+                if dwp.data_ptr() != wsink[0].data_ptr():      # a fallback path produced it elsewhere: one copy instead of AccumulateGrad's add
+                    wsink[0].view(dwp.shape).copy_(dwp)
+                dw = wsink[1][0]
+            elif kh == 1 and kw == 1:
                 dw = dwp[:, :Ci].reshape(Co, Ci, 1, 1)
                 dw = dw if dw.dtype == weight.dtype else dw.to(weight.dtype)
             elif _is_ohwi(weight):     # the master weight lies in the kernels' order (FlatAdamW): the gradient is the reduction's output itself, no permuting copy
@@ -344,21 +380,35 @@ class _LinearFn(torch.autograd.Function):
             dxp = ops.gemm(g64, wt, alpha=alpha)                    # [M, kp]
             dx = dxp.view(*xp.shape[:-1], kp)[..., :K]
         if any(need[7:]):
-            dw = ops.linear_wgrad(g, _rows(xp), alpha) if M >= 512 else None      # csrc/wgrad.hip (1x1 case); None -> the transposes + GEMM below
+            # q | k | v of one attention lie back to back in FlatAdamW's buffers: one reduction writes all their gradients in place (see grad_sink)
+            wsink = None
+            if all(need[7:]) and kp == K and all(w_.dtype == torch.float32 and w_.dim() == 2 and w_.is_contiguous() for w_ in weights):
+                wsink = grad_sink(*weights)
+            dw = ops.linear_wgrad(g, _rows(xp), alpha, out=None if wsink is None else wsink[0]) if M >= 512 else None      # csrc/wgrad.hip (1x1 case); None -> the transposes + GEMM below
             if dw is None:
                 nsplit, kc = ops.splitk_plan(N, kp, M)
                 gT = ops.transpose(g, rows_pad=nsplit * kc)             # [N, Mp]
                 xT = ops.transpose(_rows(xp), rows_pad=nsplit * kc)     # [kp, Mp]
                 dw = ops.gemm_splitk(gT, xT, nsplit, kc, alpha=alpha)   # [N, kp]
-            o = 0
-            for i, wgt in enumerate(weights):
-                n = wgt.shape[0]
-                if need[7 + i]:
-                    t = dw[o:o + n, :K]
-                    dws[i] = t if t.dtype == wgt.dtype else t.to(wgt.dtype)
-                o += n
+            if wsink is not None:
+                if dw.data_ptr() != wsink[0].data_ptr():
+                    wsink[0].view(N, K).copy_(dw)
+                dws = list(wsink[1])
+            else:
+                o = 0
+                for i, wgt in enumerate(weights):
+                    n = wgt.shape[0]
+                    if need[7 + i]:
+                        t = dw[o:o + n, :K]
+                        dws[i] = t if t.dtype == wgt.dtype else t.to(wgt.dtype)
+                    o += n
         if bias is not None and need[1]:
-            dbias = ops.colsum(g, groups=1, alpha=alpha)[0].to(bias.dtype)
+            bsink = grad_sink(bias) if (bias.dtype == torch.float32 and bias.dim() == 1) else None
+            if bsink is not None:
+                ops.colsum(g, groups=1, alpha=alpha, out=bsink[0].view(1, N))
+                dbias = bsink[1][0]
+            else:
+                dbias = ops.colsum(g, groups=1, alpha=alpha)[0].to(bias.dtype)
         return (dx, dbias, dres, None, None, None, None, *dws)
 
 
@@ -406,11 +456,15 @@ class _GroupNormFn(torch.autograd.Function):
             return dskip, None, None, None, None, None, None, None, None, None
         g = _dense_nhwc(dy, Cc)
         add = _dense_nhwc(dskip, Cc) if (dskip is not None and need[0] and x2 is None) else None
+        gs = grad_sink(gamma) if (need[2] and need[3] and gamma.dtype == torch.float32) else None
+        bs = grad_sink(beta) if (gs is not None and beta.dtype == torch.float32) else None
         dx, dg, db = ops.groupnorm_bwd(x, x2, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu, g, ws, need_dx=want_dx, need_dparams=want_p,
-                                       dx_add=add)
+                                       dx_add=add, dg_out=None if gs is None else gs[0], db_out=None if bs is None else bs[0])
         d1 = dx[..., :c1] if (need[0] and dx is not None) else None
         d2 = dx[..., c1:] if (x2 is not None and need[1]) else None
-        return d1, d2, (dg.to(gamma.dtype) if need[2] else None), (db.to(beta.dtype) if need[3] else None), None, None, None, None, None, None
+        dgam = None if not need[2] else gs[1][0] if gs is not None else dg.to(gamma.dtype)
+        dbet = None if not need[3] else bs[1][0] if bs is not None else db.to(beta.dtype)
+        return d1, d2, dgam, dbet, None, None, None, None, None, None
 
 
 def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, split=False):
@@ -441,7 +495,10 @@ class _LayerNormFn(torch.autograd.Function):
         x, gamma, beta = ctx.saved_tensors
         need = ctx.needs_input_grad
         g = dy if dy.is_contiguous() else dy.contiguous()
-        dx, dg, db = ops.layernorm_bwd(x, _vec(gamma, x.dtype), ctx.eps, g, need_dx=need[0])
+        sink = grad_sink(gamma, beta) if (need[1] and need[2] and gamma.dtype == torch.float32 and beta.dtype == torch.float32) else None   # weight | bias: adjacent slots
+        dx, dg, db = ops.layernorm_bwd(x, _vec(gamma, x.dtype), ctx.eps, g, need_dx=need[0], gb_out=None if sink is None else sink[0].view(2, -1))
+        if sink is not None:
+            return dx, sink[1][0], sink[1][1], None
         return dx, (dg.to(gamma.dtype) if need[1] else None), (db.to(beta.dtype) if need[2] else None), None
 
 

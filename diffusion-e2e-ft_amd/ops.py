@@ -791,9 +791,11 @@ def im2col_t(x, x2, kh, kw, stride, pad, up_to=None, Pp=None):
 WGRAD_DIRECT = True   # tests / A-B: False keeps every weight gradient on the transpose + im2col_t + split-K GEMM path
 
 
-def conv2d_wgrad(dy, x, x2, cout, kh, kw, stride, pad, alpha):
+def conv2d_wgrad(dy, x, x2, cout, kh, kw, stride, pad, alpha, out=None):
     """Weight gradient straight from the NHWC tensors (csrc/wgrad.hip): dy [B,hout,wout,>=cout] (pixel-dense), x [B,H,W,c1], x2 optional second
     concat source -> fp32 [cout, kh*kw*(c1+c2)] (OHWI rows), or None when the kernel does not serve the problem (the caller falls back).
+    out: a dense fp32 tensor of cout * kh*kw*(c1+c2) elements that receives the result (FlatAdamW's gradient slot: the reduction's last pass — or the kernel
+    itself when it does not split — writes there, no copy / add afterwards).
     The kernel addresses each operand through ONE 32-bit buffer descriptor, so tensors of 4 GB and more (configs[2] as benchmarked: 32 images of
     576^2 x 256 channels = 5.4 GB) are cut along the batch into launches below that limit; every launch adds its split partials to the same reduction."""
     if not WGRAD_DIRECT or dy.dtype == torch.float32:
@@ -817,20 +819,25 @@ def conv2d_wgrad(dy, x, x2, cout, kh, kw, stride, pad, alpha):
         nbytes = lib.e2eft_conv2d_wgrad_workspace_bytes(C.byref(d), lddy)
         if nbytes == 0:
             return None
-        part = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
+        direct = out is not None and step >= B and nbytes == cout * N * 4      # one launch, no split: the kernel's workspace IS the result
+        part = out.view(-1) if direct else torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
         ns = C.c_int32(0)
         P = d.batch * d.hout * d.wout
         with _timed("wgrad", 2.0 * P * cout * N, (P * (cout + cin)) * es, label="wgrad %dx%ds%d P%d %d->%d" % (kh, kw, stride, P, cin, cout)):
             check(lib.e2eft_conv2d_wgrad(C.byref(d), _ptr(dys), lddy, _ptr(xs), _ptr(x2s), _ptr(part), nbytes, C.byref(ns), _stream()))
         parts.append(part.view(ns.value, cout * N))
     if len(parts) == 1 and parts[0].shape[0] == 1:
+        if out is not None and parts[0].data_ptr() != out.data_ptr():
+            out.view(1, -1).copy_(parts[0])
+            return out.view(cout, N)
         return parts[0].view(cout, N)
     allp = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
-    return colsum(allp, groups=1).view(cout, N)
+    return colsum(allp, groups=1, out=None if out is None else out.view(1, -1)).view(cout, N)
 
 
-def linear_wgrad(dy2d, x2d, alpha=1.0):
-    """dW [N, K] fp32 = alpha * dy2d^T x2d for row views dy2d [M, N], x2d [M, K] (K a multiple of 64) — the 1x1 case of conv2d_wgrad; None = fall back"""
+def linear_wgrad(dy2d, x2d, alpha=1.0, out=None):
+    """dW [N, K] fp32 = alpha * dy2d^T x2d for row views dy2d [M, N], x2d [M, K] (K a multiple of 64) — the 1x1 case of conv2d_wgrad; None = fall back.
+    out: see conv2d_wgrad"""
     if not WGRAD_DIRECT or dy2d.dtype == torch.float32 or x2d.shape[1] % 64 != 0:
         return None
     M, N = dy2d.shape
@@ -843,7 +850,7 @@ def linear_wgrad(dy2d, x2d, alpha=1.0):
         return None
     xv = x2d.as_strided((1, 1, M, K), (M * ldx, M * ldx, ldx, 1))
     dv = dy2d.as_strided((1, 1, M, N), (M * ldy, M * ldy, ldy, 1))
-    return conv2d_wgrad(dv, xv, None, N, 1, 1, 1, (0, 0, 0, 0), alpha)
+    return conv2d_wgrad(dv, xv, None, N, 1, 1, 1, (0, 0, 0, 0), alpha, out=out)
 
 
 def conv2d_dgrad(dy, w_dgrad, x_shape, c2, kh, kw, stride, pad, up_to, alpha):
@@ -871,15 +878,18 @@ def conv2d_dgrad(dy, w_dgrad, x_shape, c2, kh, kw, stride, pad, up_to, alpha):
     return dx
 
 
-def colsum(x2d, groups=1, alpha=1.0):
-    """x2d [rows, cols] row-strided -> fp32 [groups, cols] sums over each group of rows/groups consecutive rows"""
-    _check_cuda(x2d)
+def colsum(x2d, groups=1, alpha=1.0, out=None):
+    """x2d [rows, cols] row-strided -> fp32 [groups, cols] sums over each group of rows/groups consecutive rows (into `out`, dense fp32 [groups, cols], if given)"""
+    _check_cuda(x2d, out)
     R, Cc = x2d.shape
     assert R % groups == 0
     lib = _lib.load()
     nbytes = lib.e2eft_colsum_workspace_bytes(groups, R // groups, Cc)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2d.device)
-    out = torch.empty((groups, Cc), dtype=torch.float32, device=x2d.device)
+    if out is None:
+        out = torch.empty((groups, Cc), dtype=torch.float32, device=x2d.device)
+    else:
+        assert out.dtype == torch.float32 and tuple(out.shape) == (groups, Cc) and out.is_contiguous(), (out.dtype, out.shape, out.stride())
     check(lib.e2eft_colsum(dtype_id(x2d.dtype), groups, R // groups, Cc, _rows_ld(x2d), alpha, _ptr(x2d), _ptr(out), _ptr(ws), nbytes, _stream()))
     return out
 
@@ -927,8 +937,9 @@ def _gn_desc(x, x2, groups, eps, silu, ldy):
     return d
 
 
-def groupnorm_bwd(x, x2, gamma, beta, groups, eps, silu, dy, fwd_ws, need_dx=True, need_dparams=True, dx_add=None):
-    """-> (dx [B,H,W,C] or None, dgamma fp32 [C] or None, dbeta fp32 [C] or None); dx_add: a [B,H,W,C] gradient added into dx"""
+def groupnorm_bwd(x, x2, gamma, beta, groups, eps, silu, dy, fwd_ws, need_dx=True, need_dparams=True, dx_add=None, dg_out=None, db_out=None):
+    """-> (dx [B,H,W,C] or None, dgamma fp32 [C] or None, dbeta fp32 [C] or None); dx_add: a [B,H,W,C] gradient added into dx;
+    dg_out / db_out: dense fp32 [C] tensors that receive dgamma / dbeta"""
     _check_cuda(x, x2, gamma, beta, dy, fwd_ws)
     B, H, W, c1 = x.shape
     Cc = c1 + (0 if x2 is None else x2.shape[3])
@@ -939,8 +950,10 @@ def groupnorm_bwd(x, x2, gamma, beta, groups, eps, silu, dy, fwd_ws, need_dx=Tru
         raise RuntimeError("groupnorm_bwd: %s" % lib.e2eft_last_error().decode())
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     dx = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device) if need_dx else None
-    dg = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_dparams else None
-    db = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_dparams else None
+    for o_ in (dg_out, db_out):
+        assert o_ is None or (o_.dtype == torch.float32 and tuple(o_.shape) == (Cc,) and o_.is_contiguous())
+    dg = (dg_out if dg_out is not None else torch.empty(Cc, dtype=torch.float32, device=x.device)) if need_dparams else None
+    db = (db_out if db_out is not None else torch.empty(Cc, dtype=torch.float32, device=x.device)) if need_dparams else None
     with _timed("groupnorm_bwd", 0.0, 5.0 * B * H * W * Cc * x.element_size(), label="gn_bwd B%d %dx%d C%d" % (B, H, W, Cc)):
         check(lib.e2eft_groupnorm_bwd_add(C.byref(d), _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(dy), _nhwc_ld(dy), _ptr(dx_add),
                                           _nhwc_ld(dx_add) if dx_add is not None else 0, _ptr(dx), Cc, _ptr(dg), _ptr(db), _ptr(fwd_ws), _ptr(ws), nbytes,
@@ -948,8 +961,8 @@ def groupnorm_bwd(x, x2, gamma, beta, groups, eps, silu, dy, fwd_ws, need_dx=Tru
     return dx, dg, db
 
 
-def layernorm_bwd(x, gamma, eps, dy, need_dx=True):
-    """-> (dx like x or None, dgamma fp32 [C], dbeta fp32 [C])"""
+def layernorm_bwd(x, gamma, eps, dy, need_dx=True, gb_out=None):
+    """-> (dx like x or None, dgamma fp32 [C], dbeta fp32 [C]); gb_out: dense fp32 [2, C] that receives (dgamma, dbeta)"""
     _check_cuda(x, gamma, dy)
     Cc = x.shape[-1]
     a = x.reshape(-1, Cc) if x.is_contiguous() else _as_rows(x)
@@ -958,7 +971,9 @@ def layernorm_bwd(x, gamma, eps, dy, need_dx=True):
     lib = _lib.load()
     nbytes = lib.e2eft_layernorm_bwd_workspace_bytes(a.shape[0], Cc)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    gb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    if gb_out is not None:
+        assert gb_out.dtype == torch.float32 and tuple(gb_out.shape) == (2, Cc) and gb_out.is_contiguous()
+    gb = gb_out if gb_out is not None else torch.empty((2, Cc), dtype=torch.float32, device=x.device)
     check(lib.e2eft_layernorm_bwd(dtype_id(x.dtype), a.shape[0], Cc, _rows_ld(a), _rows_ld(g), Cc, eps, _ptr(a), _ptr(gamma), _ptr(g), _ptr(dx), _ptr(gb),
                                   _ptr(ws), nbytes, _stream()))
     return dx, gb[0], gb[1]

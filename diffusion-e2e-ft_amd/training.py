@@ -165,10 +165,16 @@ class FlatAdamW(torch.optim.Optimizer):
     external_grad_sync=True: somebody else averages the gradients across ranks (a DistributedDataParallel wrap by `accelerator.prepare`,
     train.py:369) — no hooks, no division by the world size here.
     Non-finite gradient norm: the step is skipped on the device, the bias-correction step does not advance, `skipped_steps()` counts it
-    (e2eft_adamw_step_guarded, include/e2eft.h)."""
+    (e2eft_adamw_step_guarded, include/e2eft.h).
+
+    direct_grads=True (default): `zero_grad()` leaves every `.grad` None (torch's own default) instead of clearing the flat buffer, and the backward kernels of
+    the libe2eft autograd Functions write a parameter's FIRST gradient of an optimizer step straight into its slot of `flat_grad` (autograd.grad_sink): the
+    tensor autograd then stores as `.grad` is a view of the exchange buffer, no AccumulateGrad add per parameter, no 3.5 GB memset per step.  Later gradients of the
+    same step (gradient accumulation) are accumulated by autograd in place as before; gradients that arrive any other way are adopted (copied) into their slot by
+    the hook / `step()`; slots that received nothing are zeroed there."""
 
     def __init__(self, params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0, n_slices=4,
-                 process_group=None, external_grad_sync=False):
+                 process_group=None, external_grad_sync=False, direct_grads=True):
         params = list(params)
         if params and isinstance(params[0], dict):
             if len(params) != 1:
@@ -215,6 +221,9 @@ class FlatAdamW(torch.optim.Optimizer):
                     p.data = view
                     p.grad = self._slot(self.flat_grad, i)
                     p._e2eft_flat = (self.shadow, o)
+                    p._e2eft_gslot = (self, i)
+        self.direct_grads = bool(direct_grads)
+        self._claimed = [False] * len(self.params)
         self._bind_state()
         F.bump_param_epoch()
         self.group = process_group
@@ -263,6 +272,21 @@ class FlatAdamW(torch.optim.Optimizer):
             Co, Ci, kh, kw = p.shape
             return flat.view(Co, kh, kw, Ci).permute(0, 3, 1, 2)
         return flat.view(p.shape)
+
+    def _claim(self, idx, params):
+        """autograd.grad_sink: hand the gradient slots `idx` (of `params`) to a backward kernel as its output — once per optimizer step and parameter.
+        Several slots must lie back to back (q | k | v, LayerNorm weight | bias).  -> (flat fp32 view over the slots, [one view per parameter]) or None"""
+        if not self.direct_grads:
+            return None
+        for k, i in enumerate(idx):
+            if self._claimed[i] or self.params[i] is not params[k]:
+                return None
+            if k > 0 and self.offsets[i] != self.offsets[idx[k - 1]] + self.params[idx[k - 1]].numel():
+                return None
+        for i in idx:
+            self._claimed[i] = True
+        lo, hi = self.offsets[idx[0]], self.offsets[idx[-1]] + self.params[idx[-1]].numel()
+        return self.flat_grad[lo:hi], [self._slot(self.flat_grad, i) for i in idx]
 
     # ---- torch.optim.Optimizer surface -------------------------------------------------------------------------------------------
     def _bind_state(self):
@@ -414,15 +438,21 @@ class FlatAdamW(torch.optim.Optimizer):
             return math.sqrt(float(ops.sumsq(self.flat_grad, out=self._sumsq).item())) / self.world
 
     @torch.no_grad()
-    def zero_grad(self, set_to_none=False):
-        """Gradients are zeroed in ONE memset of the flat buffer and stay bound to it (also with set_to_none=True: a fresh `.grad` tensor
-        per parameter would take the gradient out of the exchange buffer; `step()` would copy it back, at a price)."""
+    def zero_grad(self, set_to_none=None):
+        """direct_grads (the default; or set_to_none=True): every `.grad` becomes None and the flat buffer is NOT cleared — the next backward's kernels write
+        the gradients into their slots (see the class docstring), `step()` zeroes the slots that got none.  Otherwise (direct_grads=False, or set_to_none=False
+        asked explicitly): ONE memset of the flat buffer, `.grad` stays bound to its slot and autograd accumulates into it."""
         for sl in self.slices:                           # a backward without a step() (skipped iteration): drain its exchange first,
-            if sl["work"] is not None:                   # the memset below must not race an in-flight all-reduce
+            if sl["work"] is not None:                   # the buffer must not be rewritten under an in-flight all-reduce
                 sl["work"].wait()
             sl["work"], sl["ready"] = None, 0
-        self.flat_grad.zero_()
         self._rearm_exchange()
+        self._claimed = [False] * len(self.params)
+        if self.direct_grads if set_to_none is None else set_to_none:
+            for p in self.params:
+                p.grad = None
+            return
+        self.flat_grad.zero_()
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):      # autograd may have re-bound .grad (e.g. set_to_none by a caller)
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self._slot(self.flat_grad, i)

@@ -61,12 +61,14 @@ def _worker(rank, world, port, q):
     for p, a, b in zip(net.parameters(), refs[0], refs[1]):
         assert p.grad.data_ptr() >= opt.flat_grad.data_ptr()
         assert torch.allclose(p.grad / world, (a + b) / 2, atol=1e-6)
+    opt.zero_grad(set_to_none=False)
+    assert opt.flat_grad.abs().max().item() == 0 and all(p.grad is not None for p in net.parameters())
+    # zero_grad() (direct_grads, torch's set_to_none default) / a generic loop's model.zero_grad(set_to_none=True): .grad is None, the buffer keeps the
+    # LAST step's values, and a plain torch module's autograd creates fresh .grad tensors OUTSIDE the flat buffer.  They must be adopted BEFORE their slice
+    # is exchanged (the exchange used to run on the stale slots, then the local gradient overwrote them)
+    opt.flat_grad.fill_(7.0)
     opt.zero_grad()
-    assert opt.flat_grad.abs().max().item() == 0
-    # a generic loop's model.zero_grad(set_to_none=True): autograd creates fresh .grad tensors OUTSIDE the flat buffer.  They must be
-    # adopted BEFORE their slice is exchanged (the exchange used to run on the stale slots, then the local gradient overwrote them)
-    for p in net.parameters():
-        p.grad = None
+    assert all(p.grad is None for p in net.parameters())
     net(xs[rank]).sum().backward()
     assert all(sl["work"] is not None for sl in opt.slices)
     opt._adopt_grads()
@@ -80,7 +82,7 @@ def _worker(rank, world, port, q):
     opt.zero_grad()
     net(xs[rank]).sum().backward()
     assert all(sl["work"] is not None for sl in opt.slices)
-    opt.zero_grad()
+    opt.zero_grad(set_to_none=False)
     assert all(sl["work"] is None and sl["ready"] == 0 and not sl["done"] for sl in opt.slices) and opt.flat_grad.abs().max().item() == 0
     net(xs[rank]).sum().backward()
     assert all(sl["work"] is not None for sl in opt.slices)

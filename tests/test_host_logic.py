@@ -253,13 +253,42 @@ def test_flat_adamw_is_a_torch_optimizer_with_live_lr_and_torch_format_state():
         assert opt.state[p]["exp_avg"].data_ptr() == opt.exp_avg.data_ptr() + 4 * o
         assert sd2["state"][i]["exp_avg"].eq(5.0).all() and float(sd2["state"][i]["step"]) == 7.0
         assert sd["state"][i]["exp_avg"].data_ptr() != sd2["state"][i]["exp_avg"].data_ptr() and float(sd["state"][i]["step"]) == 1.0
-    # zero_grad keeps .grad bound to the flat buffer, also with set_to_none=True; a re-bound .grad is adopted back
-    opt.zero_grad(set_to_none=True)
+    # zero_grad(set_to_none=False): one memset, .grad stays bound to the flat buffer; a re-bound .grad is adopted back
+    opt.zero_grad(set_to_none=False)
     p0 = opt.params[0]
-    assert p0.grad is not None and p0.grad.data_ptr() == opt.flat_grad.data_ptr()
+    assert p0.grad is not None and p0.grad.data_ptr() == opt.flat_grad.data_ptr() and opt.flat_grad.eq(0).all()
     p0.grad = torch.ones_like(p0)
     opt._adopt_grads()
     assert p0.grad.data_ptr() == opt.flat_grad.data_ptr() and opt.flat_grad[:p0.numel()].eq(1).all()
+    # direct_grads (the default): zero_grad() leaves .grad None and the buffer alone; a backward kernel may claim a parameter's slot ONCE per step
+    # (autograd.grad_sink), adjacent slots as one span; whatever got no gradient is zeroed when the step adopts
+    from diffusion_e2e_ft_amd import autograd as F
+    opt.flat_grad.fill_(3.0)
+    opt.zero_grad()
+    assert all(q.grad is None for q in opt.params) and opt.flat_grad.eq(3).all()
+    flat, views = F.grad_sink(p0)
+    assert flat.data_ptr() == opt.flat_grad.data_ptr() and flat.numel() == p0.numel() and views[0].shape == p0.shape and views[0].stride() == p0.stride()
+    assert F.grad_sink(p0) is None                                                               # second writer of the same step: the ordinary path
+    flat.fill_(2.0)
+    p0.grad = views[0]                                                                           # (what AccumulateGrad does with a gradient nobody else references)
+    adj = [i for i in range(len(opt.params) - 1) if opt.offsets[i + 1] == opt.offsets[i] + opt.params[i].numel() and i > 0]
+    if adj:
+        i = adj[0]
+        span = F.grad_sink(opt.params[i], opt.params[i + 1])
+        assert span is not None and span[0].numel() == opt.params[i].numel() + opt.params[i + 1].numel() and len(span[1]) == 2
+        assert span[1][1].data_ptr() == opt.flat_grad.data_ptr() + 4 * opt.offsets[i + 1]
+        assert F.grad_sink(opt.params[i + 1]) is None
+    assert F.grad_sink(opt.params[0], opt.params[-1]) is None                                    # not adjacent (and p0 is taken)
+    other = torch.nn.Parameter(torch.zeros(3))
+    assert F.grad_sink(other) is None                                                            # not FlatAdamW's
+    opt._adopt_grads()
+    assert opt.flat_grad[:p0.numel()].eq(2).all() and opt.flat_grad[opt.offsets[-1]:opt.offsets[-1] + opt.params[-1].numel()].eq(0).all()
+    assert all(q.grad is not None and q.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * o for q, o in zip(opt.params, opt.offsets))
+    opt.zero_grad()
+    assert F.grad_sink(p0) is not None                                                           # re-armed
+    opt.direct_grads = False
+    opt.zero_grad()
+    assert p0.grad is not None and opt.flat_grad.eq(0).all() and F.grad_sink(p0) is None
     with pytest.raises(ValueError):
         FlatAdamW([{"params": [torch.nn.Parameter(torch.zeros(2))]}, {"params": [torch.nn.Parameter(torch.zeros(2))]}])
 

@@ -143,7 +143,7 @@ def test_optimizer_step_matches_torch_adamw(dev):
     ropt.step()
     for p, (k, v) in zip(ref_params, unet.named_parameters()):
         assert rel_err(v, p) < 1e-5, k
-        assert v.grad is not None and v.grad.abs().max().item() == 0
+        assert v.grad is None                      # FlatAdamW(direct_grads=True).zero_grad(): the next backward's kernels write the slots
     # the step changed the weights the kernels see: a second forward uses re-packed weights
     loss2 = training.e2e_ft_loss(unet, vae, batch, text, "depth")
     assert loss2.item() != loss.item() and math.isfinite(loss2.item())
@@ -413,3 +413,48 @@ def test_bf16_weights_are_views_of_one_flat_cast_and_steps_are_bit_equal(dev):
     assert losses[True][0] == losses[False][0], (losses[True][0], losses[False][0])
     assert torch.equal(losses[True][1], losses[False][1])
     assert F._key(vae.decoder.conv_in.weight) == vkey           # the frozen decoder's packed weights survive optimizer steps (the epoch only concerns flat-resident parameters)
+
+
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+def test_gradients_are_born_in_the_flat_buffer_and_steps_are_bit_equal(dev, cdt):
+    """FlatAdamW(direct_grads=True) (round 4): after zero_grad() every .grad is None, the backward kernels' reductions write each parameter's first gradient of
+    the step into its slot of the flat fp32 buffer and autograd keeps that view as .grad — no AccumulateGrad add, no memset.  (i) after a backward every gradient
+    IS its slot; (ii) optimizer steps — one plain, one with two accumulation micro-steps — equal the same steps with the sink switched off (gradients handed to
+    autograd as fresh tensors and adopted) and with direct_grads=False (memset + in-place accumulation, the round-3 behaviour) bit for bit."""
+    from diffusion_e2e_ft_amd import training, autograd as F
+    batch, text = gc.train_batch()
+
+    def make(direct):
+        unet, vae = _models(dev)
+        if cdt != torch.float32:
+            unet.set_compute_dtype(cdt)
+            vae = vae.to(cdt)
+        return unet, vae, training.FlatAdamW(unet.parameters(), lr=1e-3, max_grad_norm=1.0, direct_grads=direct)
+
+    def run(u, v, o, sink):
+        F.GRAD_SINK_ENABLED = sink
+        try:
+            o.zero_grad()
+            ls = []
+            for n in (1, 2, 1):
+                for i in range(n):
+                    loss = training.e2e_ft_loss(u, v, batch, text, "depth")
+                    (loss / n).backward()
+                    ls.append(loss.item())
+                if n == 1 and sink and o.direct_grads:
+                    born = [q.grad is not None and q.grad.data_ptr() == o.flat_grad.data_ptr() + 4 * off and q.grad.stride() == q.stride()
+                            for q, off in zip(o.params, o.offsets)]
+                    assert all(born), "%d of %d gradients were not written into their slot: %s" % (
+                        len(born) - sum(born), len(born), [k for k, q in u.named_parameters() if any(q is r and not b for r, b in zip(o.params, born))][:8])
+                o.step()
+                o.zero_grad()
+            torch.cuda.synchronize()
+        finally:
+            F.GRAD_SINK_ENABLED = True
+        return ls, o.flat_param.detach().clone()
+
+    a = run(*make(True), True)
+    b = run(*make(True), False)
+    c = run(*make(False), True)
+    assert a[0] == b[0] == c[0], (a[0], b[0], c[0])
+    assert torch.equal(a[1], b[1]) and torch.equal(a[1], c[1])

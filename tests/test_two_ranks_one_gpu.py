@@ -129,6 +129,7 @@ def _two_ranks(dev, backend):
     grads = []
     for sh in shards:
         training.e2e_ft_loss(unet, vae, sh, text, "depth").backward()
+        ref_opt._adopt_grads()          # (direct_grads: slots nobody wrote this step are zeroed here, as step() / grad_norm() do)
         grads.append(ref_opt.flat_grad.detach().clone().cpu())
         ref_opt.zero_grad()
     want_sum = grads[0] + grads[1]
