@@ -50,6 +50,7 @@ def parse():
                     "configs[2] batch in one pass, 122 GB of the 288 GB HBM; 16 in fp32)")
     ap.add_argument("--accum", type=int, default=None, help="--train: gradient-accumulation micro-steps per optimizer step (default 32 / micro-batch)")
     ap.add_argument("--modality", default="depth", choices=["depth", "normals"])
+    ap.add_argument("--no-direct-grads", action="store_true", help="--train, A/B: FlatAdamW(direct_grads=False) — gradients accumulated by autograd into a cleared flat buffer (round 3) instead of written into it by the backward kernels")
     ap.add_argument("--grad-ckpt", action="store_true", help="--train: activation recompute in the UNet blocks and the frozen decoder "
                     "(`--gradient_checkpointing` of the reference's training scripts); off by default: the whole batch fits in 288 GB")
     ap.add_argument("--graph", action="store_true", help="inference: replay one captured hipGraph per batch instead of launching ~1.4k kernels from the host "
@@ -280,7 +281,7 @@ def run_train(args, rank, world, dev):
     if getattr(args, "grad_ckpt", False):
         unet.enable_gradient_checkpointing()
         vae.enable_gradient_checkpointing()
-    opt = training.FlatAdamW(unet.parameters(), lr=3e-5, max_grad_norm=1.0)
+    opt = training.FlatAdamW(unet.parameters(), lr=3e-5, max_grad_norm=1.0, direct_grads=not getattr(args, "no_direct_grads", False))
     R = args.res_h
     mb, acc = train_batching(args)
     text = 0.5 * torch.randn((1, 77, unet.config.cross_attention_dim), generator=torch.Generator(device=dev).manual_seed(0), device=dev)

@@ -91,7 +91,8 @@ def grad_sink(*params):
     tags = [getattr(q, "_e2eft_gslot", None) for q in params]
     if any(t is None for t in tags) or any(q.grad is not None for q in params) or any(t[0] is not tags[0][0] for t in tags):
         return None
-    return tags[0][0]._claim([t[1] for t in tags], params)
+    owner = tags[0][0]()
+    return None if owner is None else owner._claim([t[1] for t in tags], params)
 
 
 def cached(owner, name, params, builder):
@@ -118,10 +119,15 @@ def _vec(p, dtype):
 def packed_conv_weight(conv, dtype):
     """[Co,Ci,kh,kw] -> OHWI rows [Co, kh*kw*Ci_pad] in `dtype` (Ci padded with zeros to a 16-byte multiple)."""
     w = conv.weight
-    if w.dtype != dtype and w.shape[1] % ops.epc(dtype) == 0 and _is_ohwi(w):
-        sv = shadow_view(w, dtype)
-        if sv is not None:                               # the master copy already lies in OHWI order: the packed weight IS the twin's slice
-            return sv.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    if w.dtype != dtype and w.shape[1] % ops.epc(dtype) == 0:
+        if _is_ohwi(w):
+            sv = shadow_view(w, dtype)
+            if sv is not None:                           # the master copy already lies in OHWI order: the packed weight IS the twin's slice
+                return sv.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+        elif w.shape[2] * w.shape[3] == 1 and w.is_contiguous():
+            sv = shadow_view(w, dtype)
+            if sv is not None:                           # 1x1: OIHW and OHWI are the same order
+                return sv.reshape(w.shape[0], w.shape[1])
 
     def build():
         Co, Ci, kh, kw = w.shape
@@ -142,6 +148,10 @@ def packed_conv_weight_dgrad(conv, dtype):
         Co, Ci, kh, kw = w.shape
         e = ops.epc(dtype)
         cip, cop = ops.round_up(Ci, e), ops.round_up(Co, e)
+        if w.is_cuda:      # one batched transpose of the packed forward weight (for FlatAdamW-resident weights that is a view of the 16-bit twin: no cast, no flip, no strided copy)
+            pk = packed_conv_weight(conv, dtype)
+            if pk.is_contiguous() and pk.data_ptr() % 16 == 0:
+                return ops.dgrad_weight_from_packed(pk, Co, kh * kw, cip)
         t = w.detach().to(dtype).flip(2, 3).permute(1, 2, 3, 0)        # [Ci, kh, kw, Co]
         t = torch.nn.functional.pad(t, (0, cop - Co, 0, 0, 0, 0, 0, cip - Ci))
         return t.reshape(cip, kh * kw * cop).contiguous()
@@ -235,20 +245,17 @@ class _Conv2dFn(torch.autograd.Function):
             dres = dy
         if (bias is not None and need[3]) or (ctx.has[0] and need[4]):
             bsink = grad_sink(conv.bias) if (bias is not None and need[3] and conv.bias is not None and conv.bias.dtype == torch.float32) else None
-            if not (ctx.has[0] and need[4]) and cop == Co:
-                # bias only: ONE reduction over all rows (the same order with and without a gradient slot to write into)
-                s1 = ops.colsum(ops._as_rows(dyp), groups=1, alpha=alpha, out=None if bsink is None else bsink[0].view(1, Co))
-                dbias = bsink[1][0] if bsink is not None else s1[0].to(bias.dtype)
-            else:
-                s = ops.colsum(ops._as_rows(dyp), groups=B, alpha=alpha)[:, :Co]       # [B, Co] fp32
-                if ctx.has[0] and need[4]:
-                    drow = s.to(dt)
-                if bias is not None and need[3]:
-                    if bsink is not None:
-                        torch.sum(s, 0, out=bsink[0])
-                        dbias = bsink[1][0]
-                    else:
-                        dbias = s.sum(0).to(bias.dtype)
+            # per-image column sums (B groups: B x the workgroups of one reduction over all rows), then the sum over the images — written into the bias
+            # gradient's slot of the flat buffer when this call is its first writer (same kernels, same order either way)
+            s = ops.colsum(ops._as_rows(dyp), groups=B, alpha=alpha)[:, :Co]       # [B, Co] fp32
+            if ctx.has[0] and need[4]:
+                drow = s.to(dt)
+            if bias is not None and need[3]:
+                if bsink is not None:
+                    torch.sum(s, 0, out=bsink[0])
+                    dbias = bsink[1][0]
+                else:
+                    dbias = s.sum(0).to(bias.dtype)
         if need[0] or (x2 is not None and need[1]):
             dxl = ops.conv2d_dgrad(dyp, packed_conv_weight_dgrad(conv, dt), (B, H, W, c1), c2, kh, kw, stride, pad, up_to, alpha)
             if up_to is not None:

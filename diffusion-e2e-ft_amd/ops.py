@@ -751,6 +751,22 @@ def transpose(x, rows_pad=None, out=None):
     return out[0] if squeeze else out
 
 
+def dgrad_weight_from_packed(pk, cout, taps, cp):
+    """The dgrad operand of a convolution from its packed forward weight: pk [cout, taps*cp] (OHWI rows, 16-byte channel padding) ->
+    [cp, taps*cop] with out[ci][(taps-1-t)*cop + co] = pk[co][t*cp + ci], cop = cout padded to a 16-byte multiple with zeros (include/e2eft.h,
+    e2eft_conv2d_dgrad: flipped taps, channels transposed).  ONE batched e2eft_transpose: batch = tap, the output walks the taps backwards
+    (negative batch stride)."""
+    _check_cuda(pk)
+    e = epc(pk.dtype)
+    assert pk.dim() == 2 and pk.shape == (cout, taps * cp) and pk.is_contiguous() and cp % e == 0 and pk.data_ptr() % 16 == 0
+    cop = round_up(cout, e)
+    out = torch.empty((cp, taps * cop), dtype=pk.dtype, device=pk.device)
+    last = out.data_ptr() + (taps - 1) * cop * pk.element_size()
+    with _timed("transpose", 0.0, 2.0 * taps * cout * cp * pk.element_size(), label="dgrad weight %dx%d taps%d" % (cout, cp, taps)):
+        check(_lib.load().e2eft_transpose(dtype_id(pk.dtype), taps, cout, cp, taps * cp, cp, cop, taps * cop, -cop, _ptr(pk), C.c_void_p(last), _stream()))
+    return out
+
+
 def splitk_plan(M, N, K):
     """(nsplit, kc): weight-gradient GEMMs are [Cout x kh*kw*Cin] outputs contracted over 10^4..10^5 pixels — a handful of output
     tiles.  Split the contraction into nsplit chunks of kc (multiple of 64) columns so that >= ~512 workgroups exist; the

@@ -15,6 +15,7 @@ gradient, the last-finishing one the smallest) keep all seven links busy; the fi
 starts its exchange while the down blocks are still computing.
 """
 import math
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -198,7 +199,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
-            n += (p.numel() + 3) // 4 * 4                     # keep every view 16-byte aligned
+            n += (p.numel() + 7) // 8 * 8                     # keep every view 16-byte aligned in the 16-bit twin too (autograd.FlatShadow): 32 bytes here
         self.numel = n
         # Convolution weights are stored in the order the kernels read them — OHWI, i.e. the Parameter becomes a channels_last view of its slot (same values, same
         # logical OIHW shape: state_dict / save_pretrained / copy_ see no difference) — so that with 16-bit compute the packed weight of every convolution is a
@@ -221,7 +222,7 @@ class FlatAdamW(torch.optim.Optimizer):
                     p.data = view
                     p.grad = self._slot(self.flat_grad, i)
                     p._e2eft_flat = (self.shadow, o)
-                    p._e2eft_gslot = (self, i)
+                    p._e2eft_gslot = (weakref.ref(self), i)      # (weak: the tag must not tie the optimizer's buffers into a reference cycle with its parameters)
         self.direct_grads = bool(direct_grads)
         self._claimed = [False] * len(self.params)
         self._bind_state()
