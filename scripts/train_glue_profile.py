@@ -1,5 +1,6 @@
 """Which host code launches the ATen / runtime-copy kernels of a training step: torch.profiler with Python stacks over one E2E-FT step (full-size UNet + VAE,
-small batch — launch COUNTS do not depend on the batch), grouped by (aten op, innermost frames inside this package).  Usage: python scripts/train_glue_profile.py [B] [res]"""
+any batch), grouped by (aten op, innermost frames inside this package; ops the autograd engine issues itself show `_engine_run_backward`).
+Usage: python scripts/train_glue_profile.py [B] [res] [stacks|methods]   (methods: counters on the torch.Tensor methods instead of the profiler)"""
 import collections
 import os
 import sys
@@ -15,6 +16,7 @@ from diffusion_e2e_ft_amd.vae import AutoencoderKL  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+MODE = sys.argv[3] if len(sys.argv) > 3 else "stacks"
 dev = torch.device("cuda", 0)
 cdt = torch.bfloat16
 with torch.device(dev):
@@ -30,6 +32,23 @@ batches = [training.synthetic_batch(B, R, R, dev, seed=1, dtype=cdt)]
 for i in range(2):
     training.train_step(unet, vae, opt, batches, text, "depth")
 torch.cuda.synchronize()
+if MODE == "stacks":
+  from torch.profiler import ProfilerActivity, profile  # noqa: E402
+  from torch._C._profiler import _ExperimentalConfig  # noqa: E402
+  with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, experimental_config=_ExperimentalConfig(verbose=True)) as prof:
+      training.train_step(unet, vae, opt, batches, text, "depth")
+      torch.cuda.synchronize()
+  rows = []
+  for e in prof.key_averages(group_by_stack_n=14):
+      if not e.key.startswith("aten::") or e.self_device_time_total <= 0:
+          continue
+      frames = [f for f in e.stack if ("diffusion" in f and "scripts/" not in f) or "autograd/" in f or "checkpoint" in f]
+      where = " <- ".join(f.split("/")[-1][:64] for f in frames[:3]) if frames else " <- ".join(f.split("/")[-1][:50] for f in e.stack[:3])
+      rows.append((e.self_device_time_total, e.count, e.key, where))
+  print("device us | calls per step | op | innermost package frames (none = called from C++, e.g. the autograd engine)")
+  for t, n, k, w in sorted(rows, key=lambda r: -r[1])[:45]:
+      print("%9.0f %5d  %-18s %s" % (t, n, k, w))
+  sys.exit(0)
 # ---- who calls the tensor methods that launch ATen kernels: counters keyed on the calling line inside this package (the profiler of this build records no Python stacks)
 import collections as _c  # noqa: E402
 calls = _c.Counter()

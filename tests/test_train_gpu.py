@@ -415,8 +415,8 @@ def test_bf16_weights_are_views_of_one_flat_cast_and_steps_are_bit_equal(dev):
     assert F._key(vae.decoder.conv_in.weight) == vkey           # the frozen decoder's packed weights survive optimizer steps (the epoch only concerns flat-resident parameters)
 
 
-@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
-def test_gradients_are_born_in_the_flat_buffer_and_steps_are_bit_equal(dev, cdt):
+@pytest.mark.parametrize("cdt,ckpt", [(torch.bfloat16, False), (torch.float32, False), (torch.bfloat16, True)], ids=["bf16", "fp32", "bf16_recompute"])
+def test_gradients_are_born_in_the_flat_buffer_and_steps_are_bit_equal(dev, cdt, ckpt):
     """FlatAdamW(direct_grads=True) (round 4): after zero_grad() every .grad is None, the backward kernels' reductions write each parameter's first gradient of
     the step into its slot of the flat fp32 buffer and autograd keeps that view as .grad — no AccumulateGrad add, no memset.  (i) after a backward every gradient
     IS its slot; (ii) optimizer steps — one plain, one with two accumulation micro-steps — equal the same steps with the sink switched off (gradients handed to
@@ -429,6 +429,9 @@ def test_gradients_are_born_in_the_flat_buffer_and_steps_are_bit_equal(dev, cdt)
         if cdt != torch.float32:
             unet.set_compute_dtype(cdt)
             vae = vae.to(cdt)
+        if ckpt:       # activation recompute: the backward kernels run inside torch.utils.checkpoint's re-entered segments
+            unet.enable_gradient_checkpointing()
+            vae.enable_gradient_checkpointing()
         return unet, vae, training.FlatAdamW(unet.parameters(), lr=1e-3, max_grad_norm=1.0, direct_grads=direct)
 
     def run(u, v, o, sink):
