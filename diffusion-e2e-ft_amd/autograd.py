@@ -361,6 +361,7 @@ class _LinearFn(torch.autograd.Function):
         _stash_stats(y)
         ctx.save_for_backward(xp, bias, *weights)
         ctx.meta = (owner, name, alpha, K, residual is not None)
+        ctx.psrc = (bias, weights)      # the Parameter objects themselves (grad_sink reads their tags): under activation recompute saved_tensors hands back detached aliases
         return y
 
     @staticmethod
@@ -390,7 +391,7 @@ class _LinearFn(torch.autograd.Function):
             # q | k | v of one attention lie back to back in FlatAdamW's buffers: one reduction writes all their gradients in place (see grad_sink)
             wsink = None
             if all(need[7:]) and kp == K and all(w_.dtype == torch.float32 and w_.dim() == 2 and w_.is_contiguous() for w_ in weights):
-                wsink = grad_sink(*weights)
+                wsink = grad_sink(*ctx.psrc[1])
             dw = ops.linear_wgrad(g, _rows(xp), alpha, out=None if wsink is None else wsink[0]) if M >= 512 else None      # csrc/wgrad.hip (1x1 case); None -> the transposes + GEMM below
             if dw is None:
                 nsplit, kc = ops.splitk_plan(N, kp, M)
@@ -410,7 +411,7 @@ class _LinearFn(torch.autograd.Function):
                         dws[i] = t if t.dtype == wgt.dtype else t.to(wgt.dtype)
                     o += n
         if bias is not None and need[1]:
-            bsink = grad_sink(bias) if (bias.dtype == torch.float32 and bias.dim() == 1) else None
+            bsink = grad_sink(ctx.psrc[0]) if (bias.dtype == torch.float32 and bias.dim() == 1) else None
             if bsink is not None:
                 ops.colsum(g, groups=1, alpha=alpha, out=bsink[0].view(1, N))
                 dbias = bsink[1][0]
@@ -445,6 +446,7 @@ class _GroupNormFn(torch.autograd.Function):
         y, ws = ops.groupnorm_fwd_ws(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, x2=x2, s1=s1, s2=s2)
         ctx.save_for_backward(x, x2, gamma, beta, ws)
         ctx.meta = (groups, eps, silu)
+        ctx.psrc = (gamma, beta)        # (see _LinearFn)
         if split:
             return y, x.view_as(x)
         return y
@@ -463,8 +465,8 @@ class _GroupNormFn(torch.autograd.Function):
             return dskip, None, None, None, None, None, None, None, None, None
         g = _dense_nhwc(dy, Cc)
         add = _dense_nhwc(dskip, Cc) if (dskip is not None and need[0] and x2 is None) else None
-        gs = grad_sink(gamma) if (need[2] and need[3] and gamma.dtype == torch.float32) else None
-        bs = grad_sink(beta) if (gs is not None and beta.dtype == torch.float32) else None
+        gs = grad_sink(ctx.psrc[0]) if (need[2] and need[3] and gamma.dtype == torch.float32) else None
+        bs = grad_sink(ctx.psrc[1]) if (gs is not None and beta.dtype == torch.float32) else None
         dx, dg, db = ops.groupnorm_bwd(x, x2, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu, g, ws, need_dx=want_dx, need_dparams=want_p,
                                        dx_add=add, dg_out=None if gs is None else gs[0], db_out=None if bs is None else bs[0])
         d1 = dx[..., :c1] if (need[0] and dx is not None) else None
@@ -495,6 +497,7 @@ class _LayerNormFn(torch.autograd.Function):
         y = ops.layernorm(x, _vec(gamma, dt), _vec(beta, dt), eps)
         ctx.save_for_backward(x, gamma, beta)
         ctx.eps = eps
+        ctx.psrc = (gamma, beta)        # (see _LinearFn)
         return y
 
     @staticmethod
@@ -502,7 +505,7 @@ class _LayerNormFn(torch.autograd.Function):
         x, gamma, beta = ctx.saved_tensors
         need = ctx.needs_input_grad
         g = dy if dy.is_contiguous() else dy.contiguous()
-        sink = grad_sink(gamma, beta) if (need[1] and need[2] and gamma.dtype == torch.float32 and beta.dtype == torch.float32) else None   # weight | bias: adjacent slots
+        sink = grad_sink(*ctx.psrc) if (need[1] and need[2] and gamma.dtype == torch.float32 and beta.dtype == torch.float32) else None   # weight | bias: adjacent slots
         dx, dg, db = ops.layernorm_bwd(x, _vec(gamma, x.dtype), ctx.eps, g, need_dx=need[0], gb_out=None if sink is None else sink[0].view(2, -1))
         if sink is not None:
             return dx, sink[1][0], sink[1][1], None
