@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
         unsigned int off1[4], off2[4];          // per-row byte offsets of the current tap in x1 / x2 (OOB_SENTINEL if invalid)
         unsigned int cur_a[4], cur_b[4];        // byte offsets of the NEXT tile to issue (advanced by 128 B per tile)
         int brel[4] = {0, 0, 0, 0};
-        int tile_c = 0, tap = tap0;
+        int tile_c = 0;
         const T* b1;
         const T* b2 = X2;
         if (MODE == 0) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NW * 64) void igemm2_kernel(const IgemmParams p) {
                 }
                 tile_c += BK;
                 if (tile_c >= p.cin) {
-                    tile_c = 0; ++tap;
+                    tile_c = 0;
                     if (++kx == p.kw) { kx = 0; ++ky; }
                 }
             }
