@@ -26,7 +26,7 @@
 namespace e2eft {
 
 namespace wg {
-constexpr int BK = 64, NW = 8;             // tile: 64 NA output channels x 64 (6 - NA) columns, NA = 2 (128 x 256) or 4 (256 x 128)
+constexpr int BK = 64;                     // (8 waves per workgroup) tile: 64 NA output channels x 64 (6 - NA) columns, NA = 2 (128 x 256) or 4 (256 x 128)
 constexpr int PANEL = 64 * 128;            // [64 pixels][64 channels] of 16-bit
 constexpr int STAGE = 6 * PANEL;           // dY panels 0 .. NA - 1, then the X panels
 constexpr int NSTAGE = 3;
