@@ -239,6 +239,8 @@ def test_gradient_checkpointing_gives_bit_equal_gradients_and_saves_memory(dev, 
             unet.enable_gradient_checkpointing()
             vae.enable_gradient_checkpointing()
             assert unet.gradient_checkpointing and all(b.gradient_checkpointing for b in unet.down_blocks)
+        import gc
+        gc.collect()                     # garbage of earlier tests that only the cycle collector frees must not be released INSIDE the measured region
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
