@@ -10,6 +10,8 @@ Activations keep the NHWC / token layout of the forward; parameters keep the dif
 gradients are returned in the parameter's dtype and shape.  Compute dtype follows the activations: fp32 parameters with 16-bit
 activations are cast once per parameter version (cached).
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -42,19 +44,43 @@ def _key(*params):
 # weights, (concatenated) Linear weights, biases and norm parameters are then VIEWS of that twin — no per-tensor cast / permute / cat launches (round 3: ~1100
 # `bfloat16_copy`, 214 `direct_copy` and 84 `flip` ATen launches per step, 12 ms).
 class FlatShadow:
-    def __init__(self, flat):
-        self.flat, self.twins, self.state = flat, {}, {}
+    """flat: the fp32 master buffer; `register(params, offsets)`: the Parameters whose storage it is.  A twin is current for the key (PARAM_EPOCH, flat._version)
+    AND the per-parameter version counters recorded when it was cast: FlatAdamW binds a parameter with `p.data = view`, so p has its OWN version counter —
+    `p.copy_()` under no_grad (load_state_dict, an EMA copy_to) writes the flat buffer but bumps neither flat._version nor the epoch.  `shadow_view`
+    therefore compares the asking parameter's `_version` with the recorded one and re-casts on a mismatch.  (`p.data.copy_()` bumps no counter anywhere in torch;
+    call `bump_param_epoch()` after such a write.)"""
 
-    def twin(self, dtype):
-        key = (PARAM_EPOCH, self.flat._version)          # in-place writes through any parameter view bump the base's version; the optimizer kernel bumps the epoch
+    def __init__(self, flat):
+        self.flat, self.twins, self.state, self.pver, self.params = flat, {}, {}, {}, []
+
+    def register(self, params, offsets):
+        self.params = [(weakref.ref(p), o) for p, o in zip(params, offsets)]      # weak: no cycle parameter -> tag -> shadow -> parameter
+
+    def _versions(self):
+        out = {}
+        for r, o in self.params:
+            p = r()
+            if p is not None:
+                out[o] = p._version
+        return out
+
+    def twin(self, dtype, force=False):
+        key = (PARAM_EPOCH, self.flat._version)          # in-place writes to the flat buffer itself bump its version; the optimizer kernel bumps the epoch
         t = self.twins.get(dtype)
         if t is None:
             t = self.twins[dtype] = torch.empty(self.flat.shape, dtype=dtype, device=self.flat.device)
             self.state[dtype] = None
-        if self.state[dtype] != key:
+        if force or self.state[dtype] != key:
             with torch.no_grad(), ops.on_device_of(self.flat):
                 ops.cast_(self.flat, t)
             self.state[dtype] = key
+            self.pver[dtype] = self._versions()
+        return t
+
+    def view_for(self, p, off, dtype):
+        t = self.twin(dtype)
+        if self.pver[dtype].get(off, p._version) != p._version:      # p was written in place through its own version counter since the cast
+            t = self.twin(dtype, force=True)
         return t
 
 
@@ -69,7 +95,7 @@ def shadow_view(p, dtype):
     sh, off = tag
     if p.data_ptr() != sh.flat.data_ptr() + off * sh.flat.element_size() or p.device != sh.flat.device:
         return None                                      # the parameter was re-bound since (.to(), a deepcopy's stale tag): the lazy per-tensor path serves it
-    return sh.twin(dtype).as_strided(p.shape, p.stride(), off)
+    return sh.view_for(p, off, dtype).as_strided(p.shape, p.stride(), off)
 
 
 def _is_ohwi(w):

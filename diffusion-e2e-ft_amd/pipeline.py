@@ -386,17 +386,25 @@ def aa_tables(in_size, out_size, device, kind="bilinear"):
     return hit
 
 
+def cv2_nearest_indices(in_size, out_size):
+    """cv2.resize(..., interpolation=INTER_NEAREST) along one dimension (geowizard_pipeline.py:205; OpenCV imgproc/resize.cpp `resizeNN`): the scale is formed in
+    DOUBLE as fx = out / in, ifx = 1 / fx, and output i reads min(floor(i * ifx), in - 1).  (torch's "nearest" forms in / out in float32: for non-dyadic ratios the
+    two differ by one source pixel at exact-boundary positions, so the device path and the host path both use THIS table.)  -> int32 [out]"""
+    ifx = 1.0 / (float(out_size) / float(in_size))
+    return np.minimum(np.floor(np.arange(out_size, dtype=np.float64) * ifx).astype(np.int64), in_size - 1).astype(np.int32)
+
+
 def _aa_tables(in_size, out_size, device, kind="bilinear"):
     """aten `_compute_indices_min_size_weights_aa` (UpSampleKernel.cpp), align_corners = False, in aten's float32 arithmetic: (bounds int32 [out, 2] = (first tap,
     tap count), weights fp32 [out, ksize]) — what `F.interpolate(mode=kind, antialias=True)` applies along one dimension.  kind "bilinear": the triangle filter
     (support 1); "bicubic": Keys' cubic with a = -0.5 (support 2) — aten's antialiased bicubic is Pillow's resize (`Image.resize` of a float image, default
     BICUBIC: the resize-back of GeoWizard's `__call__`, geowizard_pipeline.py:201-203) and torchvision's `resize(..., BICUBIC, antialias=True)` (the CLIP image
-    preprocessing, geowizard_pipeline.py:236-245); "nearest": one tap at floor(i * scale) (cv2.INTER_NEAREST / torch "nearest", geowizard_pipeline.py:205).
+    preprocessing, geowizard_pipeline.py:236-245); "nearest": one tap at cv2.INTER_NEAREST's source index (`cv2_nearest_indices`, geowizard_pipeline.py:205).
     Built on the host (a few hundred numbers), consumed by e2eft_resample_bilinear_aa (a separable table-driven resampler: the filter lives in the table)."""
     f32 = np.float32
     scale = f32(in_size) / f32(out_size)
     if kind == "nearest":
-        idx = np.minimum(np.floor(np.arange(out_size, dtype=np.float32) * scale).astype(np.int32), in_size - 1)
+        idx = cv2_nearest_indices(in_size, out_size)
         bounds = np.stack([idx, np.ones_like(idx)], axis=1).astype(np.int32)
         return torch.from_numpy(bounds).to(device), torch.ones((out_size, 1), dtype=torch.float32, device=device)
     base = {"bilinear": f32(1.0), "bicubic": f32(2.0)}[kind]
@@ -692,7 +700,9 @@ class DepthNormalEstimationPipeline:
                 normal_pred = resize_device(normal_pred, (H0, W0), kind="nearest")
             else:
                 depth_pred = torch.nn.functional.interpolate(depth_pred[None, None], size=(H0, W0), mode="bicubic", antialias=True, align_corners=False)[0, 0]
-                normal_pred = torch.nn.functional.interpolate(normal_pred[None], size=(H0, W0), mode="nearest")[0]
+                iy = torch.from_numpy(cv2_nearest_indices(normal_pred.shape[-2], H0)).long()
+                ix = torch.from_numpy(cv2_nearest_indices(normal_pred.shape[-1], W0)).long()
+                normal_pred = normal_pred[:, iy][:, :, ix]
         if match_input_res:
             normal_pred, hwc = normal_pred.permute(1, 2, 0), True      # the reference returns HWC normals after its cv2 resize (:205)
         return DepthNormalPipelineOutput(depth_np=depth_pred.clamp(0, 1).cpu().numpy().astype(np.float32), depth_colored=None,

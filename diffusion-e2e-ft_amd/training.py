@@ -172,7 +172,10 @@ class FlatAdamW(torch.optim.Optimizer):
     the libe2eft autograd Functions write a parameter's FIRST gradient of an optimizer step straight into its slot of `flat_grad` (autograd.grad_sink): the
     tensor autograd then stores as `.grad` is a view of the exchange buffer, no AccumulateGrad add per parameter, no 3.5 GB memset per step.  Later gradients of the
     same step (gradient accumulation) are accumulated by autograd in place as before; gradients that arrive any other way are adopted (copied) into their slot by
-    the hook / `step()`; slots that received nothing are zeroed there."""
+    the hook / `step()`; slots that received nothing are zeroed there.  Scope of the sink: `loss.backward()` accumulating into `.grad`, gradients cleared by
+    `zero_grad()` (this optimizer's or the model's, set_to_none=True).  The tensor such a backward hands to autograd is a VIEW of the exchange buffer that later
+    steps overwrite in place: do not keep it across steps (`torch.autograd.grad(...)` results, hooks that retain the gradient, a `retain_graph` second backward —
+    use direct_grads=False for those)."""
 
     def __init__(self, params, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0, n_slices=4,
                  process_group=None, external_grad_sync=False, direct_grads=True):
@@ -223,6 +226,7 @@ class FlatAdamW(torch.optim.Optimizer):
                     p.grad = self._slot(self.flat_grad, i)
                     p._e2eft_flat = (self.shadow, o)
                     p._e2eft_gslot = (weakref.ref(self), i)      # (weak: the tag must not tie the optimizer's buffers into a reference cycle with its parameters)
+                self.shadow.register(self.params, self.offsets)
         self.direct_grads = bool(direct_grads)
         self._claimed = [False] * len(self.params)
         self._bind_state()
@@ -427,14 +431,19 @@ class FlatAdamW(torch.optim.Optimizer):
                                     g["eps"], g["weight_decay"], self._steps, self._coef, sumsq, grad_scale=grad_scale / self.world,
                                     max_norm=float(self.max_grad_norm or 0.0))
         self._rearm_exchange()
+        self._claimed = [False] * len(self.params)       # a loop that clears gradients with model.zero_grad() instead of ours still gets the sink next step
         F.bump_param_epoch()
         return loss
 
     def grad_norm(self):
-        """global L2 norm of the (averaged) gradient — host value, synchronises.  With world > 1 this completes the exchange (each slice
-        is summed once per optimizer step, so a following `step()` does not exchange again)."""
+        """global L2 norm of the (averaged) gradient — host value, synchronises.  With world > 1 and `sync_grads` this completes the exchange (each slice
+        is summed once per optimizer step, so a following `step()` does not exchange again).  On a gradient-accumulation micro-step (`sync_grads` False) nothing
+        is exchanged — summing a partial accumulation across ranks early and then adding local micro-gradients on top would corrupt the step —
+        and the value is the norm of THIS rank's local gradient so far."""
         with ops.on_device_of(self.flat_param):
             self._adopt_grads()
+            if not self.sync_grads:
+                return math.sqrt(float(ops.sumsq(self.flat_grad, out=self._sumsq).item()))
             self._finish_exchange()
             return math.sqrt(float(ops.sumsq(self.flat_grad, out=self._sumsq).item())) / self.world
 

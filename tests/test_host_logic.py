@@ -1,5 +1,6 @@
 """Host-side logic of the product package on CPU (no kernels run): parameter layout, weight packing, config surface,
 scheduler, checkpoint round trip, rank sharding."""
+import math
 import os
 
 import pytest
@@ -412,13 +413,15 @@ def _apply_tables(x, xt, yt):
 
 def test_aa_bicubic_and_nearest_tables_match_torch_and_pillow():
     """pipeline.aa_tables(kind="bicubic") = aten's antialiased bicubic (the CLIP preprocessing of geowizard_pipeline.py:236-245 through torchvision) = Pillow's
-    `Image.resize` of a float image with its default BICUBIC (the depth resize-back of geowizard_pipeline.py:201-203); kind="nearest" = cv2.INTER_NEAREST / torch
-    "nearest" (:205)."""
+    `Image.resize` of a float image with its default BICUBIC (the depth resize-back of geowizard_pipeline.py:201-203); kind="nearest" = cv2.INTER_NEAREST (:205): OpenCV's
+    resizeNN forms the inverse scale in DOUBLE (1 / (out / in)), torch's "nearest" forms in / out in float32 — the last case below is a ratio where the two pick
+    different source pixels, and the table follows cv2."""
     import numpy as np
     from PIL import Image
     from diffusion_e2e_ft_amd.pipeline import aa_tables
     g = torch.Generator().manual_seed(1)
-    for (H, W, h, w) in [(768, 576, 224, 224), (96, 128, 480, 640), (61, 45, 224, 224), (576, 768, 1000, 1333)]:
+    differs = 0
+    for (H, W, h, w) in [(768, 576, 224, 224), (96, 128, 480, 640), (61, 45, 224, 224), (576, 768, 1000, 1333), (58, 87, 577, 1000)]:
         img = torch.rand((2, H, W), generator=g)
         out = _apply_tables(img.numpy(), aa_tables(W, w, "cpu", "bicubic"), aa_tables(H, h, "cpu", "bicubic"))
         want = torch.nn.functional.interpolate(img[None], size=(h, w), mode="bicubic", antialias=True, align_corners=False)[0].numpy()
@@ -426,7 +429,11 @@ def test_aa_bicubic_and_nearest_tables_match_torch_and_pillow():
         pil = np.asarray(Image.fromarray(img[0].numpy()).resize((w, h)))                 # mode "F", default resample
         assert np.abs(out[0] - pil).max() <= 2e-4, ((H, W, h, w), np.abs(out[0] - pil).max())       # (Pillow builds its coefficients in double precision)
         near = _apply_tables(img.numpy(), aa_tables(W, w, "cpu", "nearest"), aa_tables(H, h, "cpu", "nearest"))
-        assert np.array_equal(near, torch.nn.functional.interpolate(img[None], size=(h, w), mode="nearest")[0].numpy())
+        iy = [min(int(math.floor(i * (1.0 / (h / H)))), H - 1) for i in range(h)]
+        ix = [min(int(math.floor(i * (1.0 / (w / W)))), W - 1) for i in range(w)]
+        assert np.array_equal(near, img.numpy()[:, iy][:, :, ix])
+        differs += int(not np.array_equal(near, torch.nn.functional.interpolate(img[None], size=(h, w), mode="nearest")[0].numpy()))
+    assert differs >= 1          # the float32 rule is NOT the same function: at least the last ratio tells them apart
 
 
 def test_flat_adamw_keeps_convolution_weights_in_kernel_order():

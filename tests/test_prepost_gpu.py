@@ -37,7 +37,9 @@ def test_resize_device_bicubic_antialiased_and_nearest(dev, H, W, h, w):
     f = torch.rand(3, H, W, generator=g)
     want = TF.interpolate(f[None], size=(h, w), mode="bicubic", antialias=True, align_corners=False)[0]
     assert (resize_device(f.to(dev), (h, w), kind="bicubic").cpu() - want).abs().max().item() <= 4e-6
-    assert torch.equal(resize_device(f.to(dev), (h, w), kind="nearest").cpu(), TF.interpolate(f[None], size=(h, w), mode="nearest")[0])
+    iy = torch.tensor([min(int(i * (1.0 / (h / H))), H - 1) for i in range(h)])          # cv2 resizeNN: double-precision inverse scale, floor, clamp
+    ix = torch.tensor([min(int(i * (1.0 / (w / W))), W - 1) for i in range(w)])
+    assert torch.equal(resize_device(f.to(dev), (h, w), kind="nearest").cpu(), f[:, iy][:, :, ix])
     rgb = f[None] * 2 - 1
     a = preprocess_for_clip(rgb.to(dev)).cpu()
     b = preprocess_for_clip(rgb)

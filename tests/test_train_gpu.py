@@ -2,6 +2,7 @@
 CPU oracle under torch autograd (tests/golden/train_golden.pt from tests/golden/make_golden.py): same seeded weights, batch
 and text embedding.  fp32 bar: loss 1e-4, every parameter's gradient norm within 2e-3 relative, sampled gradient tensors
 within 2e-3 of their largest entry; bf16 activations with fp32 master weights are checked at a stated looser tolerance."""
+import gc as _pygc          # the cycle collector; the module-level name `gc` below is golden_cases
 import math
 import os
 
@@ -239,8 +240,7 @@ def test_gradient_checkpointing_gives_bit_equal_gradients_and_saves_memory(dev, 
             unet.enable_gradient_checkpointing()
             vae.enable_gradient_checkpointing()
             assert unet.gradient_checkpointing and all(b.gradient_checkpointing for b in unet.down_blocks)
-        import gc
-        gc.collect()                     # garbage of earlier tests that only the cycle collector frees must not be released INSIDE the measured region
+        _pygc.collect()                   # garbage of earlier tests that only the cycle collector frees must not be released INSIDE the measured region
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
@@ -415,6 +415,44 @@ def test_bf16_weights_are_views_of_one_flat_cast_and_steps_are_bit_equal(dev):
     assert losses[True][0] == losses[False][0], (losses[True][0], losses[False][0])
     assert torch.equal(losses[True][1], losses[False][1])
     assert F._key(vae.decoder.conv_in.weight) == vkey           # the frozen decoder's packed weights survive optimizer steps (the epoch only concerns flat-resident parameters)
+
+
+def test_bf16_twin_follows_in_place_parameter_writes(dev):
+    """FlatAdamW binds parameters with `p.data = view`, so `p.copy_()` (load_state_dict, an EMA `copy_to`) writes the flat fp32 buffer through the
+    PARAMETER's version counter — neither the buffer's `_version` nor the optimizer epoch moves.  The 16-bit twin must still be re-cast: a bf16 forward, then
+    `load_state_dict` of different weights, then a forward again must equal a freshly built model with those weights, bit for bit."""
+    from diffusion_e2e_ft_amd import training, autograd as F
+    batch, text = gc.train_batch()
+    bf = torch.bfloat16
+
+    def make(sd):
+        unet, vae = _models(dev)
+        unet.load_state_dict(sd)
+        unet.set_compute_dtype(bf)
+        return unet, vae.to(bf), training.FlatAdamW(unet.parameters(), lr=1e-3)
+
+    sd0 = gc.tiny_unet_sd()
+    g = torch.Generator().manual_seed(5)
+    sd1 = {k: v + 0.05 * v.abs().mean() * torch.randn(v.shape, generator=g) for k, v in sd0.items()}
+    unet, vae, opt = make(sd0)
+    with torch.no_grad():
+        l0 = training.e2e_ft_loss(unet, vae, batch, text, "depth").item()            # builds the twin from sd0
+    casts = opt.shadow.state[bf]
+    ver = opt.flat_param._version
+    unet.load_state_dict(sd1)                                                          # p.copy_() per parameter, under no_grad
+    assert opt.flat_param._version == ver and opt.shadow.state[bf] == casts            # the premise: nothing the old key looked at has moved
+    conv = unet.down_blocks[0].resnets[0].conv1
+    assert torch.equal(F.packed_conv_weight(conv, bf), conv.weight.detach().to(bf).permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1))
+    with torch.no_grad():
+        l1 = training.e2e_ft_loss(unet, vae, batch, text, "depth").item()
+    fresh, fvae, _ = make(sd1)
+    with torch.no_grad():
+        want = training.e2e_ft_loss(fresh, fvae, batch, text, "depth").item()
+    assert l1 == want and l1 != l0, (l0, l1, want)
+    # a single parameter written in place (what an EMA copy_to does parameter by parameter)
+    with torch.no_grad():
+        conv.bias.copy_(conv.bias * 2 + 1)
+    assert torch.equal(F._vec(conv.bias, bf), conv.bias.detach().to(bf))
 
 
 @pytest.mark.parametrize("cdt,ckpt", [(torch.bfloat16, False), (torch.float32, False), (torch.bfloat16, True)], ids=["bf16", "fp32", "bf16_recompute"])

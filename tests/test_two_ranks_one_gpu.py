@@ -38,15 +38,14 @@ def _models(dev):
     return unet.to(dev).train(), vae.to(dev).eval().requires_grad_(False)
 
 
-def _shards():
+def _shards(world=2):
     import golden_cases as gc
-    batch, text = gc.train_batch()
-    n = batch["rgb"].shape[0]
-    assert n >= 2
-    return [{k: v[i:i + 1] for k, v in batch.items()} for i in range(2)], text
+    batch, text = gc.train_batch(B=world)
+    assert batch["rgb"].shape[0] == world
+    return [{k: v[i:i + 1] for k, v in batch.items()} for i in range(world)], text
 
 
-def _worker(rank, world, port, q, backend="gloo"):
+def _worker(rank, world, port, q, backend="gloo", ckpt=False):
     """backend "gloo": both ranks on cuda:0; "nccl" (= RCCL): rank r on cuda:r, the exchange on RCCL's own stream"""
     try:
         sys.path.insert(0, HERE)
@@ -67,15 +66,21 @@ def _worker(rank, world, port, q, backend="gloo"):
             q.put(("skip", rank, repr(e)))
             dist.destroy_process_group()
             return
-        assert probe.tolist() == [3.0] * 4
+        assert probe.tolist() == [world * (world + 1) / 2.0] * 4
         unet, vae = _models(dev)
-        shards, text = _shards()
+        if ckpt:                          # the reference recipe (train_marigold_e2e_ft_depth.sh:11): the hooks fire from the backward of RECOMPUTED blocks
+            unet.enable_gradient_checkpointing()
+            vae.enable_gradient_checkpointing()
+        shards, text = _shards(world)
         opt = training.FlatAdamW(unet.parameters(), lr=1e-3, max_grad_norm=1.0, n_slices=3)
-        assert opt.world == 2 and len(opt._hooks) == len(opt.params)
+        assert opt.world == world and len(opt._hooks) == len(opt.params)
         # two accumulation micro-steps on this rank's shard (the same shard twice, halved): only the second one exchanges
         opt.sync_grads = False
         (training.e2e_ft_loss(unet, vae, shards[rank], text, "depth") * 0.5).backward()
         assert all(sl["work"] is None for sl in opt.slices)
+        local_norm = opt.grad_norm()          # on a micro-step: THIS rank's partial gradient, nothing exchanged, nothing marked done
+        assert all(sl["work"] is None and not sl["done"] for sl in opt.slices) and local_norm > 0
+        assert abs(local_norm - opt.flat_grad.double().norm().item()) <= 1e-6 * local_norm
         opt.sync_grads = True
         (training.e2e_ft_loss(unet, vae, shards[rank], text, "depth") * 0.5).backward()
         assert all(sl["work"] is not None for sl in opt.slices)          # every slice's all-reduce was launched from a hook, during the backward
@@ -98,6 +103,18 @@ def test_two_ranks_share_one_gpu_hooks_exchange_and_update(dev):
     _two_ranks(dev, "gloo")
 
 
+def test_four_ranks_share_one_gpu_hooks_exchange_and_update(dev):
+    """world size 4 (BASELINE configs[3] is 8 ranks; four processes is what one device's launch queues take in reasonable time): the slice bookkeeping, the
+    division by the world size inside the update kernel and the mean-over-ranks = mean-over-micro-batches identity at a world size that is not 2"""
+    _two_ranks(dev, "gloo", world=4)
+
+
+def test_two_ranks_share_one_gpu_with_activation_recompute(dev):
+    """the reference recipe runs with --gradient_checkpointing: the parameter hooks fire from the backward of recomputed blocks (torch.utils.checkpoint
+    re-runs a block's forward inside the backward), the slices must still be launched exactly once and carry the same sums"""
+    _two_ranks(dev, "gloo", ckpt=True)
+
+
 def test_two_ranks_two_gpus_rccl_hooks_exchange_and_update(dev):
     """The same step with backend "nccl" = RCCL over xGMI, one rank per GPU (training/scripts/multi_gpu.yaml:1-15; train.py:369,559,563): FlatAdamW's
     hook-launched slices run on RCCL's stream while the backward continues on the compute stream.  Needs two visible GPUs; a one-GPU box skips."""
@@ -106,15 +123,15 @@ def test_two_ranks_two_gpus_rccl_hooks_exchange_and_update(dev):
     _two_ranks(dev, "nccl")
 
 
-def _two_ranks(dev, backend):
+def _two_ranks(dev, backend, world=2, ckpt=False):
     from diffusion_e2e_ft_amd import training
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, ckpt)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in range(2)]
+    res = [q.get(timeout=600) for _ in range(world)]
     for p in procs:
         p.join(120)
     if any(r[0] == "skip" for r in res):
@@ -124,7 +141,7 @@ def _two_ranks(dev, backend):
     # ---- reference in this process: per-shard gradients, then ONE step over the two shards as accumulated micro-batches
     sys.path.insert(0, HERE)
     unet, vae = _models(dev)
-    shards, text = _shards()
+    shards, text = _shards(world)
     ref_opt = training.FlatAdamW(unet.parameters(), lr=1e-3, max_grad_norm=1.0)
     grads = []
     for sh in shards:
@@ -132,18 +149,18 @@ def _two_ranks(dev, backend):
         ref_opt._adopt_grads()          # (direct_grads: slots nobody wrote this step are zeroed here, as step() / grad_norm() do)
         grads.append(ref_opt.flat_grad.detach().clone().cpu())
         ref_opt.zero_grad()
-    want_sum = grads[0] + grads[1]
+    want_sum = sum(grads[1:], grads[0])
     for r in res:
         err = (r[2] - want_sum).abs().max().item() / want_sum.abs().max().item()
         assert err < 1e-5, ("exchanged gradient != sum over ranks", r[1], err)
         assert r[4] == 1 and r[5] == 0
-    assert torch.equal(res[0][3], res[1][3]), "ranks diverged"
+    assert all(torch.equal(res[0][3], r[3]) for r in res[1:]), "ranks diverged"
     # the update: clip_grad_norm_(1.0) + torch.optim.AdamW on the MEAN of the ranks' gradients (train.py:561-566 under DDP).  Fed with the very buffer
     # the ranks exchanged (an Adam step is ~ lr * sign(g) where |g| >> eps and ill-conditioned in g where |g| ~ eps, so a reference built from
     # separately rounded gradients would differ there by O(lr) without anything being wrong)
     before = ref_opt.flat_param.detach().clone().cpu()
     rp = torch.nn.Parameter(before.clone())
-    rp.grad = res[0][2] / 2
+    rp.grad = res[0][2] / world
     torch.nn.utils.clip_grad_norm_([rp], 1.0)
     torch.optim.AdamW([rp], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2).step()
     perr = (res[0][3] - rp.detach()).abs().max().item()
