@@ -299,14 +299,18 @@ def run_train(args, rank, world, dev):
     timer = ops.KernelTimer()
     ops.TIMER = timer
     opt.profile_exchange = world > 1
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # step boundaries on the launch stream: per-step times -> median
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     assert torch.isfinite(loss).all(), "non-finite loss"
     elapsed = D.max_over_ranks(elapsed, device=dev)
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
@@ -326,6 +330,7 @@ def run_train(args, rank, world, dev):
             "metric": "E2E-FT training step time (affine-invariant depth loss, UNet bwd): one optimizer step",
             "value": sec, "unit": "s/step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "median_ms_per_step": per_step[len(per_step) // 2], "min_ms_per_step": per_step[0], "max_ms_per_step": per_step[-1],
             "images_per_s": n_img / sec, "final_loss": float(loss), "peak_mem_gib": peak_mem,
             "config": {"workload": "E2E-FT training step (%s loss, UNet bwd) batch=%d/GPU (%d micro-steps x %d) at %dx%d, %s compute, fp32 master "
                                    "weights + flat AdamW, %s%s" % (args.modality, mb * acc, acc, mb, R, R, args.dtype,
@@ -487,8 +492,12 @@ def kernel_mix(symbols):
 
 def pmc_traffic(mix, want):
     """HBM bytes per launch of the dominant family from the PMC counters.  rocprofv3 --pmc cannot wrap its own process, so the counters are
-    collected offline on exactly this workload (scripts/pmc_traffic.py) and committed with the build's launch counts PER KERNEL of the
-    family; the figure is printed only when every one of those counts equals this run's (same kernel population), else null."""
+    collected offline on exactly this workload (scripts/pmc_traffic.py) and committed under profiles/ together with the BUILD ID of the library
+    they were collected on (`e2eft_build_id()`: hash of csrc/, the headers and the flags) and the launch counts per kernel of the family.  The
+    figure is printed only when the committed profile's build id equals the id of the library THIS process runs (round 4 matched launch counts
+    only and cited a round-3 profile as "the same build") and the launch counts agree; else null with the reason."""
+    from diffusion_e2e_ft_amd import _lib
+    mine = _lib.build_id()
     prof = os.path.join(ROOT, "profiles")
     files = sorted((f for f in os.listdir(prof) if f.endswith("_pmc_hbm_traffic.json")), reverse=True) if os.path.isdir(prof) else []
     if not want:
@@ -498,6 +507,9 @@ def pmc_traffic(mix, want):
     for fn in files:
         with open(os.path.join(prof, fn)) as f:
             pj = json.load(f)
+        if pj.get("build_id") != mine:
+            seen.append("%s: build id %s" % (fn, pj.get("build_id", "none (collected before round 5)")))
+            continue
         k = pj["kernels"].get("igemm")
         if not k or k.get("launches_per_step") is None:
             seen.append("%s: no launch counts" % fn)
@@ -507,8 +519,14 @@ def pmc_traffic(mix, want):
         seen.append("%s: %s" % (fn, {kk: vv for kk, vv in theirs.items() if vv}))
         if all(abs(theirs[kern] - ours[kern]) < 0.01 for kern in names) and abs(k["launches_per_step"] - sum(mix.values())) < 0.01:
             others = {g: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "launches_per_step": v.get("launches_per_step")} for g, v in pj["kernels"].items() if g != "igemm"}
-            return k["hbm_bytes_per_launch"], "static: profiles/%s (PMC pass of the same build: launches per step %s there and here)" % (fn, {kk: vv for kk, vv in theirs.items() if vv}), pj["source"], others
-    return None, None, "no committed PMC profile has this run's igemm launches per step %s (%s)" % ({kk: vv for kk, vv in mix.items() if vv}, "; ".join(seen[:3])), {}
+            return (k["hbm_bytes_per_launch"], "static: profiles/%s (rocprofv3 --pmc passes over this workload on build id %s = the id of the library this run loaded; launches per step %s there and here)"
+                    % (fn, mine, {kk: vv for kk, vv in theirs.items() if vv}), pj["source"], others)
+    return None, None, "no committed PMC profile was collected on this build (library id %s; %s)" % (mine, "; ".join(seen[:4])), {}
+
+
+def _build_id():
+    from diffusion_e2e_ft_amd import _lib
+    return _lib.build_id()
 
 
 def latency_leg(pipe, dev, dtype, warm=5, iters=30):
@@ -659,7 +677,7 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "world": world, "ranks": ranks, "rccl_ranks": world if world > 1 else 0,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if args.dtype == "fp16" else args.dtype, "data": "synthetic",
+            "dtype": "f16" if args.dtype == "fp16" else args.dtype, "data": "synthetic", "build_id": _build_id(),
             "config": {"workload": "marigold-e2e-ft-depth 1-step inference, batch=%d/GPU at %dx%d %s, random-init SD-v2 UNet (866M) + SD VAE (84M)%s"
                                    % (B, RH, RW, args.dtype, " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
                        "images_per_step": B * world, "resolution": R, "parallelism": "dp%d (image sharding, no collective)" % world,
@@ -713,16 +731,18 @@ def main():
             # recipe's precision (`--mixed_precision no`, training/scripts/train_marigold_e2e_ft_depth.sh:15) AND with bf16 compute over
             # fp32 master weights
             del pipe, out, rgb, img
-            for key, tdt, tsteps in (("train_step", "bf16", 3), ("train_step_fp32", "fp32", 3)):
+            # 10 timed steps after 2 warm-up steps each, mean (`value`) and median: VERDICT r4 (3 steps after 1 were too few).  `train_step_fp32_ckpt` is the
+            # reference recipe as its script runs it: fp32, `--gradient_checkpointing`, micro-batches of 2 x 16 (train_marigold_e2e_ft_depth.sh:9-11,15)
+            for key, tdt, tsteps, twarm, ckpt in (("train_step", "bf16", 10, 2, False), ("train_step_fp32", "fp32", 10, 2, False), ("train_step_fp32_ckpt", "fp32", 10, 2, True)):
                 try:
                     torch.cuda.empty_cache()
                     torch.cuda.reset_peak_memory_stats()
                     _mark(timeline, "%s leg start" % key)
                     targs = argparse.Namespace(**vars(args))
-                    targs.dtype, targs.res, targs.steps, targs.warmup, targs.detail, targs.micro_batch, targs.accum = tdt, 576, tsteps, 1, None, None, None
+                    targs.dtype, targs.res, targs.steps, targs.warmup, targs.detail, targs.micro_batch, targs.accum, targs.grad_ckpt = tdt, 576, tsteps, twarm, None, None, None, ckpt
                     targs.res_h = targs.res_w = 576
                     t = run_train(targs, 0, 1, dev)
-                    line[key] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "images_per_s", "dtype", "steps", "warmup", "peak_mem_gib")}
+                    line[key] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "median_ms_per_step", "min_ms_per_step", "max_ms_per_step", "images_per_s", "dtype", "steps", "warmup", "peak_mem_gib")}
                     line[key]["workload"] = t["config"]["workload"]
                     line[key]["roofline"] = {k: t["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac")}
                 except Exception as e:

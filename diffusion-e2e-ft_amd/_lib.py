@@ -43,7 +43,7 @@ class AttnDesc(C.Structure):
 
 
 # e2eft_set_option keys (include/e2eft.h)
-OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV, OPT_THIN_INPUT_CONV, OPT_FUSED_NORM = range(9)
+OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV, OPT_THIN_INPUT_CONV, OPT_FUSED_NORM, OPT_ATTN_DMA = range(10)
 
 _P = C.c_void_p
 _I = C.c_int32
@@ -55,6 +55,7 @@ _Z = C.c_size_t
 SIGNATURES = {
     "e2eft_version": (_I, []),
     "e2eft_last_error": (C.c_char_p, []),
+    "e2eft_build_id": (C.c_char_p, []),
     "e2eft_set_option": (_I, [_I, _I]),
     "e2eft_get_option": (_I, [_I]),
     "e2eft_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -148,6 +149,14 @@ def load():
     if _LIB is not None:
         return _LIB
     path = lib_path()
+    default = os.path.abspath(path) == os.path.abspath(_build.LIB)
+    if default and os.path.exists(path) and os.path.isdir(_build.CSRC) and _build.built_id() != _build.source_id():
+        # the binary on disk was built from other sources than the ones next to it (an edit without a rebuild, a stale snapshot): never run it silently
+        try:
+            _build.build(verbose=False)
+        except Exception as e:
+            raise RuntimeError("libe2eft.so (build id %s) does not match the sources in %s (id %s) and could not be rebuilt: %s"
+                               % (_build.built_id(), _build.CSRC, _build.source_id(), e))
     if not os.path.exists(path):
         try:
             _build.build(verbose=False)
@@ -160,10 +169,18 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.e2eft_version() < 115:
+    if lib.e2eft_version() < 118:
         raise RuntimeError("libe2eft.so is stale (version %d)" % lib.e2eft_version())
+    if default and os.path.isdir(_build.CSRC) and lib.e2eft_build_id().decode() != _build.source_id():
+        raise RuntimeError("libe2eft.so carries build id %s, the sources next to it hash to %s: rebuild (python -m diffusion_e2e_ft_amd.build --force)"
+                           % (lib.e2eft_build_id().decode(), _build.source_id()))
     _LIB = lib
     return lib
+
+
+def build_id():
+    """e2eft_build_id() of the loaded library (hash of its sources + flags)"""
+    return load().e2eft_build_id().decode()
 
 
 def set_option(key, value):

@@ -3,6 +3,7 @@
 The shared library is the product's compute path; nothing here falls back to PyTorch or to the oracle.
 `python -m diffusion_e2e_ft_amd.build` or `__graft_entry__.build()` run this; hipcc cross-compiles without a GPU.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -37,8 +38,39 @@ def _newest_source_mtime():
     return max(os.path.getmtime(p) for p in paths)
 
 
+ID_MARK = b"E2EFT_BUILD_ID="      # api.hip embeds "E2EFT_BUILD_ID=<16 hex>" in the binary: the id can be read without loading the library
+
+
+def source_id():
+    """sha256 (first 16 hex digits) over everything that determines the binary: every file of csrc/, the public headers, the flags.  Stamped into the
+    library (-DE2EFT_BUILD_ID, `e2eft_build_id()`); a measurement made with one build and quoted by another process carries it."""
+    h = hashlib.sha256()
+    inc = os.path.join(HERE, "..", "include")
+    for path in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(inc, "e2eft.h"), os.path.join(inc, "e2eft_debug.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(repr((SOURCES, FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    return h.hexdigest()[:16]
+
+
+def built_id(path=None):
+    """the source id the library on disk was stamped with (what `e2eft_build_id()` returns once it is loaded), read from the file's bytes; None if absent"""
+    try:
+        with open(path or LIB, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(ID_MARK)
+    if i < 0:
+        return None
+    tail = blob[i + len(ID_MARK):i + len(ID_MARK) + 16]
+    return tail.decode("ascii", "replace") if len(tail) == 16 and all(c in b"0123456789abcdef" for c in tail) else None
+
+
 def needs_build():
-    return not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest_source_mtime()
+    """the library is missing, older than a source, or stamped with another source id (a checkout that moved mtimes backwards)"""
+    return not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest_source_mtime() or built_id() != source_id()
 
 
 def build(force=False, verbose=True):
@@ -47,14 +79,16 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
+    sid = source_id()
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
+        stamp = ['-DE2EFT_BUILD_ID="%s"' % sid] if src == "api.hip" else []      # api.hip carries the id: it is recompiled on every build (2 s)
         deps = [srcp, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm.h"), os.path.join(CSRC, "attn512_regs.inc"), os.path.join(CSRC, "igemm_persistent_epilogue.inc"), os.path.join(HERE, "..", "include", "e2eft.h"), os.path.join(HERE, "..", "include", "e2eft_debug.h"), os.path.abspath(__file__)]
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(d) for d in deps):
+        if not force and not stamp and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(d) for d in deps):
             return obj
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", srcp, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + stamp + ["-c", srcp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -69,8 +103,9 @@ def build(force=False, verbose=True):
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     os.replace(tmp, LIB)
+    assert built_id() == sid, (built_id(), sid)
     if verbose:
-        print("built", LIB)
+        print("built", LIB, "build id", sid)
     return LIB
 
 

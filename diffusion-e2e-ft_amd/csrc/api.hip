@@ -45,7 +45,7 @@ void tag_kernel(const char* fmt, ...) {
 }
 const char* last_tag() { return g_tag; }
 
-static std::atomic<int> g_opt[E2EFT_OPT_COUNT] = {{1}, {0}, {1}, {1}, {0}, {0}, {1}, {1}, {1}};
+static std::atomic<int> g_opt[E2EFT_OPT_COUNT] = {{1}, {0}, {1}, {1}, {0}, {0}, {1}, {1}, {1}, {1}};
 
 int option(int key) { return g_opt[key].load(std::memory_order_relaxed); }
 
@@ -68,4 +68,12 @@ extern "C" int e2eft_get_option(int32_t key) { return key >= 0 && key < E2EFT_OP
 extern "C" const char* e2eft_debug_last_kernel(void) { return e2eft::last_tag(); }
 
 extern "C" int e2eft_version(void) { return E2EFT_VERSION; }
+// identity of the SOURCES this binary was built from: sha256 over csrc/*, include/*.h and the compiler flags, computed by build.py and passed as
+// -DE2EFT_BUILD_ID (hex string).  Measurements that are collected in one process and quoted by another (the PMC traffic figure in bench.py's
+// roofline) carry it, so "same build" is an equality of ids, not of launch counts.
+#ifndef E2EFT_BUILD_ID
+#define E2EFT_BUILD_ID "unstamped"
+#endif
+static const char k_build_id[] = "E2EFT_BUILD_ID=" E2EFT_BUILD_ID;      // (the marker lets build.py read the id from the file without loading it)
+extern "C" const char* e2eft_build_id(void) { return k_build_id + 15; }
 extern "C" const char* e2eft_last_error(void) { return e2eft::err_buf(); }

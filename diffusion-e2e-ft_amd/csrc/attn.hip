@@ -348,6 +348,239 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// attn_fwd_dma_kernel — the same arithmetic per (query, key) as attn_fwd_kernel, instruction for instruction (swapped MFMAs, the same accumulation chains, scores
+// relative to a reference maximum, row sums on the matrix pipe, deferred rescale: results are bit-identical), with another K / V delivery:
+//   * the 64-key tiles arrive by LDS-DMA (`buffer_load ... lds`: one wave instruction = 8 key rows of 128 data bytes = 1 KiB, two K and two V pieces per wave and
+//     tile) into a THREE-stage ring — no global -> VGPR -> ds_write staging (attn_fwd_kernel spends 4 global loads, 4 ds_write_b128 and 16 registers per thread and
+//     tile on it, and stalls on vmcnt(0) in front of the stores when a load is late); the pieces of tile t + 2 are requested before tile t multiplies;
+//   * LDS rows are the 128 data bytes (a DMA piece is lane-linear, there is no row padding), the bank spread comes from XOR swizzles on the SOURCE side, undone in
+//     the fragment addresses: K chunk ^ ((row >> 1) & 7) (conflict-free ds_read_b128, as igemm2.hip), V chunk ^ (((row >> 1) & 1) << 2) (the four key rows of a
+//     transpose read land on four different 64-byte windows, as wgrad.hip);
+//   * one counted wait (this wave's pieces of tile t + 1; those of tile t + 2 may still be in flight) and one barrier per tile, as before.
+// Still 4 waves and two workgroups per CU: the two waves of a SIMD belong to DIFFERENT workgroups, drift apart and overlap their MFMA and softmax phases — the
+// 8-wave form of this delivery (one workgroup, both waves of a SIMD in lockstep behind one barrier) measured 765 against 795 TF/s (profiles/r04_attention_experiments.md).
+// K / V are addressed through one 32-bit buffer descriptor per tensor: the launcher takes this kernel only below 3.5 GB.
+namespace adma {
+constexpr int KT = 64, HALF = KT * 128, STAGE = 2 * HALF;      // one 64-key tile: 8 KiB of K rows, 8 KiB of V rows
+constexpr unsigned OOB = 0xF0000000u, RECORDS = 0xE0000000u;
+}
+typedef __attribute__((address_space(3))) void* lptr_a_t;
+// one LDS-DMA piece (64 lanes x 16 B -> 1 KiB at m0) from asm: issued through the builtin the compiler would count it and drain vmcnt(0) in front of LDS reads it
+// cannot prove disjoint; the kernel counts its own pieces.  m0 is saved and restored.
+__device__ __forceinline__ void dma_piece_a(const __amdgpu_buffer_rsrc_t& rs, const unsigned voff, const unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_addr) : "memory");
+}
+
+// TPB = 64-key tiles per barrier.  1: three stages of one tile (48 KiB), tile t + 2 requested while tile t multiplies; 2: two stages of two tiles (64 KiB), the next
+// pair requested while this pair multiplies — half the barriers (the measurement that asked for it: with TPB = 1 the DMA delivery runs exactly as fast as the
+// register-staged kernel, 802 against 800 TF/s, while the probe with the tile pinned in LDS — no loads AND no barrier — runs at 957: what costs is the
+// synchronisation of the four waves once per tile, not the instructions that move the data).
+template <typename T, bool JOINT, int TPB>
+__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnParams p) {
+    using namespace adma;
+    constexpr int NSTAGE = 2, SSTAGE = TPB * STAGE, LDS = NSTAGE * SSTAGE;      // 32 KiB at TPB = 1: measured 772-776 against 749-752 TF/s (production) and 749-755 (three stages)
+    __shared__ __attribute__((aligned(1024))) char smem[LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    int b, head, qblk;
+    {   // XCD-aware block map, as attn_fwd_kernel
+        const int npair = p.batch * p.heads, nqb = p.nqb;
+        const int L = blockIdx.x, full = (npair >> 3) << 3;
+        if (L < full * nqb) {
+            const int xcd = L & 7, idx = L >> 3;
+            const int pr = (idx / nqb) * 8 + xcd;
+            qblk = idx - (idx / nqb) * nqb;
+            b = pr / p.heads; head = pr - b * p.heads;
+        } else {
+            const int r = L - full * nqb;
+            const int pr = full + r / nqb;
+            qblk = r - (r / nqb) * nqb;
+            b = pr / p.heads; head = pr - b * p.heads;
+        }
+    }
+    const int q0 = qblk * 128 + wave * 32;
+    const T* __restrict__ Q = (const T*)p.q;
+
+    // ---- loader: wave w moves key rows 8 w .. 8 w + 7 and 8 (w + 4) .. of every tile; lane -> row 8 w + (lane >> 3), LDS slot lane & 7 (the swizzle keys only see
+    // (row >> 1) & 7 / & 1: unchanged by + 32)
+    const int lrow = 8 * wave + (lane >> 3);
+    const unsigned kch = (unsigned)(((lane & 7) ^ ((lrow >> 1) & 7)) * 16), vch = (unsigned)(((lane & 7) ^ (((lrow >> 1) & 1) << 2)) * 16);
+    const int kvb0 = b % p.kv_bmod;
+    const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.k + head * 64), 0, RECORDS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.v + head * 64), 0, RECORDS, 0x00020000);
+    const unsigned ldkb = (unsigned)p.ldk * (unsigned)sizeof(T), ldvb = (unsigned)p.ldv * (unsigned)sizeof(T);
+    const unsigned lds0 = (unsigned)(uintptr_t)((lptr_a_t)smem);
+    auto fire = [&](const int G) {       // the 4 TPB pieces of tile group G this wave owns; keys beyond the last one fetch zeros (their scores are masked below)
+#pragma unroll
+        for (int sub = 0; sub < TPB; ++sub) {
+            const unsigned dst0 = lds0 + (unsigned)((G % NSTAGE) * SSTAGE + sub * STAGE + wave * 1024);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int key = (G * TPB + sub) * KT + lrow + 32 * i;
+                unsigned row;
+                if (JOINT) {
+                    const int seg = key / p.nk_seg;
+                    row = (unsigned)((kvb0 + seg * p.kv_bmod) * p.nk_seg + (key - seg * p.nk_seg));
+                } else {
+                    row = (unsigned)(kvb0 * p.nk_seg + key);
+                }
+                const bool ok = key < p.nk_total;
+                dma_piece_a(rsk, ok ? row * ldkb + kch : OOB, dst0 + (unsigned)(i * 4096));
+                dma_piece_a(rsv, ok ? row * ldvb + vch : OOB, dst0 + (unsigned)(i * 4096 + HALF));
+            }
+        }
+    };
+    const int nt = (p.nk_total + KT - 1) / KT, ng = (nt + TPB - 1) / TPB;
+    fire(0);
+
+    // ---- Q'^T fragments (B operand), pre-multiplied by scale * log2(e)
+    u32x4 qf[4];
+    {
+        const int qr = q0 + l31;
+        const bool ok = qr < p.nq;
+        const T* src = Q + ((long)b * p.nq + (ok ? qr : 0)) * p.ldq + head * 64 + 8 * hh;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            Vec16<T> v;
+            v.raw = ok ? *reinterpret_cast<const u32x4*>(src + 16 * ds) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.e[e] = from_f<T>(to_f(v.e[e]) * p.c);
+            qf[ds] = v.raw;
+        }
+    }
+    // fragment addresses inside a stage.  K: row kt2 * 32 + l31, k-step ds: chunk (2 ds + hh) ^ ((l31 >> 1) & 7)
+    const int kswz = (l31 >> 1) & 7;
+    int kofs[4];
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) kofs[ds] = l31 * 128 + (((2 * ds + hh) ^ kswz) << 4);
+    // V^T (transpose read): 16-lane group g1 = (lane >> 4) & 1 serves d columns 16 g1 .. + 15 of the 32-column block dt, lane i16 supplies key row (i16 >> 2) + 4 hh of
+    // a run and 4 d; the row's swizzle bit ((row >> 1) & 1 = (i16 >> 3) & 1) toggles the 64-byte half, i.e. dt
+    const int i16 = lane & 15, vb1 = (i16 >> 3) & 1;
+    const int vrow = ((i16 >> 2) + 4 * hh) * 128 + 32 * ((lane >> 4) & 1) + 8 * (i16 & 3);
+    const int vofs[2] = {HALF + vrow + vb1 * 64, HALF + vrow + (1 - vb1) * 64};      // dt = 0, 1
+
+    constexpr float THR = 6.0f;
+    const u32x4 ones = std::is_same<T, f16>::value ? u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u} : u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    floatx16 o[2], lacc, cinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; lacc[r] = 0.f; cinit[r] = 0.f; }
+    float m_ref = 0.f;
+    bool first = true;
+    asm volatile("" : "+v"(cinit));
+    u32x4 ones_v = ones;
+    asm volatile("" : "+v"(ones_v));
+
+    // group 0 (this wave's pieces; with TPB = 1 the four of tile 1 may still be in flight), then everybody's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    auto tile = [&](const int t, const char* st) {
+        // ---- S'^T = K Q'^T - m_ref : two 32-key sub-tiles ----
+        floatx16 s[2];
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+            const char* row = st + kt2 * 32 * 128;
+            s[kt2] = MmaA<T>::run(*reinterpret_cast<const u32x4*>(row + kofs[0]), qf[0], cinit);
+#pragma unroll
+            for (int ds = 1; ds < 4; ++ds) s[kt2] = MmaA<T>::run(*reinterpret_cast<const u32x4*>(row + kofs[ds]), qf[ds], s[kt2]);
+        }
+        if (t * 64 + 64 > p.nk_total) {
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + kt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= p.nk_total) s[kt2][r] = -INFINITY;
+                }
+        }
+        uint32_t pw[2][8];
+        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
+        mx = fmaxf(fmaxf(mx, s[0][15]), s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
+        mx = fmaxf(mx, s[1][15]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (first || __builtin_amdgcn_ballot_w64(mx > THR) != 0) {   // uniform; after the first tiles: rare
+            const float delta = first ? mx : (mx > THR ? mx : 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            m_ref += delta;
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt2][r] -= delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; lacc[r] *= alpha; cinit[r] = -m_ref; }
+            asm volatile("" : "+v"(cinit));
+            first = false;
+        }
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+                pw[kt2][w] = Pk<T>::pack(__builtin_amdgcn_exp2f(s[kt2][2 * w]), __builtin_amdgcn_exp2f(s[kt2][2 * w + 1]));
+
+        // ---- O^T += V^T P^T and l^T += 1 P^T ----
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4 pf = {pw[kt2][4 * s2], pw[kt2][4 * s2 + 1], pw[kt2][4 * s2 + 2], pw[kt2][4 * s2 + 3]};
+                const char* vb = st + (kt2 * 32 + 16 * s2) * 128;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const u32x2 v0 = tr_read(vb + vofs[dt]);
+                    const u32x2 v1 = tr_read(vb + 8 * 128 + vofs[dt]);
+                    const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+                    o[dt] = MmaA<T>::run(vf, pf, o[dt]);
+                }
+                lacc = MmaA<T>::run(ones_v, pf, lacc);
+            }
+        }
+    };
+
+    for (int G = 0; G < ng; ++G) {
+        // the stage being refilled held group G - 1 (TPB = 2) / G - 1 of three (TPB = 1): every wave finished reading it before the barrier that closed iteration G - 1
+        constexpr int AHEAD = 1;
+        if (G + AHEAD < ng) fire(G + AHEAD);
+        const char* st = smem + (G % NSTAGE) * SSTAGE;
+        tile(G * TPB, st);
+        if constexpr (TPB == 2) {
+            if (G * TPB + 1 < nt) tile(G * TPB + 1, st + STAGE);      // (uniform)
+        }
+        if (G + 1 < ng) {   // this wave's pieces of group G + 1 have landed (TPB = 1: those of G + 2 may fly); after the barrier everybody's have, and everybody is done with this stage
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+
+    {   // ---- epilogue: as attn_fwd_kernel
+        const float l_tot = lacc[0];
+        const float inv = 1.f / l_tot;
+        const int qr = q0 + l31;
+        if (p.lse && hh == 0 && qr < p.nq) p.lse[((long)b * p.heads + head) * p.nq + qr] = m_ref + __builtin_amdgcn_logf(l_tot);
+        if (qr < p.nq) {
+            T* dst = (T*)p.out + ((long)b * p.nq + qr) * p.ldo + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 w;
+                    w[0] = pack2<T>(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
+                    w[1] = pack2<T>(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+                    *reinterpret_cast<u32x2*>(dst + dt * 32 + 8 * g + 4 * hh) = w;
+                }
+        }
+    }
+}
+
 }  // namespace e2eft
 
 using namespace e2eft;
@@ -380,7 +613,11 @@ extern "C" int e2eft_attn_fwd_lse(const E2eftAttnDesc* d, const void* q, const v
     p.nqb = cdiv(d->nq, 128);
     E2EFT_REQUIRE(pairs * p.nqb < 2147483647L, "attn: grid");
     dim3 grid((unsigned)(pairs * p.nqb));
-#define E2EFT_ATTN_LAUNCH(TT, JJ) hipLaunchKernelGGL((attn_fwd_kernel<TT, JJ, 1>), grid, dim3(256), 0, s, p)
+    // LDS-DMA delivery (E2EFT_OPT_ATTN_DMA): K / V addressed through one 32-bit buffer descriptor each
+    const long kv_rows = (long)d->kv_bmod * d->kv_nseg * d->nk_seg;
+    const bool dma = option(E2EFT_OPT_ATTN_DMA) != 0 && kv_rows * (d->ldk > d->ldv ? d->ldk : d->ldv) * 2 < 0xE0000000L;
+#define E2EFT_ATTN_LAUNCH(TT, JJ) do { if (dma) hipLaunchKernelGGL((attn_fwd_dma_kernel<TT, JJ, 1>), grid, dim3(256), 0, s, p); \
+                                       else hipLaunchKernelGGL((attn_fwd_kernel<TT, JJ, 1>), grid, dim3(256), 0, s, p); } while (0)
     if (d->dtype == E2EFT_F16) {
         if (joint) E2EFT_ATTN_LAUNCH(f16, true); else E2EFT_ATTN_LAUNCH(f16, false);
     } else {

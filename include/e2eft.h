@@ -34,7 +34,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: what this header (and e2eft_debug.h) declares is ALL it exports (tests/test_abi.py) */
 #pragma GCC visibility push(default)
 
-#define E2EFT_VERSION 116 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
+#define E2EFT_VERSION 118 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
 
 enum {
     E2EFT_OK = 0,
@@ -48,6 +48,8 @@ enum { E2EFT_F32 = 0, E2EFT_F16 = 1, E2EFT_BF16 = 2 };
 
 int e2eft_version(void);
 const char* e2eft_last_error(void);
+/* hex id of the sources + flags this library was built from (build.py: sha256 over csrc, include and the hipcc flags); "unstamped" for a hand build */
+const char* e2eft_build_id(void);
 
 /* Process-wide tuning options (A/B measurements and tests; the defaults are what the product path runs with).  Setting an
  * option affects launches issued AFTER the call, on every thread.  e2eft_set_option returns E2EFT_ERR_BAD_ARG for an
@@ -62,7 +64,8 @@ enum {
     E2EFT_OPT_PATCH_CONV = 6,        /* 1 (default): big 16-bit 3x3 / stride-1 / pad-1 convolutions on the halo-patch kernel (igemm6); 0: igemm5 */
     E2EFT_OPT_THIN_INPUT_CONV = 7,   /* 1 (default): big 16-bit 3x3 / stride-1 / pad-1 convolutions with EIGHT input channels on convin.hip; 0: igemm2 */
     E2EFT_OPT_FUSED_NORM = 8,        /* 1 (default): e2eft_conv2d_fwd_normed_supported may answer 1; 0: it answers 0 (GroupNorm applied by its own pass) */
-    E2EFT_OPT_COUNT = 9
+    E2EFT_OPT_ATTN_DMA = 9,          /* 1 (default since round 5): e2eft_attn_fwd delivers K / V tiles by LDS-DMA into a two-stage ring (K / V below 3.5 GB); 0: staged through registers (bit-identical results) */
+    E2EFT_OPT_COUNT = 10
 };
 int e2eft_set_option(int32_t key, int32_t value);
 int e2eft_get_option(int32_t key);

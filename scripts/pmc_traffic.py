@@ -59,6 +59,13 @@ def main():
     if "gn_apply" in res["kernels"]:
         k = res["kernels"]["gn_apply"]
         res["calibration_gn_apply_raw_fetch_over_write"] = k["raw_fetch_kib_per_launch"] / k["raw_write_kib_per_launch"]
+    # identity of the build the counters were collected on: bench.py prints the figure only for a library with this id ("same build" used to be
+    # inferred from launch counts alone)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from diffusion_e2e_ft_amd import build as _b
+    res["build_id"] = _b.built_id()
+    res["source_id"] = _b.source_id()
+    assert res["build_id"] == res["source_id"], "the library on this box was not built from the sources on this box: %r" % (res,)
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps({g: round(v["hbm_bytes_per_launch"] / 1e6, 1) for g, v in res["kernels"].items()}), res.get("calibration_gn_apply_raw_fetch_over_write"))

@@ -1,5 +1,5 @@
-"""e2eft_attn_fwd with E2EFT_OPT_ATTN_DMA = 1 (csrc/attn.hip, attn_fwd_dma_kernel): K / V tiles delivered by LDS-DMA into a three-stage ring instead of
-through registers.  The arithmetic per (query, key) is the production kernel's, instruction for instruction, so outputs and log-sum-exps must be BIT-identical —
+"""e2eft_attn_fwd with E2EFT_OPT_ATTN_DMA = 1 (csrc/attn.hip, attn_fwd_dma_kernel; the default since round 5): K / V tiles delivered by LDS-DMA into a
+two-stage ring instead of through registers (option 0: attn_fwd_kernel, the round-3 kernel).  The arithmetic per (query, key) is the production kernel's, instruction for instruction, so outputs and log-sum-exps must be BIT-identical —
 ragged query / key counts (partial last tile, a single key, fewer keys than one tile), 1 ... 7 tiles (ring wrap-around), fused q|k|v column views, the
 GeoWizard joint (two-segment) keys, a late dominant key (the deferred rescale), fp16 and bf16 — and equal to torch's SDPA within the usual bar."""
 import pytest
@@ -11,18 +11,15 @@ from util import assert_close, q
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 2], ids=["one_tile_per_barrier", "two_tiles_per_barrier"])
-def dma(request):
+@pytest.fixture
+def dma():
     from diffusion_e2e_ft_amd import _lib
 
     def run(fn):
-        _lib.set_option(_lib.OPT_ATTN_DMA, 0)
-        a = fn()
-        _lib.set_option(_lib.OPT_ATTN_DMA, request.param)
-        try:
+        with _lib.option(_lib.OPT_ATTN_DMA, 0):
+            a = fn()
+        with _lib.option(_lib.OPT_ATTN_DMA, 1):
             b = fn()
-        finally:
-            _lib.set_option(_lib.OPT_ATTN_DMA, 0)
         torch.cuda.synchronize()
         return a, b
     return run
