@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 5, call 1: is the tree green on a GPU (suite incl. the new tests), attention A/B, default bench line with the new legs, fp32 training per-shape table
+TAG=${1:-r05a}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out
+mkdir -p $O
+timeout 300 python -m pytest tests/test_attn_dma_gpu.py -q -x 2>&1 | tail -4 > $O/${TAG}_attn_dma_tests.log
+if ! grep -q " passed" $O/${TAG}_attn_dma_tests.log || grep -q "failed" $O/${TAG}_attn_dma_tests.log; then export E2EFT_TEST_OPTIONS=attn_dma=0; echo "DMA attention FAILED its bit-identity test: suite runs with attn_dma=0" >> $O/${TAG}_attn_dma_tests.log; fi
+timeout 1500 python -m pytest tests -q -m gpu --maxfail=25 2>&1 | tail -40 > $O/${TAG}_gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1
+for rep in 1 2; do for v in 0 1; do
+  python scripts/attn_bench.py 8 5 9216 30 fp16 attn_dma=$v; python scripts/attn_bench.py 8 10 2304 60 fp16 attn_dma=$v; python scripts/attn_bench.py 8 20 576 200 fp16 attn_dma=$v
+done; done > $O/${TAG}_attn_ab.txt 2>&1
+timeout 900 python bench.py --steps 20 --warmup 5 --detail $O/${TAG}_bench_per_shape.tsv > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
+timeout 300 python bench.py --train --dtype fp32 --steps 2 --warmup 1 --detail $O/${TAG}_bench_train_fp32_per_shape.tsv > $O/${TAG}_bench_train_fp32.json 2>/dev/null
+cat $O/${TAG}_attn_dma_tests.log; tail -5 $O/${TAG}_gpu_tests.log; tail -2 $O/${TAG}_smoke.log; cat $O/${TAG}_attn_ab.txt
+python - <<PY
+import json
+j=json.load(open("gpurun_out/${TAG}_bench_default.json"))
+print("inference", j["value"], j["ms_per_step"], j["roofline"]["frac"], j["roofline"]["traffic_note"][:200])
+for k in ("train_step","train_step_fp32","train_step_fp32_ckpt"):
+    t=j.get(k,{}); print(k, t.get("value"), t.get("median_ms_per_step"), t.get("peak_mem_gib"), t.get("error"))
+print("latency", j.get("latency_b1_576x768",{}).get("value"), "geo", j.get("geowizard",{}).get("value"), "stages", j.get("stages",{}).get("ms_per_step"))
+PY
