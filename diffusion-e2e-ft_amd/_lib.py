@@ -122,6 +122,7 @@ SIGNATURES = {
     "e2eft_masked_quantiles_workspace_bytes": (_Z, [_I]),
     "e2eft_masked_quantiles": (_I, [_I, _L, _P, _F, _F, _F, _F, _P, _P, _Z, _P]),
     "e2eft_prepare_sample": (_I, [_I, _L, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "e2eft_align_normals_u8": (_I, [_I, _I, _I, _P, _P, C.POINTER(C.c_double), _P, _P]),
     "e2eft_resample_bilinear_aa": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
     "e2eft_minmax_unit_workspace_bytes": (_Z, []),
     "e2eft_minmax_unit": (_I, [_L, _P, _P, _P, _P, _Z, _P]),

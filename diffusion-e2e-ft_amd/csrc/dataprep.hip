@@ -195,6 +195,42 @@ __global__ __launch_bounds__(256) void dp_prepare(long hw, float near, float far
     }
 }
 
+// Hypersim.__getitem__'s normal orientation fix (load.py:225-232 with align_normals / creat_uv_mesh, :185-204; Hypersim's stored normals do not always
+// face the camera), on the DECODED uint8 normal image and the metric depth, in the reference's float64 arithmetic operation for operation (no contraction):
+//   n = u8 / 255 * 2 - 1;  n.y, n.z *= -1;  P = depth * (invK [x, y, 1]^T);  if (n . P > 0) n = -n;  n = -n;  u8' = trunc((n + 1) / 2 * 255).
+// One thread per pixel; 7 B read, 3 B written.
+struct DpInvK { double m[9]; };
+__global__ __launch_bounds__(256) void dp_align_normals(int h, int w, const uint8_t* __restrict__ nrm, const float* __restrict__ depth, DpInvK ik,
+                                                        uint8_t* __restrict__ out) {
+#pragma clang fp contract(off)
+    const long hw = (long)h * w;
+    const long b = blockIdx.y;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < hw; p += (long)gridDim.x * 256) {
+        const int y = (int)(p / w), x = (int)(p - (long)y * w);
+        const uint8_t* src = nrm + (b * hw + p) * 3;
+        double n[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) n[c] = ((double)src[c] / 255.0) * 2.0 - 1.0;
+        n[1] *= -1.0;
+        n[2] *= -1.0;
+        const double d = (double)depth[b * hw + p];
+        double dot = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double pr = (ik.m[3 * r] * (double)x + ik.m[3 * r + 1] * (double)y) + ik.m[3 * r + 2] * 1.0;      // (inv_K @ xy)[r], k in order
+            const double t = n[r] * (d * pr);
+            dot = r == 0 ? t : dot + t;
+        }
+        const double sgn = dot > 0.0 ? 1.0 : -1.0;          // flipped by the mask, then the whole map times -1: net +1 where the mask is set, -1 elsewhere
+        uint8_t* dst = out + (b * hw + p) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double v = n[c] * sgn;
+            dst[c] = (uint8_t)(int)(((v + 1.0) / 2.0) * 255.0);      // .astype(np.uint8): truncation
+        }
+    }
+}
+
 static size_t dp_ws_bytes(int batch) {
     return (size_t)batch * (DP_BINS + 2 * DP_RANKS * DP_BINS) * sizeof(unsigned) + (size_t)batch * (sizeof(DpHead) + DP_RANKS * sizeof(DpSel));
 }
@@ -243,4 +279,15 @@ extern "C" int e2eft_prepare_sample(int32_t batch, int64_t hw, const float* rgb0
     hipLaunchKernelGGL(dp_prepare, dim3(blocks, batch), dim3(256), 0, (hipStream_t)stream, (long)hw, near_plane, far_plane, rgb01, depth, normal01,
                        quantiles, rgb, depth3, metric, normals, val_mask);
     return check_launch("prepare_sample");
+}
+
+extern "C" int e2eft_align_normals_u8(int32_t batch, int32_t h, int32_t w, const uint8_t* normal_u8, const float* depth, const double* inv_k,
+                                      uint8_t* out, void* stream) {
+    E2EFT_REQUIRE(batch >= 1 && batch <= 65535 && h >= 1 && w >= 1 && normal_u8 && depth && inv_k && out, "align_normals: bad arguments");
+    DpInvK ik;
+    for (int i = 0; i < 9; ++i) ik.m[i] = inv_k[i];
+    const long hw = (long)h * w;
+    const int blocks = cdiv(hw, 256) < 4096 ? (int)cdiv(hw, 256) : 4096;
+    hipLaunchKernelGGL(dp_align_normals, dim3(blocks, batch), dim3(256), 0, (hipStream_t)stream, (int)h, (int)w, normal_u8, depth, ik, out);
+    return check_launch("align_normals");
 }

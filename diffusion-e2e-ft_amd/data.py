@@ -7,7 +7,22 @@
   hflip_sample      load.py:76-84: synchronised horizontal flip incl. the sign change of the normals' x component.
   augment_hypersim / augment_vkitti   load.py:67-152: the synchronised transforms (h-flip, PIL-exact bilinear / nearest resize to 480 x 640,
                     ToTensor; h-flip, ToTensor, KITTI benchmark crop 352 x 1216) on batches of DECODED images resident on the device.
-File decoding (PNG / EXR through PIL / cv2) stays with the caller: no image library is part of this package."""
+  Hypersim / VirtualKITTI2   load.py:160-283 / :285-375: the dataset classes — same constructor arguments, same file discovery (`_find_pairs`), same
+                    `len()`; `__getitem__` stops after DECODING (host numpy arrays as the files hold them): everything the reference does to a sample after
+                    that — the Hypersim normal-orientation fix, the synchronised transform, the validity mask / quantiles / normalisation — is batched on
+                    the device by `DeviceLoader`.
+  DeviceLoader      the `torch.utils.data.DataLoader(dataset, shuffle=True, batch_size=...)` of train.py:364-365 for those classes: torch's own sampler
+                    (the reference's index order), a thread pool that decodes ahead, pinned staging buffers, upload + device preparation on a side stream;
+                    yields the batch dict train.py consumes (train.py:470-475).  `MixedDataLoader(DeviceLoader(hypersim), DeviceLoader(vkitti), 9, 1)` is
+                    the reference's training input.
+File decoding itself is a callable (`decoder=`): the default uses Pillow when it is importable (every file of both datasets is a PNG / JPEG it reads,
+16-bit depth included — the reference's cv2.imread of the KITTI depth returns the same integers); the package does not import an image library otherwise."""
+import csv
+import os
+import random
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import torch
 
@@ -176,3 +191,223 @@ def augment_vkitti(rgb_u8, depth, normal_u8=None, flip=None):
     d = ops.aug_gather(depth.float().contiguous(), ym, xm, flip=fl)[:, None]
     n01 = None if normal_u8 is None else ops.aug_gather(normal_u8.contiguous(), ym, xm, flip=fl, invert_x_on_flip=True)
     return rgb01, d, n01
+
+
+# ---- dataset classes (decode on the host) + the device-side loader -----------------------------------------------------------------------------------
+def pil_decoder(path, kind):
+    """default `decoder`: kind "rgb" / "normal" -> uint8 [H,W,3] (`Image.open(p).convert('RGB')`, load.py:217,224,327,333), "depth" -> the integer
+    array as stored (uint16 millimetres / centimetres; `np.array(Image.open(p))` load.py:220-221, `cv2.imread(p, ANYCOLOR | ANYDEPTH)` :329)"""
+    from PIL import Image
+    with Image.open(path) as im:
+        if kind == "depth":
+            return np.array(im)
+        return np.array(im.convert("RGB"))
+
+
+class _DecodedDataset:
+    """base: `pairs` (file triplets), `decoder`, the per-dataset constants DeviceLoader needs"""
+    name = None
+
+    def __len__(self):
+        return len(self.pairs)
+
+    def _decode(self, rgb_path, depth_path, normal_path):
+        rgb = np.ascontiguousarray(self.decoder(rgb_path, "rgb"))
+        normal = np.ascontiguousarray(self.decoder(normal_path, "normal"))
+        return rgb, self.decoder(depth_path, "depth"), normal
+
+
+class Hypersim(_DecodedDataset):
+    """load.py:160-283.  root_dir / transform / near_plane / far_plane as the reference; `split_path` (the reference hard-codes the relative path below)
+    and `decoder` are additions.  `__getitem__(i)` -> {"rgb_u8" uint8 [768,1024,3], "depth" fp32 [768,1024] metres, "normal_u8" uint8 [768,1024,3]}:
+    decoded, depth converted as the reference converts it (uint16 / 1000 in float64, stored as a float32 PIL image: load.py:220-222)."""
+    name = "hypersim"
+    FOCAL = 886.81                   # load.py:230
+
+    def __init__(self, root_dir, transform=True, near_plane=1e-5, far_plane=65.0, split_path=None, decoder=None):
+        self.root_dir = root_dir
+        self.split_path = split_path or os.path.join("data/hypersim/processed/train/filename_meta_train.csv")
+        self.near_plane, self.far_plane = near_plane, far_plane
+        self.align_cam_normal = True
+        self.decoder = decoder or pil_decoder
+        self.pairs = self._find_pairs()
+        self.transform = (480, 640) if transform else None          # SynchronizedTransform_Hyper(H=480, W=640)
+
+    def _find_pairs(self):           # load.py:170-183
+        pairs = []
+        with open(self.split_path, newline="") as f:
+            for row in csv.DictReader(f):
+                if str(row["included_in_public_release"]).strip().lower() not in ("true", "1") or row["split_partition_name"] != "train":
+                    continue
+                rgb_path = os.path.join(self.root_dir, "train", row["rgb_path"])
+                depth_path = os.path.join(self.root_dir, "train", row["depth_path"])
+                head, _ = os.path.split(os.path.join(self.root_dir, "train"))
+                normal_path = os.path.join(head, "normals", row["scene_name"], "images", "scene_%s_geometry_preview" % row["camera_name"],
+                                           "frame.%s.normal_cam.png" % str(int(row["frame_id"])).zfill(4))
+                if os.path.exists(rgb_path) and os.path.exists(depth_path) and os.path.exists(normal_path):
+                    pairs.append({"rgb_path": rgb_path, "depth_path": depth_path, "normal_path": normal_path})
+        return pairs
+
+    @staticmethod
+    def inverse_intrinsics(H, W):    # load.py:194-198 with K = [886.81, 886.81, W / 2, H / 2] (:230)
+        K = np.array([[Hypersim.FOCAL, 0, W / 2], [0, Hypersim.FOCAL, H / 2], [0, 0, 1]])
+        return np.linalg.inv(K)
+
+    def __getitem__(self, idx):
+        pr = self.pairs[idx]
+        rgb, depth, normal = self._decode(pr["rgb_path"], pr["depth_path"], pr["normal_path"])
+        return {"rgb_u8": rgb, "depth": np.ascontiguousarray((depth / 1000).astype(np.float32)), "normal_u8": normal}
+
+
+class VirtualKITTI2(_DecodedDataset):
+    """load.py:285-375.  `__getitem__(i)` -> {"rgb_u8" uint8 [375,1242,3], "depth" fp32 [375,1242] metres (`.astype(np.float32) / 100.0`, :330), "normal_u8"}"""
+    name = "vkitti"
+
+    def __init__(self, root_dir, transform=None, near_plane=1e-5, far_plane=80.0, decoder=None):
+        self.root_dir = root_dir
+        self.near_plane, self.far_plane = near_plane, far_plane
+        self.decoder = decoder or pil_decoder
+        self.pairs = self._find_pairs()
+        self.transform = "kitti_benchmark_crop" if transform else None        # SynchronizedTransform_VKITTI()
+
+    def _find_pairs(self):           # load.py:294-318
+        pairs = []
+        roots = [os.path.join(self.root_dir, d) for d in ("vkitti_2.0.3_rgb", "vkitti_2.0.3_depth", "vkitti_DAG_normals")]
+        for scene in ("Scene01", "Scene02", "Scene06", "Scene18", "Scene20"):
+            for weather in ("morning", "fog", "rain", "sunset", "overcast"):
+                for camera in ("Camera_0", "Camera_1"):
+                    rgb_dir, depth_dir, normal_dir = (os.path.join(r, scene, weather, "frames", k, camera) for r, k in zip(roots, ("rgb", "depth", "normal")))
+                    if os.path.exists(rgb_dir) and os.path.exists(depth_dir):
+                        for f in os.listdir(rgb_dir):
+                            if f.endswith(".jpg"):
+                                stem = f[3:]
+                                pairs.append((os.path.join(rgb_dir, "rgb" + stem), os.path.join(depth_dir, "depth" + stem.replace(".jpg", ".png")),
+                                              os.path.join(normal_dir, "normal" + stem.replace(".jpg", ".png"))))
+        return pairs
+
+    def __getitem__(self, idx):
+        rgb, depth, normal = self._decode(*self.pairs[idx])
+        return {"rgb_u8": rgb, "depth": np.ascontiguousarray(depth.astype(np.float32) / 100.0), "normal_u8": normal}
+
+
+@torch.no_grad()
+@ops.tensor_scoped
+def finish_samples(rgb_u8, depth, normal_u8, dataset, flip=None, transform=True, near_plane=None, far_plane=None, align=True):
+    """everything `__getitem__` does after decoding (load.py:225-283 / :336-375), batched on the device: rgb_u8 / normal_u8 uint8 [B,H0,W0,3], depth fp32
+    [B,H0,W0] metres, flip = per-sample booleans -> the batch dict.  Hypersim: normals turned towards the camera on the full-resolution image
+    (e2eft_align_normals_u8), then flip + Pillow-exact resize to 480 x 640; Virtual KITTI 2: flip + KITTI benchmark crop; then prepare_batch."""
+    if dataset == "hypersim":
+        if align:
+            H0, W0 = rgb_u8.shape[1:3]
+            normal_u8 = ops.align_normals_u8(normal_u8.contiguous(), depth.float().contiguous(), Hypersim.inverse_intrinsics(H0, W0).reshape(-1))
+        if transform:
+            rgb01, d, n01 = augment_hypersim(rgb_u8, depth, normal_u8, size=(480, 640), flip=flip)
+        else:
+            rgb01, d, n01 = _to_tensor(rgb_u8), depth.float()[:, None].contiguous(), _to_tensor(normal_u8)
+    else:
+        if transform:
+            rgb01, d, n01 = augment_vkitti(rgb_u8, depth, normal_u8, flip=flip)
+        else:
+            rgb01, d, n01 = _to_tensor(rgb_u8), depth.float()[:, None].contiguous(), _to_tensor(normal_u8)
+    return prepare_batch(rgb01, d, n01, dataset, near_plane, far_plane)
+
+
+def _to_tensor(u8):
+    """transforms.ToTensor() of a uint8 HWC image batch (the reference's `transform=None` branch): identity gather through the same kernel"""
+    B, H, W, _ = u8.shape
+    dev = u8.device
+    return ops.aug_gather(u8.contiguous(), _tables("crop", 0, H, dev), _tables("crop", 0, W, dev))
+
+
+class DeviceLoader:
+    """`torch.utils.data.DataLoader(dataset, shuffle=True, batch_size=B, num_workers=0)` (train.py:364-365) for Hypersim / VirtualKITTI2 above, with the
+    work split MI355X-first: indices from torch's own RandomSampler / BatchSampler (the reference's order for the same torch RNG state), the flip coin
+    per sample from Python's `random` in sample order (load.py:76,134), files decoded by `workers` threads `prefetch` batches ahead, one pinned staging
+    buffer set per in-flight batch, upload + `finish_samples` on a side stream so that both hide under the training step.  Iterating yields batch dicts
+    on `device` (the consumer's current stream waits for the batch's event)."""
+
+    def __init__(self, dataset, batch_size=1, device="cuda", shuffle=True, drop_last=False, workers=8, prefetch=2):
+        self.dataset, self.batch_size, self.device = dataset, int(batch_size), torch.device(device)
+        self.shuffle, self.drop_last, self.workers, self.prefetch = shuffle, drop_last, max(1, int(workers)), max(1, int(prefetch))
+        from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
+        self._batches = BatchSampler(RandomSampler(dataset) if shuffle else SequentialSampler(dataset), self.batch_size, drop_last)
+        self._pool = None
+        self._stream = None
+        self._lock = threading.Lock()
+
+    def __len__(self):
+        return len(self._batches)
+
+    def _stage(self, samples):
+        """stack decoded samples into pinned host buffers (one set per call: the upload is asynchronous)"""
+        pin = self.device.type == "cuda"
+        out = {}
+        for key, dt in (("rgb_u8", torch.uint8), ("depth", torch.float32), ("normal_u8", torch.uint8)):
+            first = samples[0][key]
+            buf = torch.empty((len(samples),) + tuple(first.shape), dtype=dt, pin_memory=pin)
+            for i, smp in enumerate(samples):
+                if smp[key].shape != first.shape:
+                    raise ValueError("DeviceLoader: samples of one batch differ in size (%s vs %s)" % (smp[key].shape, first.shape))
+                buf[i] = torch.from_numpy(smp[key])
+            out[key] = buf
+        return out
+
+    def _finish(self, staged, flips):
+        ds = self.dataset
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceLoader prepares batches with libe2eft kernels: it needs a HIP device (got %s)" % self.device)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(self._stream):
+            dev = {k: v.to(self.device, non_blocking=True) for k, v in staged.items()}
+            batch = finish_samples(dev["rgb_u8"], dev["depth"], dev["normal_u8"], ds.name, flip=flips if ds.transform else None,
+                                   transform=bool(ds.transform), near_plane=ds.near_plane, far_plane=ds.far_plane, align=getattr(ds, "align_cam_normal", False))
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        return batch, ev, staged
+
+    def index_batches(self):
+        """the index lists of one epoch, consuming torch's global RNG exactly as `iter(DataLoader(...))` does: the iterator first draws its `base_seed`
+        (an int64 it hands to worker processes; drawn with num_workers = 0 too), then RandomSampler draws the seed of its permutation"""
+        torch.empty((), dtype=torch.int64).random_()
+        return iter(self._batches)
+
+    def __iter__(self):
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="e2eft-decode")
+        pending = []          # [(futures of one batch, flips)]
+        it = self.index_batches()
+
+        def submit():
+            idx = next(it, None)
+            if idx is None:
+                return False
+            # the reference draws the coin inside the transform, i.e. once per sample in sample order, only when a transform exists (load.py:76,134)
+            flips = [random.random() > 0.5 for _ in idx] if self.dataset.transform else None
+            pending.append(([self._pool.submit(self.dataset.__getitem__, i) for i in idx], flips))
+            return True
+
+        for _ in range(self.prefetch):
+            if not submit():
+                break
+        ready = None          # the batch whose upload + preparation is already in flight on the side stream
+        while pending or ready is not None:
+            nxt = None
+            if pending:
+                futs, flips = pending.pop(0)
+                submit()
+                nxt = self._finish(self._stage([f.result() for f in futs]), flips)
+            if ready is not None:
+                batch, ev, staged = ready
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                for v in batch.values():
+                    if isinstance(v, torch.Tensor):
+                        v.record_stream(torch.cuda.current_stream(self.device))
+                yield batch
+                del staged
+            ready = nxt
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=False, cancel_futures=True)
+            self._pool = None

@@ -1241,6 +1241,19 @@ def prepare_sample(rgb01, depth, normal01, near, far, quantiles):
     return rgb, depth3, metric, normals, mask.bool()
 
 
+def align_normals_u8(normal_u8, depth, inv_k):
+    """Hypersim's camera-facing fix (load.py:185-204,225-232): normal_u8 uint8 [B,H,W,3], depth fp32 [B,H,W] metres, inv_k = 9 floats (row-major inverse
+    intrinsics, host) -> uint8 [B,H,W,3]"""
+    _check_cuda(normal_u8, depth)
+    assert normal_u8.dtype == torch.uint8 and normal_u8.is_contiguous() and normal_u8.dim() == 4 and normal_u8.shape[-1] == 3
+    B, H, W, _ = normal_u8.shape
+    assert depth.dtype == torch.float32 and depth.is_contiguous() and tuple(depth.shape) == (B, H, W)
+    ik = (C.c_double * 9)(*[float(v) for v in inv_k])
+    out = torch.empty_like(normal_u8)
+    check(_lib.load().e2eft_align_normals_u8(B, H, W, _ptr(normal_u8), _ptr(depth), ik, _ptr(out), _stream()))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------
 # sample augmentation (csrc/dataaug.hip) and evaluation metrics (csrc/evalmetrics.hip)
 def aug_resample_bilinear_u8(img, size, xtab, ytab, flip=None, invert_x_on_flip=False):

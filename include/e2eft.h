@@ -390,6 +390,11 @@ int e2eft_masked_quantiles(int32_t batch, int64_t n, const float* depth, float n
 int e2eft_prepare_sample(int32_t batch, int64_t hw, const float* rgb01, const float* depth, const float* normal01, float near_plane,
                          float far_plane, const float* quantiles, float* rgb, float* depth3, float* metric, float* normals,
                          uint8_t* val_mask, void* stream);
+/* Hypersim's normal-orientation fix on decoded samples (/root/reference/training/dataloaders/load.py:185-204,225-232): normal_u8 [B][h][w][3] as decoded,
+ * depth [B][h][w] metres (fp32), inv_k = the nine doubles of inv([[fx,0,cx],[0,fy,cy],[0,0,1]]) row-major (a HOST pointer, read during the call);
+ * out [B][h][w][3] uint8 = the re-quantised image the reference hands to its transforms (float64 arithmetic, truncating cast). */
+int e2eft_align_normals_u8(int32_t batch, int32_t h, int32_t w, const uint8_t* normal_u8, const float* depth, const double* inv_k, uint8_t* out,
+                           void* stream);
 /* Synchronised augmentation of decoded training samples on the device (/root/reference/training/dataloaders/load.py:67-152): horizontal flip
  * (per-image flags; `invert_x_on_flip`: first channel -> 255 - x, the normals' x component, :80-82), PIL-exact bilinear resize of uint8 HWC
  * images (torchvision.transforms.Resize on a PIL image = Image.resize: separable triangle filter, 22-bit fixed-point coefficients, uint8

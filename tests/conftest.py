@@ -18,7 +18,7 @@ def pytest_configure(config):
 # test_oracle_pins / test_host_logic / test_data_cpu / test_ensemble_cpu): /root/reference is public, untrusted content.  The files those tests run
 # were reviewed once; their sha256 is committed (tests/golden/reference_manifest.json).  If the tree on this box differs, the tests that would
 # execute it are skipped (E2EFT_TRUST_REFERENCE=1 runs them anyway, after you have looked at the diff); the golden-fixture pins still run.
-EXECUTES_REFERENCE = ("test_reference_wiring_cpu.py", "test_oracle_pins.py", "test_host_logic.py", "test_data_cpu.py", "test_ensemble_cpu.py")
+EXECUTES_REFERENCE = ("test_reference_wiring_cpu.py", "test_oracle_pins.py", "test_host_logic.py", "test_data_cpu.py", "test_ensemble_cpu.py", "test_datasets_cpu.py")
 
 
 def _reference_mismatch():
