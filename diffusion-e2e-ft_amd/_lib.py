@@ -118,6 +118,7 @@ SIGNATURES = {
     "e2eft_adamw_step": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _F, _F, _P]),
     "e2eft_adamw_step_guarded": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _F, _F, _P]),
     "e2eft_cast": (_I, [_I, _I, _L, _F, _I, _P, _P, _P]),
+    "e2eft_ema_step": (_I, [_L, _P, _P, _F, _P]),
     "e2eft_activation": (_I, [_I, _I, _L, _P, _P, _P]),
     "e2eft_masked_quantiles_workspace_bytes": (_Z, [_I]),
     "e2eft_masked_quantiles": (_I, [_I, _L, _P, _F, _F, _F, _F, _P, _P, _Z, _P]),

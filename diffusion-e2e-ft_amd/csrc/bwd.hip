@@ -557,6 +557,30 @@ extern "C" int e2eft_angular_loss_bwd(int32_t batch, int32_t hw, const float* pr
     return check_launch("angular_loss_bwd");
 }
 
+// EMA of the parameters (diffusers EMAModel.step, used by GeoWizard/geowizard/training/train_depth_normal.py:352-353,785-786): shadow -= (1 - decay) * (shadow - param),
+// torch's operation order (sub, mul, sub — no contraction), 16-byte vectors over the flat buffers: 12 B per element, HBM-bound
+__global__ __launch_bounds__(256) void ema_kernel(long n, float* __restrict__ shadow, const float* __restrict__ param, float omd) {
+#pragma clang fp contract(off)
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 s = reinterpret_cast<float4*>(shadow)[i];
+        const float4 q = reinterpret_cast<const float4*>(param)[i];
+        s.x = s.x - omd * (s.x - q.x); s.y = s.y - omd * (s.y - q.y); s.z = s.z - omd * (s.z - q.z); s.w = s.w - omd * (s.w - q.w);
+        reinterpret_cast<float4*>(shadow)[i] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        shadow[i] = shadow[i] - omd * (shadow[i] - param[i]);
+    }
+}
+
+extern "C" int e2eft_ema_step(int64_t n, float* shadow, const float* param, float one_minus_decay, void* stream) {
+    E2EFT_REQUIRE(shadow && param && n > 0 && (((uintptr_t)shadow | (uintptr_t)param) & 15) == 0, "ema_step: bad args (16-byte aligned fp32 buffers)");
+    unsigned nb = grid_for((n + 3) / 4);
+    hipLaunchKernelGGL(ema_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (long)n, shadow, param, one_minus_decay);
+    return check_launch("ema_step");
+}
+
 extern "C" int e2eft_sumsq(int64_t n, const float* g, double* out, void* stream) {
     E2EFT_REQUIRE(g && out && n > 0 && ((uintptr_t)out & 7) == 0, "sumsq: bad args");
     hipStream_t s = (hipStream_t)stream;

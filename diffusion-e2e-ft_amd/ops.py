@@ -1112,6 +1112,14 @@ def adamw_step_guarded_(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
     return param
 
 
+def ema_step_(shadow, param, one_minus_decay):
+    """shadow -= one_minus_decay * (shadow - param) over flat fp32 buffers (diffusers EMAModel.step; csrc/bwd.hip ema_kernel)"""
+    _check_cuda(shadow, param)
+    assert shadow.dtype == param.dtype == torch.float32 and shadow.is_contiguous() and param.is_contiguous() and shadow.numel() == param.numel()
+    check(_lib.load().e2eft_ema_step(shadow.numel(), _ptr(shadow), _ptr(param), float(one_minus_decay), _stream()))
+    return shadow
+
+
 def cast_(x, y, mul=1.0, accumulate=False):
     """y <- (y if accumulate else 0) + x*mul with dtype conversion; flat contiguous buffers"""
     _check_cuda(x, y)

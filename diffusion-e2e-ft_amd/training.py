@@ -468,6 +468,158 @@ class FlatAdamW(torch.optim.Optimizer):
                 p.grad = self._slot(self.flat_grad, i)
 
 
+class EMAModel:
+    """`diffusers.training_utils.EMAModel` as GeoWizard's training script uses it (GeoWizard/geowizard/training/train_depth_normal.py:352-353 construct, :785-786
+    `step` after every optimizer step, :843-850 `store` / `copy_to` / `restore` around validation, :380-381,388-391 `save_pretrained` / `from_pretrained` /
+    `load_state_dict` in the accelerate hooks).  diffusers (0.30.2, third-party) is not in the tree: the constructor arguments, `get_decay`, `step`'s update
+    `shadow -= (1 - decay) * (shadow - param)` and the `state_dict` keys are restated from its published definition (tests pin the arithmetic to that
+    formula evaluated by torch).
+
+    MI355X-first: when the parameters live in a FlatAdamW buffer (construct the optimizer first) the shadow is ONE flat fp32 buffer with the same layout and
+    `step()` is ONE `e2eft_ema_step` launch over it (12 B per parameter, HBM-bound: 10.4 GB -> ~2 ms for the SD-v2 UNet, against 686 x 3 elementwise torch launches);
+    `copy_to` / `store` / `restore` are flat device copies (the reference parks the stored copy on the host: 288 GB of HBM make that unnecessary) and bump the
+    parameter epoch so that 16-bit weight twins and packed weights are rebuilt.  `shadow_params` stays a list of per-parameter tensors (views of the flat
+    shadow).  Parameters outside a flat buffer take the per-tensor form of the same update (torch ops: host-side plumbing, as diffusers does it)."""
+
+    def __init__(self, parameters, decay=0.9999, min_decay=0.0, update_after_step=0, use_ema_warmup=False, inv_gamma=1.0, power=2 / 3, foreach=False,
+                 model_cls=None, model_config=None, **kwargs):
+        parameters = list(parameters)
+        self.decay, self.min_decay, self.update_after_step = decay, min_decay, update_after_step
+        self.use_ema_warmup, self.inv_gamma, self.power = use_ema_warmup, inv_gamma, power
+        self.optimization_step = 0
+        self.cur_decay_value = None
+        self.temp_stored_params = None
+        self.model_cls, self.model_config = model_cls, model_config
+        self._flat = self._flat_source(parameters)
+        if self._flat is not None:
+            owner, flat = self._flat
+            with ops.on_device_of(flat):
+                self._shadow_flat = flat.detach().clone()
+            self.shadow_params = [owner._slot(self._shadow_flat, i) for i in range(len(owner.params))]
+        else:
+            self._shadow_flat = None
+            self.shadow_params = [p.clone().detach() for p in parameters]
+
+    @staticmethod
+    def _flat_source(parameters):
+        """(FlatAdamW, its flat parameter buffer) when `parameters` are exactly that optimizer's parameters, in its order; else None"""
+        tags = [getattr(p, "_e2eft_gslot", None) for p in parameters]
+        if not parameters or any(t is None for t in tags):
+            return None
+        owner = tags[0][0]()
+        if owner is None or len(owner.params) != len(parameters) or any(a is not b for a, b in zip(owner.params, parameters)):
+            return None
+        if any(p.data_ptr() != owner.flat_param.data_ptr() + 4 * o for p, o in zip(parameters, owner.offsets)):
+            return None
+        return owner, owner.flat_param
+
+    def get_decay(self, optimization_step):
+        step = max(0, optimization_step - self.update_after_step - 1)
+        if step <= 0:
+            return 0.0
+        cur = 1 - (1 + step / self.inv_gamma) ** -self.power if self.use_ema_warmup else (1 + step) / (10 + step)
+        return max(min(cur, self.decay), self.min_decay)
+
+    @torch.no_grad()
+    def step(self, parameters):
+        parameters = list(parameters)
+        self.optimization_step += 1
+        decay = self.get_decay(self.optimization_step)
+        self.cur_decay_value = decay
+        omd = 1 - decay
+        src = self._flat_source(parameters) if self._shadow_flat is not None else None
+        if src is not None and src[1].numel() == self._shadow_flat.numel():
+            with ops.on_device_of(src[1]):
+                ops.ema_step_(self._shadow_flat, src[1], omd)
+            return
+        for s_param, param in zip(self.shadow_params, parameters):
+            if param.requires_grad:
+                s_param.sub_(omd * (s_param - param))
+            else:
+                s_param.copy_(param)
+
+    @torch.no_grad()
+    def copy_to(self, parameters):
+        parameters = list(parameters)
+        src = self._flat_source(parameters) if self._shadow_flat is not None else None
+        if src is not None and src[1].numel() == self._shadow_flat.numel():
+            src[1].copy_(self._shadow_flat)
+        else:
+            for s_param, param in zip(self.shadow_params, parameters):
+                param.data.copy_(s_param.to(param.device).data)
+        F.bump_param_epoch()          # (`.data.copy_` moves no version counter: derived 16-bit / packed weights are keyed on the epoch)
+
+    @torch.no_grad()
+    def store(self, parameters):
+        parameters = list(parameters)
+        src = self._flat_source(parameters) if self._shadow_flat is not None else None
+        self.temp_stored_params = src[1].detach().clone() if src is not None else [p.detach().clone() for p in parameters]
+
+    @torch.no_grad()
+    def restore(self, parameters):
+        if self.temp_stored_params is None:
+            raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
+        parameters = list(parameters)
+        if isinstance(self.temp_stored_params, torch.Tensor):
+            self._flat_source(parameters)[1].copy_(self.temp_stored_params)
+        else:
+            for c_param, param in zip(self.temp_stored_params, parameters):
+                param.data.copy_(c_param.data)
+        self.temp_stored_params = None
+        F.bump_param_epoch()
+
+    def to(self, device=None, dtype=None):
+        if self._shadow_flat is not None:
+            if device is not None and torch.device(device) != self._shadow_flat.device or dtype not in (None, torch.float32):
+                raise ValueError("EMAModel over a FlatAdamW buffer lives where the buffer lives (fp32 on %s)" % self._shadow_flat.device)
+            return
+        self.shadow_params = [p.to(device=device, dtype=dtype) if p.is_floating_point() else p.to(device=device) for p in self.shadow_params]
+
+    def state_dict(self):
+        return {"decay": self.decay, "min_decay": self.min_decay, "optimization_step": self.optimization_step, "update_after_step": self.update_after_step,
+                "use_ema_warmup": self.use_ema_warmup, "inv_gamma": self.inv_gamma, "power": self.power, "shadow_params": self.shadow_params}
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        for k in ("decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma", "power"):
+            setattr(self, k, state_dict.get(k, getattr(self, k)))
+        if not 0.0 <= self.decay <= 1.0:
+            raise ValueError("Decay must be between 0 and 1")
+        sp = state_dict.get("shadow_params", None)
+        if sp is not None:
+            if len(sp) != len(self.shadow_params) or not all(isinstance(t, torch.Tensor) for t in sp):
+                raise ValueError("shadow_params must be a list of %d tensors" % len(self.shadow_params))
+            for mine, theirs in zip(self.shadow_params, sp):
+                mine.copy_(theirs)
+
+    def save_pretrained(self, path):
+        """the EMA weights as a model checkpoint whose config carries the EMA hyper-parameters (diffusers' layout: `unet_ema/`)"""
+        if self.model_cls is None or self.model_config is None:
+            raise ValueError("`save_pretrained` can only be used if `model_cls` and `model_config` were defined at __init__.")
+        model = self.model_cls(**{k: v for k, v in dict(self.model_config).items() if not k.startswith("_")})
+        sd = self.state_dict()
+        sd.pop("shadow_params")
+        model.register_to_config(**sd)
+        with torch.no_grad():
+            for s_param, param in zip(self.shadow_params, model.parameters()):
+                param.copy_(s_param.to(param.device))
+        model.save_pretrained(path)
+
+    @classmethod
+    def from_pretrained(cls, path, model_cls):
+        """diffusers: `model_cls.load_config(path, return_unused_kwargs=True)` splits the EMA hyper-parameters off the model config; here the model loader
+        ignores keys it does not know, and the EMA keys are read from the same config.json"""
+        import json
+        import os
+        with open(os.path.join(path, model_cls.config_name)) as f:
+            raw = json.load(f)
+        ema_kwargs = {k: raw[k] for k in ("decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma", "power") if k in raw}
+        model = model_cls.from_pretrained(path)
+        ema = cls(model.parameters(), model_cls=model_cls, model_config=model.config)
+        ema.load_state_dict(ema_kwargs)
+        return ema
+
+
 def train_step(unet, vae, optimizer, batches, empty_encoding, modality="depth", lr_scale=1.0):
     """One optimizer step over `batches` (a list of micro-batches = gradient accumulation, train.py:470,559-566): returns the
     mean micro-loss as a device tensor."""

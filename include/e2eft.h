@@ -477,6 +477,9 @@ int e2eft_adamw_step_guarded(int64_t n, float* param, const float* grad, float* 
                              float grad_scale, float max_norm, void* stream);
 /* y = (accumulate ? y : 0) + x * mul with dtype conversion (fp32 master weights -> 16-bit compute copies, 16-bit gradients
  * accumulated into the fp32 flat gradient buffer) */
+/* Exponential moving average of the parameters (diffusers `EMAModel.step`; GeoWizard/geowizard/training/train_depth_normal.py:352-353,785-786):
+ * shadow[i] -= one_minus_decay * (shadow[i] - param[i]) in torch's operation order; both buffers fp32, 16-byte aligned (the flat buffers of FlatAdamW). */
+int e2eft_ema_step(int64_t n, float* shadow, const float* param, float one_minus_decay, void* stream);
 int e2eft_cast(int32_t dt_in, int32_t dt_out, int64_t n, float mul, int32_t accumulate, const void* x, void* y, void* stream);
 
 #pragma GCC visibility pop

@@ -474,3 +474,61 @@ def test_flat_adamw_keeps_convolution_weights_in_kernel_order():
     assert all(torch.equal(opt.state[p]["exp_avg"], k) for p, k in zip(opt.params, keep))
     assert opt.state[w0]["exp_avg"].data_ptr() == opt.exp_avg.data_ptr() + 4 * o0
     assert torch.equal(net.state_dict()["0.weight"], ref[0].detach())
+
+
+def test_ema_model_follows_the_diffusers_definition_and_round_trips(tmp_path):
+    """training.EMAModel = diffusers.training_utils.EMAModel as GeoWizard's training script drives it (train_depth_normal.py:352-353,380-391,785-786,843-850;
+    diffusers itself is not in the tree: the decay schedule and the update are its published formulas, evaluated here independently).  Per-tensor path (no
+    flat buffer, CPU); the flat-buffer path is tests/test_train_gpu.py::test_ema_on_the_flat_buffer."""
+    from oracle import config
+    from diffusion_e2e_ft_amd.training import EMAModel
+    from diffusion_e2e_ft_amd.unet import UNet2DConditionModel
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 2))
+    net[1].bias.requires_grad_(False)
+    ema = EMAModel(net.parameters(), decay=0.9, update_after_step=1)
+    ref = [p.detach().clone() for p in net.parameters()]
+    for it in range(1, 9):
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.1 * torch.randn_like(p))
+        ema.step(net.parameters())
+        step = max(0, it - 1 - 1)
+        decay = 0.0 if step <= 0 else max(min((1 + step) / (10 + step), 0.9), 0.0)
+        assert ema.cur_decay_value == decay and ema.optimization_step == it
+        for r, p in zip(ref, net.parameters()):
+            if p.requires_grad:
+                r.sub_((1 - decay) * (r - p.detach()))
+            else:
+                r.copy_(p.detach())
+        assert all(torch.equal(a, b) for a, b in zip(ema.shadow_params, ref))
+    w = EMAModel(net.parameters(), use_ema_warmup=True, inv_gamma=2.0, power=0.75, decay=0.9999)
+    assert abs(w.get_decay(12) - (1 - (1 + 11 / 2.0) ** -0.75)) < 1e-15 and w.get_decay(1) == 0.0
+    # store / copy_to / restore around validation
+    live = [p.detach().clone() for p in net.parameters()]
+    ema.store(net.parameters())
+    ema.copy_to(net.parameters())
+    assert all(torch.equal(p, s_) for p, s_ in zip(net.parameters(), ema.shadow_params))
+    ema.restore(net.parameters())
+    assert all(torch.equal(p, q) for p, q in zip(net.parameters(), live)) and ema.temp_stored_params is None
+    with pytest.raises(RuntimeError):
+        ema.restore(net.parameters())
+    sd = ema.state_dict()
+    assert sorted(sd) == sorted(["decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma", "power", "shadow_params"])
+    other = EMAModel(net.parameters())
+    other.load_state_dict(sd)
+    assert other.optimization_step == 8 and other.decay == 0.9 and all(torch.equal(a, b) for a, b in zip(other.shadow_params, ema.shadow_params))
+    # save_pretrained / from_pretrained: a model checkpoint whose config carries the EMA state (the accelerate hooks of train_depth_normal.py:380-391)
+    unet = UNet2DConditionModel(**config.TINY_UNET)
+    e2 = EMAModel(unet.parameters(), decay=0.95, model_cls=UNet2DConditionModel, model_config=unet.config)
+    with torch.no_grad():
+        for p in unet.parameters():
+            p.mul_(1.5)
+    for _ in range(3):
+        e2.step(unet.parameters())
+    e2.save_pretrained(str(tmp_path / "unet_ema"))
+    back = EMAModel.from_pretrained(str(tmp_path / "unet_ema"), UNet2DConditionModel)
+    assert back.optimization_step == 3 and back.decay == 0.95 and len(back.shadow_params) == len(e2.shadow_params)
+    assert all(torch.equal(a, b) for a, b in zip(back.shadow_params, e2.shadow_params))
+    with pytest.raises(ValueError):
+        EMAModel(net.parameters()).save_pretrained(str(tmp_path / "x"))

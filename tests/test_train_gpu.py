@@ -455,6 +455,58 @@ def test_bf16_twin_follows_in_place_parameter_writes(dev):
     assert torch.equal(F._vec(conv.bias, bf), conv.bias.detach().to(bf))
 
 
+def test_ema_on_the_flat_buffer(dev):
+    """training.EMAModel over FlatAdamW's parameters (GeoWizard's `--use_ema`, train_depth_normal.py:352-353,785-786,843-850): the shadow is one flat buffer,
+    `step()` one e2eft_ema_step launch — bit-equal to diffusers' per-tensor update `s -= (1 - decay) * (s - p)` evaluated by torch on clones; `copy_to` puts the
+    averaged weights under the model INCLUDING its bf16 twin (a forward equals a fresh model holding the shadow weights), `restore` brings the live ones back."""
+    from diffusion_e2e_ft_amd import training
+    batch, text = gc.train_batch()
+    bf = torch.bfloat16
+    unet, vae = _models(dev)
+    unet.set_compute_dtype(bf)
+    vae = vae.to(bf)
+    opt = training.FlatAdamW(unet.parameters(), lr=1e-3, max_grad_norm=1.0)
+    ema = training.EMAModel(unet.parameters(), decay=0.8, model_cls=type(unet), model_config=unet.config)
+    assert ema._shadow_flat is not None and ema._shadow_flat.numel() == opt.flat_param.numel()
+    assert all(s_.shape == p.shape and s_.stride() == p.stride() for s_, p in zip(ema.shadow_params, unet.parameters()))
+    ref = [p.detach().clone() for p in unet.parameters()]
+    for it in range(1, 5):
+        loss = training.e2e_ft_loss(unet, vae, batch, text, "depth")
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        ema.step(unet.parameters())
+        step = max(0, it - 1)
+        decay = 0.0 if step <= 0 else min((1 + step) / (10 + step), 0.8)
+        assert ema.cur_decay_value == decay
+        for r, p in zip(ref, unet.parameters()):
+            r.sub_((1 - decay) * (r - p.detach()))
+        torch.cuda.synchronize()
+        bad = [i for i, (a, b) in enumerate(zip(ema.shadow_params, ref)) if not torch.equal(a, b)]
+        assert not bad, (it, bad[:5])
+    with torch.no_grad():
+        live_loss = training.e2e_ft_loss(unet, vae, batch, text, "depth").item()
+    live = opt.flat_param.detach().clone()
+    ema.store(unet.parameters())
+    ema.copy_to(unet.parameters())
+    assert torch.equal(opt.flat_param, ema._shadow_flat)
+    with torch.no_grad():
+        ema_loss = training.e2e_ft_loss(unet, vae, batch, text, "depth").item()
+    fresh, _ = _models(dev)
+    with torch.no_grad():
+        for p, s_ in zip(fresh.parameters(), ema.shadow_params):
+            p.copy_(s_)
+    fresh.set_compute_dtype(bf)
+    training.FlatAdamW(fresh.parameters(), lr=1e-3)       # the same weight layout (OHWI twin) as the model under test
+    with torch.no_grad():
+        want = training.e2e_ft_loss(fresh, vae, batch, text, "depth").item()
+    assert ema_loss == want and ema_loss != live_loss, (live_loss, ema_loss, want)
+    ema.restore(unet.parameters())
+    assert torch.equal(opt.flat_param, live)
+    with torch.no_grad():
+        assert training.e2e_ft_loss(unet, vae, batch, text, "depth").item() == live_loss
+
+
 @pytest.mark.parametrize("cdt,ckpt", [(torch.bfloat16, False), (torch.float32, False), (torch.bfloat16, True)], ids=["bf16", "fp32", "bf16_recompute"])
 def test_gradients_are_born_in_the_flat_buffer_and_steps_are_bit_equal(dev, cdt, ckpt):
     """FlatAdamW(direct_grads=True) (round 4): after zero_grad() every .grad is None, the backward kernels' reductions write each parameter's first gradient of
