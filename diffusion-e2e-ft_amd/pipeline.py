@@ -220,6 +220,24 @@ class MarigoldPipeline:
 
     @ops.device_scoped
     @torch.no_grad()
+    def predict_latent(self, rgb_in):
+        """the predicted x0 LATENT of the one-step zero-latent path ([B,4,h/8,w/8], logical NCHW): encode -> UNet at the scheduler's first timestep -> x0, i.e.
+        `single_infer` without the decoder — the quantity BASELINE.json states parity on ("within 1e-3 relative fp32 on the depth/normal latent")"""
+        device, dt = self.device, self.dtype
+        rgb_in = rgb_in.to(device=device, dtype=dt)
+        self.scheduler.set_timesteps(1, device=device)
+        if self.empty_text_embed is None:
+            self.encode_empty_text()
+        sb = -self.scheduler.zero_latent_x0_scale(self.scheduler.timesteps_host[0])
+        rgb_latent = self.encode_rgb(rgb_in)
+        B, C, h, w = rgb_latent.shape
+        xin = torch.zeros((B, h, w, 2 * C), dtype=dt, device=device)
+        ops.copy_scale(rgb_latent.permute(0, 2, 3, 1), xin[..., :C])
+        v = self.unet(to_nchw_view(xin), self.scheduler.timesteps[:1], encoder_hidden_states=self.empty_text_embed.to(device=device, dtype=dt).repeat(B, 1, 1)).sample
+        return _scaled(v, -sb)
+
+    @ops.device_scoped
+    @torch.no_grad()
     def stage_times_ms(self, rgb_in, normals=False, repeats=3):
         """{"vae_encode", "unet", "vae_decode"}: mean milliseconds per batch of the three stages of the E2E-FT path (HIP events on the
         launch stream; SURVEY.md §8(d) asks for the UNet-only rate next to the full path)."""

@@ -71,9 +71,10 @@ def test_config1_batch8_768_fp16_every_image_against_oracle(dev, marigold_fp16, 
     with torch.no_grad():
         depth = pipe.single_infer(rgb, 1, False, noise="zeros", normals=False).float().cpu()
         normal = pipe.single_infer(rgb, 1, False, noise="zeros", normals=True).float().cpu()
+        latent = pipe.predict_latent(rgb).float().cpu()        # the quantity the north star states parity on, in the precision that is benchmarked
     torch.cuda.synchronize()
-    assert depth.shape == (8, 1, 768, 768) and normal.shape == (8, 3, 768, 768)
-    worst = dict(e=0.0, mae=0.0, ang=0.0)
+    assert depth.shape == (8, 1, 768, 768) and normal.shape == (8, 3, 768, 768) and latent.shape == (8, 4, 96, 96)
+    worst = dict(e=0.0, mae=0.0, ang=0.0, lat=0.0, lat2=0.0)
     for i in range(8):
         with torch.no_grad():
             want_d, x0 = pipeline_ref.single_infer_ref(usd, config.SD2_UNET, vsd, config.SD_VAE, rgb[i:i + 1], ctx, return_latent=True)
@@ -84,11 +85,17 @@ def test_config1_batch8_768_fp16_every_image_against_oracle(dev, marigold_fp16, 
                 ang = _mean_angle(normal[i:i + 1], want_n)
         e = rel_err(depth[i:i + 1], want_d)
         mae = (depth[i:i + 1] - want_d).abs().mean().item()
-        print("configs[1] batch 8, image %d: depth max rel err %.3e, mean abs err %.3e; normals mean angle %.3f deg" % (i, e, mae, ang))
+        # fp16 drift where the north star defines parity: x0 latent against the fp32 oracle's, max-abs / max-ref and relative L2.
+        # The fp32 product meets 1e-3 on this quantity (test_fullsize_parity_gpu.py: 5e-6 measured); fp16 storage with fp32 accumulation is a STATED looser bar.
+        lat = rel_err(latent[i:i + 1], x0)
+        lat2 = ((latent[i:i + 1] - x0).norm() / x0.norm()).item()
+        print("configs[1] batch 8, image %d: x0 latent max rel err %.3e, rel L2 %.3e; depth max rel err %.3e, mean abs err %.3e; normals mean angle %.3f deg" % (i, lat, lat2, e, mae, ang))
         assert e <= 2e-2 and mae <= 2e-3, (i, e, mae)
         assert ang <= 1.0, (i, ang)
-        worst = dict(e=max(worst["e"], e), mae=max(worst["mae"], mae), ang=max(worst["ang"], ang))
-    print("configs[1] batch 8 worst image: depth max rel err %.3e, mean abs err %.3e, normals mean angle %.3f deg" % (worst["e"], worst["mae"], worst["ang"]))
+        assert lat <= 3e-2 and lat2 <= 1.5e-2, (i, lat, lat2)
+        worst = dict(e=max(worst["e"], e), mae=max(worst["mae"], mae), ang=max(worst["ang"], ang), lat=max(worst["lat"], lat), lat2=max(worst["lat2"], lat2))
+    print("configs[1] batch 8 worst image: x0 latent max rel err %.3e (rel L2 %.3e), depth max rel err %.3e, mean abs err %.3e, normals mean angle %.3f deg"
+          % (worst["lat"], worst["lat2"], worst["e"], worst["mae"], worst["ang"]))
 
 
 # ---- (ii) the tensors of that batch that cross 2^31 bytes ---------------------------------------------------------------------
