@@ -43,7 +43,7 @@ class AttnDesc(C.Structure):
 
 
 # e2eft_set_option keys (include/e2eft.h)
-OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV, OPT_THIN_INPUT_CONV, OPT_FUSED_NORM, OPT_ATTN_DMA = range(10)
+OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV, OPT_THIN_INPUT_CONV, OPT_FUSED_NORM, OPT_ATTN_DMA, OPT_UPCONV_PHASES = range(11)
 
 _P = C.c_void_p
 _I = C.c_int32
@@ -68,6 +68,8 @@ SIGNATURES = {
     "e2eft_groupnorm_coeff_offset": (_Z, [C.POINTER(GroupNormDesc)]),
     "e2eft_groupnorm_fwd_stats": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _I, _P, _I, _P, _Z, _P]),
     "e2eft_conv2d_fwd_normed_supported": (_I, [C.POINTER(ConvDesc)]),
+    "e2eft_upconv2x_fwd_supported": (_I, [C.POINTER(ConvDesc)]),
+    "e2eft_upconv2x_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int32), _P]),
     "e2eft_conv2d_fwd_normed": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int32), _P]),
     "e2eft_groupnorm_workspace_bytes": (_Z, [C.POINTER(GroupNormDesc)]),
     "e2eft_groupnorm_fwd": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _Z, _P]),
@@ -171,7 +173,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.e2eft_version() < 118:
+    if lib.e2eft_version() < 119:
         raise RuntimeError("libe2eft.so is stale (version %d)" % lib.e2eft_version())
     if default and os.path.isdir(_build.CSRC) and lib.e2eft_build_id().decode() != _build.source_id():
         raise RuntimeError("libe2eft.so carries build id %s, the sources next to it hash to %s: rebuild (python -m diffusion_e2e_ft_amd.build --force)"

@@ -103,6 +103,27 @@ def _is_ohwi(w):
     return w.dim() == 4 and w.stride() == (kh * kw * Ci, 1, kw * Ci, Ci)
 
 
+def phase_conv_weight(conv, dtype):
+    """[4, Co, 2 * 2 * Ci] weights of the four parity phases of `nearest-2x upsample -> conv 3x3 / pad 1` (include/e2eft.h, e2eft_upconv2x_fwd): phase (py, px),
+    source offset (i, j) collects the 3x3 taps that land on that source pixel — rows R(0) = ({0}, {1, 2}), R(1) = ({0, 1}, {2}), columns alike.  Summed in fp32
+    from the master weights, rounded once to `dtype`; cached per parameter version like the packed weights."""
+    w = conv.weight
+
+    def build():
+        w32 = w.detach().to(torch.float64 if w.dtype == torch.float64 else torch.float32)      # [Co, Ci, 3, 3]
+        R = (((0,), (1, 2)), ((0, 1), (2,)))
+        out = torch.empty((4, w32.shape[0], 2, 2, w32.shape[1]), dtype=w32.dtype, device=w32.device)
+        for py in range(2):
+            for px in range(2):
+                for i in range(2):
+                    rows = sum(w32[:, :, ky, :] for ky in R[py][i])                      # [Co, Ci, 3]
+                    for j in range(2):
+                        out[2 * py + px, :, i, j, :] = sum(rows[:, :, kx] for kx in R[px][j])
+        return out.reshape(4, w32.shape[0], 4 * w32.shape[1]).to(dtype).contiguous()
+
+    return cached(conv, "wphase_%s" % dtype, (w,), build)
+
+
 GRAD_SINK_ENABLED = True      # tests / A-B: False hands every parameter gradient to autograd as a fresh tensor (AccumulateGrad then adds it into the flat buffer)
 
 
@@ -246,7 +267,8 @@ class _Conv2dFn(torch.autograd.Function):
         cout = weight.shape[0]
         xp = ops.pad_channels(x) if x2 is None else x     # 3/4-channel inputs: zero padded copy (weights are packed to match)
         out = ops.conv2d(xp, packed_conv_weight(conv, dt), _vec(bias, dt), cout, kh, kw, stride, pad, x2=x2, up_to=up_to,
-                         rowadd=rowadd, residual=residual, alpha=alpha, gn_stats=gn_stats)
+                         rowadd=rowadd, residual=residual, alpha=alpha, gn_stats=gn_stats,
+                         w_phase=(lambda: phase_conv_weight(conv, dt)) if (up_to is not None and (kh, kw) == (3, 3)) else None)
         _stash_stats(out)
         ctx.save_for_backward(xp, x2, weight, bias)
         ctx.conv, ctx.geom = conv, (stride, pad, up_to, alpha, x.shape[3])
@@ -341,7 +363,8 @@ def conv(conv_mod, x, x2=None, up_to=None, rowadd=None, residual=None, alpha=1.0
         x = ops.pad_channels(x)
     nrm = None if norm is None else (_vec(norm[0].weight, dt), _vec(norm[0].bias, dt), norm[0].num_groups, norm[0].eps, norm[1])
     return ops.conv2d(x, packed_conv_weight(conv_mod, dt), _vec(conv_mod.bias, dt), conv_mod.weight.shape[0], kh, kw, stride, pad, x2=x2,
-                      up_to=up_to, rowadd=rowadd, residual=residual, alpha=alpha, gn_stats=gn_stats, norm=nrm)
+                      up_to=up_to, rowadd=rowadd, residual=residual, alpha=alpha, gn_stats=gn_stats, norm=nrm,
+                      w_phase=(lambda: phase_conv_weight(conv_mod, dt)) if (up_to is not None and (kh, kw) == (3, 3)) else None)
 
 
 # ------------------------------------------------------------------------------------------------------------

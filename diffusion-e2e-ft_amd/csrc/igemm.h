@@ -45,6 +45,11 @@ struct IgemmParams {
     const float* nrm_ad; // optional (igemm6 only): the A operand is read through GroupNorm(+SiLU): [image][cin][2] fp32 (a, mean) pairs of e2eft_groupnorm_fwd_stats ...
     const void* nrm_beta; // ... and the norm's beta [cin] (or null): value = (x - mean) * a + beta, then SiLU if nrm_silu
     int nrm_silu;
+    int out_seg;         // > 0 (igemm5 only, e2eft_upconv2x_fwd): the output rows are laid out in SEGMENTS of out_seg consecutive GEMM rows, segment g starting
+                         // 2 * out_seg pixel rows (of ldo elements) after segment g - 1: output row of GEMM row m = m + (m / out_seg) * out_seg.  That is one
+                         // parity phase of a 2x-upsampled image: GEMM rows = low-resolution pixels (b, Y, X), out_seg = W, ldo = 2 * (pixel stride of the full
+                         // image), so consecutive X land on every other pixel and consecutive Y on every other row.  Multiple of 16.
+    int gn_islabs;       // > 0: statistics slabs per image in gn_partial (the image stride), when it differs from gn_nslabs (four phases share one buffer)
     int debug_flags;     // instrumented build (-DE2EFT_STAMPS) only: bit 0 / 1 / 2 = the persistent kernel issues its A-operand LDS-DMA never / on the
                          // first tap of a filter row only / on the first tap of a 64-channel chunk only (WRONG results; the price of operand
                          // delivery, scripts/experiments/README: "what an A-reuse scheme could buy at most")

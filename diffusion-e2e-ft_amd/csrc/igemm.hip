@@ -241,6 +241,73 @@ static int conv2d_core(const E2eftConvDesc* d, const void* x1, const void* x2, c
 }
 
 
+// ---- nearest-2x upsample + 3x3 / stride-1 / pad-1 convolution as FOUR 2x2 convolutions of the low-resolution input -------------------------------------
+// (diffusers Upsample2D: F.interpolate(scale_factor=2, mode="nearest") then conv; unet_2d_blocks.py via the reference's upsamplers, the VAE decoder's UpDecoderBlock2D.)
+// Output pixel (2Y + py, 2X + px) reads the upsampled rows 2Y + py - 1 .. 2Y + py + 1, i.e. the SOURCE rows {Y - 1, Y, Y} (py = 0) or {Y, Y, Y + 1} (py = 1): two distinct
+// rows, the 3x3 taps that fall on the same source pixel can be added up front.  Per parity phase (py, px) the layer is a 2x2 convolution (pad_t = 1 - py, pad_l = 1 - px)
+// with weights w_phase[2 py + px][co][(i, j, ci)] = sum of the 3x3 taps that map to source offset (i, j) — 4/9 of the multiply-adds of the fused-upsample form, same
+// zero padding (the upsampled image's border IS the source's border).  The phases write interleaved pixels of the full-resolution output: IgemmParams.out_seg.
+static bool upconv2x_shape_ok(const E2eftConvDesc* d) {
+    return d && (d->dtype == E2EFT_F16 || d->dtype == E2EFT_BF16) && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->c2 == 0 &&
+           d->hl == 2 * d->hin && d->wl == 2 * d->win && d->hout == d->hl && d->wout == d->wl && d->batch > 0 && d->hin > 0 && d->c1 > 0 && d->c1 % 64 == 0 &&
+           d->win % 16 == 0 && d->cout % 8 == 0 && ((long)d->batch * d->hin * d->win) % 256 == 0 && ((long)d->hin * d->win) % 256 == 0 && d->ldo % 8 == 0 && d->alpha == 1.0f;
+}
+
+namespace e2eft { int device_cus(); }   // api.hip
+extern "C" int e2eft_upconv2x_fwd_supported(const E2eftConvDesc* d) {
+    if (!upconv2x_shape_ok(d) || !option(E2EFT_OPT_UPCONV_PHASES) || !option(E2EFT_OPT_PERSISTENT)) return 0;
+    int cus = device_cus();
+    const int gopt = option(E2EFT_OPT_PERSISTENT_GRID);
+    if (gopt >= 8 && gopt < cus) cus = gopt;
+    if (cus <= 0) return 0;
+    const long tiles = ((long)d->batch * d->hin * d->win / 256) * cdiv(d->cout, 128);
+    const long img_bytes = (long)d->hin * d->win * d->ldx1 * 2;
+    return tiles >= 2L * cus && img_bytes * 3 < 0xD0000000L && (long)128 * 4 * d->c1 * 2 < 0x40000000L ? 1 : 0;
+}
+
+extern "C" int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const void* w_phase, const void* bias, void* out, float* gn_partial,
+                                  size_t gn_partial_bytes, int32_t* slab_rows, void* stream) {
+    if (slab_rows) *slab_rows = 0;
+    E2EFT_REQUIRE(d && x && w_phase && out, "upconv2x: null pointer");
+    if (!e2eft_upconv2x_fwd_supported(d)) return fail(E2EFT_ERR_UNSUPPORTED, "upconv2x: this launch is not eligible (ask e2eft_upconv2x_fwd_supported; e2eft_conv2d_fwd serves it)");
+    E2EFT_REQUIRE(al16(x) && al16(w_phase) && al16(out) && (!bias || al16(bias)), "upconv2x: pointers must be 16-byte aligned");
+    const int rows_img = d->hin * d->win;                    // GEMM rows of one image in ONE phase
+    const int slabs = rows_img / 256;
+    if (gn_partial && slab_rows) {
+        const size_t need = (size_t)d->batch * (size_t)cdiv(4 * rows_img, 128) * (size_t)d->cout * 3 * sizeof(float);
+        if (gn_partial_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "upconv2x: gn_partial %zu < %zu bytes", gn_partial_bytes, need);
+    }
+    const size_t es = dtype_size(d->dtype);
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        IgemmParams p = {};
+        p.x1 = x; p.w = (const char*)w_phase + (size_t)ph * d->cout * 4 * d->c1 * es; p.bias = bias;
+        p.out = (char*)out + ((size_t)py * d->wl + px) * d->ldo * es;
+        p.M = d->batch * rows_img; p.N = d->cout; p.K = 4 * d->c1;
+        p.ldx1 = d->ldx1; p.c1 = d->c1; p.cin = d->c1;
+        p.hin = d->hin; p.win = d->win; p.hl = d->hin; p.wl = d->win;
+        p.kh = 2; p.kw = 2; p.stride = 1; p.pad_t = 1 - py; p.pad_l = 1 - px;
+        p.hout = d->hin; p.wout = d->win;
+        p.up_sh = p.up_sw = 1.f;
+        p.ldw = 4 * d->c1; p.ldo = 2 * d->ldo;
+        p.out_seg = d->win;
+        p.rows_per_img = rows_img;
+        p.alpha = 1.f;
+        p.nzi = 1;
+        if (gn_partial && slab_rows) {       // the four phases deposit into disjoint slab ranges of one [image][4 * slabs][cout][3] buffer
+            p.gn_partial = gn_partial + (size_t)ph * slabs * d->cout * 3;
+            p.gn_islabs = 4 * slabs;
+        }
+        p.mtiles = p.M / 256; p.ntiles = cdiv(p.N, 128);
+        const int rc = launch_igemm_persistent(d->dtype, 1, p, 1, (hipStream_t)stream);
+        if (rc < 0) return fail(E2EFT_ERR_UNSUPPORTED, "upconv2x: the persistent kernel declined phase %d", ph);
+        if (rc) return rc;
+    }
+    if (gn_partial && slab_rows) *slab_rows = 256;
+    return E2EFT_OK;
+}
+
+
 // Data gradient of the convolution `fwd` describes (forward: out = alpha*(conv(x) + ...) + residual):
 //   dx[b, i, j, ci] = alpha * sum_{ky,kx,co} dy_z[b, i + pad_t - ky, j + pad_l - kx, co] * w[co][ky][kx][ci]
 // i.e. a stride-1 convolution of dy (read through a zero-insertion grid when fwd->stride > 1) with the spatially flipped,

@@ -319,6 +319,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     T col_bias[2], col_ra[2];                          // packed epilogue (no residual): bias / rowadd of the two COLUMNS this lane owns in the accumulator layout
     long c_orow = 0, c_rrow = 0;                       // element offsets of this lane's first output / residual row in the MFMA-side tile
     int c_m0 = 0, c_n0 = 0, c_img = 0, c_ncl = 0;
+    int c_mb = 0, c_seg0 = 0;                          // first GEMM row of this wave's 64-row block and (p.out_seg > 0) the output segment it starts in
     bool c_colok = false;
 
     // one k-tile.  KIND 0: steady state; 1: the loader has issued every k-tile of the current tile — at the top the epilogue's first
@@ -342,7 +343,9 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         c_ncl = c_colok ? c_n0 + wn * 64 + ec * 8 : c_n0;
         c_img = has_ra ? fast_div5(c_m0, p.rows_per_img) : 0;
         const int m = c_m0 + wm * 64 + er;          // slice s adds 8 * s rows
-        c_orow = (long)m * p.ldo + c_ncl;
+        c_mb = c_m0 + wm * 64;
+        c_seg0 = p.out_seg > 0 ? fast_div5(c_mb, p.out_seg) : 0;      // (segmented output: er < 8 <= out_seg / 2 keeps row `er` in the block's first segment)
+        c_orow = ((long)m + (long)c_seg0 * p.out_seg) * p.ldo + c_ncl;
         c_rrow = zoff_r + (long)m * p.ldr + c_ncl;
         nxt = u_dma + nslots < cend;
         if (nxt) tile_coords(u_dma + nslots);
@@ -432,7 +435,12 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     };
 
     // ---- epilogues and statistics merge: shared with igemm6.hip (rows of a wave's block are consecutive GEMM rows here)
-    auto epi_rofs = [&](const int r) -> long { return (long)r; };
+    // p.out_seg > 0 (e2eft_upconv2x_fwd): row r (a multiple of 8; of 16 in the packed epilogue, out_seg is a multiple of 16) of the block may lie in a later output
+    // segment than row 0 — every segment passed adds out_seg pixel rows (wave-uniform: one float-reciprocal division per slice)
+    auto epi_rofs = [&](const int r) -> long {
+        if (p.out_seg <= 0) return (long)r;
+        return (long)r + (long)(fast_div5(c_mb + r, p.out_seg) - c_seg0) * p.out_seg;
+    };
     constexpr int EPI_DEP = RING;
 #define EPI_STAMP(i) STAMP5(tseq, i)
 #include "igemm_persistent_epilogue.inc"
@@ -498,6 +506,7 @@ int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStre
     if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return -1;
     if (p.rowadd && ((((uintptr_t)p.rowadd) & 15) != 0 || (p.rows_per_img % BM != 0 && p.rows_per_img < p.M))) return -1;
     if (nz > 1 && (p.so_o % 8 != 0 || p.so_i % 8 != 0 || p.sr_o % 8 != 0 || p.sr_i % 8 != 0)) return -1;
+    if (p.out_seg != 0 && (p.out_seg < 16 || p.out_seg % 16 != 0 || nz != 1 || p.residual || p.M % p.out_seg != 0)) return -1;
     if (mode == 0) {
         if ((long)256 * p.ldx1 * 2 >= 0x40000000L || (long)128 * p.ldw * 2 >= 0x40000000L) return -1;
     } else {

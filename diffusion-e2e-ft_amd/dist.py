@@ -54,3 +54,16 @@ def sum_over_ranks(value, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_mean(loss, repeat=1, group=None):
+    """`accelerator.gather(loss.repeat(train_batch_size)).mean()` (training/train.py:559, GeoWizard train_depth_normal.py:772): the logging value of a
+    micro-step = the mean over ranks of each rank's scalar loss (the repeat only weights every rank by its batch size, equal on all ranks).  One all-gather of
+    `repeat` floats per rank; returns a 0-d tensor on the loss's device WITHOUT synchronising the host (the reference calls `.item()` on it every micro-step;
+    accumulate on the device and read back when you log)."""
+    t = loss.detach().reshape(1).repeat(int(repeat)).contiguous()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t.mean()
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return torch.cat(out).mean()

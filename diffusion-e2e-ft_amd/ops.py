@@ -229,6 +229,9 @@ GN_STATS_ENABLED = True   # tests flip this to cross-check the fused statistics 
 SPLITK_ENABLED = True     # tests flip this to cross-check split-K convolutions against the single-pass kernel
 
 
+UPCONV_PHASES_ENABLED = True     # tests / A-B: False keeps 2x-upsample convolutions on the fused-upsample 3x3 form
+
+
 def _gn_buffer(images, rows_per_image, cout, device):
     nbytes = images * ((rows_per_image + 127) // 128) * cout * 12
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device), nbytes
@@ -243,7 +246,7 @@ def _attach_stats(out, buf, slab_rows, images, rows_per_image, cout):
 
 # ---------------------------------------------------------------------------------------------------------
 def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None, up_to=None, rowadd=None,
-           residual=None, alpha=1.0, out=None, gn_stats=False, norm=None):
+           residual=None, alpha=1.0, out=None, gn_stats=False, norm=None, w_phase=None):
     """Implicit-GEMM convolution. x: [B,H,W,C1] (C1 % epc == 0), x2: optional [B,H,W,C2] fused channel concat,
     w_packed: [cout, ldw] rows = (ky,kx,c) K-contiguous, pad = (top, bottom, left, right), up_to=(hl,wl) fused
     nearest upsample, rowadd: [B,cout] per-image vector added before alpha, residual: [B,hout,wout,cout].
@@ -281,6 +284,21 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
     if rowadd is not None:
         assert rowadd.dtype == x.dtype and tuple(rowadd.shape) == (B, cout) and rowadd.is_contiguous()
     want = gn_stats and GN_STATS_ENABLED and cout % 8 == 0
+    if (w_phase is not None and UPCONV_PHASES_ENABLED and up_to is not None and x2 is None and rowadd is None and residual is None and norm is None and alpha == 1.0
+            and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1) and (hl, wl) == (2 * H, 2 * W) and x.dtype != torch.float32
+            and _lib.load().e2eft_upconv2x_fwd_supported(C.byref(d)) == 1):
+        wp = w_phase()
+        assert tuple(wp.shape) == (4, cout, 4 * c1) and wp.is_contiguous() and wp.dtype == x.dtype, (wp.shape, wp.dtype)
+        if bias is not None:
+            assert bias.dtype == x.dtype and bias.numel() == cout and bias.is_contiguous()
+        nbp = (B * H * W * c1 + B * hout * wout * cout + 4 * cout * 4 * c1) * x.element_size()
+        with _timed("igemm", 2.0 * B * H * W * 4 * cout * 4 * c1, nbp, label="upconv2x(4 phases) B%d %dx%d %d->%d" % (B, hout, wout, c1, cout)):
+            buf, nbytes = _gn_buffer(B, hout * wout, cout, x.device) if want else (None, 0)
+            slab = C.c_int32(0)
+            check(_lib.load().e2eft_upconv2x_fwd(C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), _ptr(buf), nbytes, C.byref(slab), _stream()))
+            if want:
+                _attach_stats(out, buf, slab.value, B, hout * wout, cout)
+        return out
     es = x.element_size()
     nb = (B * H * W * (d.c1 + d.c2) + B * hout * wout * cout * (2 if residual is not None else 1) + cout * kh * kw * (d.c1 + d.c2)) * es
     lib = _lib.load()

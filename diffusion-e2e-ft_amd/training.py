@@ -620,15 +620,28 @@ class EMAModel:
         return ema
 
 
-def train_step(unet, vae, optimizer, batches, empty_encoding, modality="depth", lr_scale=1.0):
+def lr_lambda_for_world(lr_total_iter_length, lr_exp_warmup_steps, num_processes=None, final_ratio=0.01):
+    """the `lr_func` of training/train.py:356: `accelerate` steps a prepared scheduler `num_processes` times per optimizer step, so the reference stretches BOTH
+    lengths by the number of processes.  With `LambdaLR(FlatAdamW, ...)` stepped once per optimizer step (no accelerate wrapper) pass num_processes=1; under
+    `accelerator.prepare(lr_scheduler)` pass the world size (default: torch.distributed's), exactly as the reference does."""
+    if num_processes is None:
+        num_processes = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    return IterExponential(total_iter_length=lr_total_iter_length * num_processes, final_ratio=final_ratio, warmup_steps=lr_exp_warmup_steps * num_processes)
+
+
+def train_step(unet, vae, optimizer, batches, empty_encoding, modality="depth", lr_scale=1.0, gather_loss=False):
     """One optimizer step over `batches` (a list of micro-batches = gradient accumulation, train.py:470,559-566): returns the
-    mean micro-loss as a device tensor."""
+    mean micro-loss as a device tensor.  gather_loss=True: every micro-step's loss is averaged over the ranks as train.py:559 does for logging
+    (`dist.gather_mean`: one small all-gather per micro-step, no host synchronisation)."""
+    from . import dist as D
     n = len(batches)
     total = None
     for i, batch in enumerate(batches):
         optimizer.sync_grads = i == n - 1
         loss = e2e_ft_loss(unet, vae, batch, empty_encoding, modality)
         (loss / n).backward()
+        if gather_loss:
+            loss = D.gather_mean(loss, batch["rgb"].shape[0])
         total = loss.detach() if total is None else total + loss.detach()
     optimizer.step(lr_scale=lr_scale)
     optimizer.zero_grad()

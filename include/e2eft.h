@@ -34,7 +34,7 @@ extern "C" {
 /* the library is built with -fvisibility=hidden: what this header (and e2eft_debug.h) declares is ALL it exports (tests/test_abi.py) */
 #pragma GCC visibility push(default)
 
-#define E2EFT_VERSION 118 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
+#define E2EFT_VERSION 119 /* 0.1.1: backward entry points; 111: test-time ensembling, CLIP towers, sample preparation */
 
 enum {
     E2EFT_OK = 0,
@@ -65,7 +65,8 @@ enum {
     E2EFT_OPT_THIN_INPUT_CONV = 7,   /* 1 (default): big 16-bit 3x3 / stride-1 / pad-1 convolutions with EIGHT input channels on convin.hip; 0: igemm2 */
     E2EFT_OPT_FUSED_NORM = 8,        /* 1 (default): e2eft_conv2d_fwd_normed_supported may answer 1; 0: it answers 0 (GroupNorm applied by its own pass) */
     E2EFT_OPT_ATTN_DMA = 9,          /* 1 (default since round 5): e2eft_attn_fwd delivers K / V tiles by LDS-DMA into a two-stage ring (K / V below 3.5 GB); 0: staged through registers (bit-identical results) */
-    E2EFT_OPT_COUNT = 10
+    E2EFT_OPT_UPCONV_PHASES = 10,    /* 1 (default): e2eft_upconv2x_fwd_supported may answer 1 (2x-upsample + 3x3 convolutions as four 2x2 phase convolutions); 0: it answers 0 */
+    E2EFT_OPT_COUNT = 11
 };
 int e2eft_set_option(int32_t key, int32_t value);
 int e2eft_get_option(int32_t key);
@@ -145,6 +146,19 @@ int e2eft_conv2d_fwd_gnstats(const E2eftConvDesc* d, const void* x1, const void*
  * either 128 <= c1 <= 640, cout <= 128, width % 32 == 0, height % 8 == 0, at least two 256-pixel tiles per CU (igemm6.hip) or cout <= 4, c1 <= 128,
  * c1 % 32 == 0, at least 16384 output pixels (conv_norm_out -> conv_out: narrow.hip); otherwise E2EFT_ERR_UNSUPPORTED. */
 int e2eft_conv2d_fwd_normed_supported(const E2eftConvDesc* d);
+/* Nearest-2x upsample followed by a 3x3 / stride-1 / pad-1 convolution (diffusers Upsample2D: the UNet's and the VAE decoder's upsamplers) evaluated as FOUR 2x2
+ * convolutions of the LOW-resolution input, one per output parity (py, px): output pixel (2Y + py, 2X + px) only ever reads two distinct source rows / columns, so the 3x3
+ * taps that fall on the same source pixel are added up front — 4/9 of the multiply-adds of e2eft_conv2d_fwd's fused-upsample form.  `d` is THAT call's descriptor
+ * (hin x win the source, hl = hout = 2 hin, wl = wout = 2 win, kh = kw = 3, stride 1, pads 1, c2 = 0, alpha 1).  w_phase: [4][cout][2 * 2 * c1] in the compute dtype,
+ * phase = 2 py + px, row layout (i, j, c) with source offset (i - (1 - py), j - (1 - px)):
+ *   w_phase[ph][co][i][j][c] = sum over ky in R(py, i), kx in R(px, j) of w[co][ky][kx][c],   R(0, 0) = {0}, R(0, 1) = {1, 2}, R(1, 0) = {0, 1}, R(1, 1) = {2}
+ * (summed in fp32, rounded once: results differ from the fused-upsample form by that rounding and the summation order — inside the 16-bit bar of the path).
+ * gn_partial / slab_rows as e2eft_conv2d_fwd_gnstats (statistics of the full-resolution output; *slab_rows = 256).  Served by the persistent kernel only (16-bit,
+ * c1 % 64 == 0, win % 16 == 0, batch * hin * win and hin * win multiples of 256, at least two tiles per CU): ask e2eft_upconv2x_fwd_supported (pure host
+ * arithmetic) first; E2EFT_ERR_UNSUPPORTED otherwise. */
+int e2eft_upconv2x_fwd_supported(const E2eftConvDesc* d);
+int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const void* w_phase, const void* bias, void* out, float* gn_partial,
+                       size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
 int e2eft_conv2d_fwd_normed(const E2eftConvDesc* d, const void* x1, const float* coeff, const void* beta, int32_t silu, const void* w,
                             const void* bias, const void* rowadd, const void* residual, void* out, float* gn_partial,
                             size_t gn_partial_bytes, int32_t* slab_rows, void* stream);

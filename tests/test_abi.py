@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "libe2eft.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.e2eft_version() == 118
+    assert lib.e2eft_version() == 119
 
 
 def test_library_exports_nothing_the_headers_do_not_declare():

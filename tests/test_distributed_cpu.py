@@ -89,6 +89,12 @@ def _worker(rank, world, port, q):
     opt._finish_exchange()
     for p, a, b in zip(net.parameters(), refs[0], refs[1]):
         assert torch.allclose(p.grad / world, (a + b) / 2, atol=1e-6)
+    # the logging value of a micro-step (train.py:559): accelerator.gather(loss.repeat(B)).mean() = mean over ranks
+    gm = D.gather_mean(torch.tensor(1.0 + 2.0 * rank), repeat=3)
+    assert gm.dim() == 0 and abs(gm.item() - 2.0) < 1e-7
+    # train.py:356: both schedule lengths are stretched by the number of processes
+    lam = training.lr_lambda_for_world(100, 10)
+    assert (lam.total_length, lam.warmup_steps) == (200, 20) and training.lr_lambda_for_world(100, 10, num_processes=1).total_length == 100
     dist.destroy_process_group()
     q.put(rank)
 

@@ -86,11 +86,13 @@ def _worker(rank, world, port, q, backend="gloo", ckpt=False):
         assert all(sl["work"] is not None for sl in opt.slices)          # every slice's all-reduce was launched from a hook, during the backward
         opt._finish_exchange()
         torch.cuda.synchronize()
-        summed = opt.flat_grad.detach().clone().cpu()
+        summed = opt.flat_grad.detach().cpu().numpy().copy()
         opt.step()
         opt.zero_grad()
         torch.cuda.synchronize()
-        q.put(("ok", rank, summed, opt.flat_param.detach().clone().cpu(), opt.step_count, opt.skipped_steps()))
+        # numpy payloads are pickled BY VALUE: a torch tensor travels as a shared-memory handle that the parent can only open while this process is alive
+        # (with four ranks the first ones had exited before the parent read their results: FileNotFoundError on the handle's socket)
+        q.put(("ok", rank, summed, opt.flat_param.detach().cpu().numpy().copy(), opt.step_count, opt.skipped_steps()))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:          # noqa: BLE001
@@ -137,6 +139,7 @@ def _two_ranks(dev, backend, world=2, ckpt=False):
     if any(r[0] == "skip" for r in res):
         pytest.skip("gloo has no device-tensor all_reduce in this torch build: %s" % [r[2] for r in res if r[0] == "skip"])
     assert all(r[0] == "ok" for r in res), [r[2] for r in res if r[0] != "ok"]
+    res = [(r[0], r[1], torch.from_numpy(r[2]), torch.from_numpy(r[3]), r[4], r[5]) for r in res]
     res.sort(key=lambda r: r[1])
     # ---- reference in this process: per-shard gradients, then ONE step over the two shards as accumulated micro-batches
     sys.path.insert(0, HERE)
