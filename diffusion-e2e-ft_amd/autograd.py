@@ -638,13 +638,21 @@ def _attn_core_unfused(q, k, v, heads, scale, causal=False):
     return o
 
 
+FUSED_FP32_ATTENTION = True   # tests / A-B: False sends fp32 attention through the GEMM + softmax form (rounds 1-4) instead of csrc/attn32.hip
+
+
+def fused_attention_ok(dtype, head_dim):
+    """the fused kernels serve head dim 64: fp16 / bf16 (attn.hip, attn_bwd.hip) and, since round 5, strict fp32 (attn32.hip)"""
+    return head_dim == 64 and (dtype != torch.float32 or FUSED_FP32_ATTENTION)
+
+
 FLASH_BACKWARD = True   # tests flip this to cross-check the fused backward against the GEMM + softmax form
 
 
 class _AttentionFn(torch.autograd.Function):
     """Attention core on packed projections: self-attention takes qkv [B,N,3C]; cross-attention q [B,N,C] + kv [B,L,2C].
-    Forward: the flash kernel (16-bit, d = 64) or the GEMM + softmax form.  Backward: the fused kernels of csrc/attn_bwd.hip for
-    the flash case; otherwise (fp32, VAE's 512-dim head) it recomputes P = softmax(q k^T) and runs
+    Forward: the flash kernel (d = 64: 16-bit attn.hip, strict fp32 attn32.hip) or the GEMM + softmax form.  Backward: the fused kernels of csrc/attn_bwd.hip /
+    attn32.hip for the flash case; otherwise (VAE's 512-dim head) it recomputes P = softmax(q k^T) and runs
         dP = dO V^T,  dS = P o (dP - rowsum(dP o P)) * scale,  dQ = dS K,  dK = dS^T Q,  dV = P^T dO
     as batched MFMA GEMMs; the pixel-major operands (K^T, Q^T, dO^T, P^T, dS^T) come from e2eft_transpose."""
 
@@ -652,7 +660,7 @@ class _AttentionFn(torch.autograd.Function):
     def forward(ctx, qkv, kv, heads, scale):
         C = qkv.shape[-1] // 3 if kv is None else qkv.shape[-1]
         q, k, v = _attn_views(qkv, kv, C)
-        if qkv.dtype != torch.float32 and C // heads == 64:
+        if fused_attention_ok(qkv.dtype, C // heads):
             o, lse = ops.attention(q, k, v, heads, scale, return_lse=True)
             ctx.save_for_backward(qkv, kv, o, lse)
         else:
@@ -720,7 +728,7 @@ def attention(qkv, kv, heads, scale):
         return _AttentionFn.apply(qkv, kv, heads, scale)
     C = qkv.shape[-1] // 3 if kv is None else qkv.shape[-1]
     q, k, v = _attn_views(qkv, kv, C)
-    if qkv.dtype != torch.float32 and C // heads == 64:
+    if fused_attention_ok(qkv.dtype, C // heads):
         return ops.attention(q, k, v, heads, scale)
     return _attn_core_unfused(q, k, v, heads, scale)
 

@@ -583,6 +583,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const AttnParams p
 
 }  // namespace e2eft
 
+namespace e2eft { int attn32_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, float* lse, void* stream); }   // attn32.hip
 using namespace e2eft;
 
 extern "C" int e2eft_attn_fwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, void* stream) {
@@ -591,10 +592,12 @@ extern "C" int e2eft_attn_fwd(const E2eftAttnDesc* d, const void* q, const void*
 
 extern "C" int e2eft_attn_fwd_lse(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, void* out, float* lse, void* stream) {
     E2EFT_REQUIRE(d && q && k && v && out, "attn: null pointer");
-    E2EFT_REQUIRE(d->dtype == E2EFT_F16 || d->dtype == E2EFT_BF16, "attn: dtype %d unsupported (fp16/bf16 only; fp32 uses the unfused path)", d->dtype);
+    E2EFT_REQUIRE(d->dtype == E2EFT_F16 || d->dtype == E2EFT_BF16 || d->dtype == E2EFT_F32, "attn: dtype %d unsupported", d->dtype);
     E2EFT_REQUIRE(d->batch > 0 && d->heads > 0 && d->nq > 0 && d->nk_seg > 0, "attn: geometry");
     E2EFT_REQUIRE(d->kv_nseg == 1 || d->kv_nseg == 2, "attn: kv_nseg must be 1 or 2");
     E2EFT_REQUIRE(d->kv_bmod > 0, "attn: kv_bmod");
+    E2EFT_REQUIRE(d->scale > 0.f, "attn: scale must be positive");
+    if (d->dtype == E2EFT_F32) return attn32_fwd(d, q, k, v, out, lse, stream);      // strict fp32 on v_mfma_f32_32x32x2_f32: attn32.hip
     const int w = d->heads * 64;
     E2EFT_REQUIRE(d->ldq >= w && d->ldk >= w && d->ldv >= w && d->ldo >= w, "attn: row strides smaller than heads*64");
     E2EFT_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0, "attn: row strides must be multiples of 8");

@@ -424,6 +424,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
 
 }  // namespace e2eft
 
+namespace e2eft {
+int attn32_bwd(const E2eftAttnDesc* d, const void* q, const void* k, const void* v, const void* out, const void* dout, int32_t lddo, const float* lse, void* dq,
+               int32_t lddq, void* dk, int32_t lddk, void* dv, int32_t lddv, void* workspace, void* stream);   // attn32.hip
+}
 using namespace e2eft;
 
 extern "C" size_t e2eft_attn_bwd_workspace_bytes(const E2eftAttnDesc* d) {
@@ -435,9 +439,15 @@ extern "C" int e2eft_attn_bwd(const E2eftAttnDesc* d, const void* q, const void*
                               int32_t lddo, const float* lse, void* dq, int32_t lddq, void* dk, int32_t lddk, void* dv, int32_t lddv,
                               void* workspace, size_t ws_bytes, void* stream) {
     E2EFT_REQUIRE(d && q && k && v && out && dout && lse && dq && dk && dv && workspace, "attn_bwd: null pointer");
-    E2EFT_REQUIRE(d->dtype == E2EFT_F16 || d->dtype == E2EFT_BF16, "attn_bwd: dtype %d unsupported (fp16/bf16, head dim 64)", d->dtype);
+    E2EFT_REQUIRE(d->dtype == E2EFT_F16 || d->dtype == E2EFT_BF16 || d->dtype == E2EFT_F32, "attn_bwd: dtype %d unsupported (head dim 64)", d->dtype);
     E2EFT_REQUIRE(d->batch > 0 && d->heads > 0 && d->nq > 0 && d->nk_seg > 0, "attn_bwd: geometry");
     E2EFT_REQUIRE(d->kv_nseg == 1 && d->kv_bmod == d->batch, "attn_bwd: joint (segmented) keys are not supported; concatenate k / v");
+    if (d->dtype == E2EFT_F32) {      // strict fp32: attn32.hip
+        E2EFT_REQUIRE(d->heads <= 65535 && d->batch <= 65535, "attn_bwd: grid");
+        const size_t need32 = e2eft_attn_bwd_workspace_bytes(d);
+        if (ws_bytes < need32) return fail(E2EFT_ERR_WORKSPACE, "attn_bwd: workspace %zu < %zu", ws_bytes, need32);
+        return attn32_bwd(d, q, k, v, out, dout, lddo, lse, dq, lddq, dk, lddk, dv, lddv, workspace, stream);
+    }
     const int w = d->heads * 64;
     E2EFT_REQUIRE(d->ldq >= w && d->ldk >= w && d->ldv >= w && d->ldo >= w && lddo >= w && lddq >= w && lddk >= w && lddv >= w, "attn_bwd: row strides");
     E2EFT_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,

@@ -254,7 +254,7 @@ class Attention(nn.Module):
             ctx = ctx.ctx
         if F.needs_grad(x, ctx, self.to_q.weight, self.to_k.weight, self.to_v.weight, out.weight):
             return out(self._forward_train(x, ctx), residual=residual)
-        fused = x.dtype != torch.float32 and d == 64
+        fused = F.fused_attention_ok(x.dtype, d)
         dt = x.dtype
         if fused:
             if ctx is None:

@@ -587,7 +587,7 @@ def attention512(q, k, v, scale, out=None):
 
 
 def attention_bwd(q, k, v, out, dout, lse, heads, scale, dq, dk, dv):
-    """Fused attention backward (head dim 64, 16-bit): writes dq / dk / dv (row-strided views shaped like q / k / v)."""
+    """Fused attention backward (head dim 64; fp16 / bf16 / strict fp32): writes dq / dk / dv (row-strided views shaped like q / k / v)."""
     _check_cuda(q, k, v, out, dout, lse, dq, dk, dv)
     B, Nq, Wd = q.shape
     Nk = k.shape[1]

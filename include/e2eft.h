@@ -223,7 +223,9 @@ int e2eft_softmax_rows(int32_t dtype, int64_t rows, int32_t n, int64_t lds, floa
 int e2eft_softmax_rows_causal(int32_t dtype, int64_t rows, int32_t n, int64_t lds, float scale, int32_t nq, void* s, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Fused (flash-style) attention forward, head dim 64, fp16/bf16, MFMA + online softmax.
+ * Fused (flash-style) attention forward, head dim 64, MFMA + online softmax: fp16 / bf16 (attn.hip) and strict fp32 on v_mfma_f32_32x32x2_f32
+ * (attn32.hip, round 5: the reference's training recipe is fp32 with xformers' fused attention, training/train.py:308-318; q / k / v / out row strides
+ * multiples of 4 floats, 16-byte aligned pointers).
  *   out[b, i, h*64:(h+1)*64] = softmax_j( scale * q[b,i,h,:] . k[kb(b),j,h,:] ) v[kb(b),j,h,:]
  * q/out: [batch, nq, heads*64] (row strides ldq/ldo), k/v: [kv_batch, nk_seg, heads*64] (ldk/ldv).
  * Joint (GeoWizard) attention: kv_nseg = 2 concatenates, along the key axis, the rows of kv batches
@@ -233,7 +235,7 @@ int e2eft_softmax_rows_causal(int32_t dtype, int64_t rows, int32_t n, int64_t ld
  * (attention.py:338-343,375-380,497).
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct E2eftAttnDesc {
-    int32_t dtype;            /* E2EFT_F16 or E2EFT_BF16 */
+    int32_t dtype;            /* E2EFT_F16, E2EFT_BF16 or E2EFT_F32 (e2eft_attn_fwd / _lse / e2eft_attn_bwd; e2eft_attn512_fwd: 16-bit only) */
     int32_t batch, heads, nq, nk_seg;
     int32_t kv_nseg, kv_bmod;
     int32_t ldq, ldk, ldv, ldo;
@@ -263,7 +265,7 @@ int e2eft_attn512_fwd(const E2eftAttnDesc* d, const void* q, const void* k, cons
 size_t e2eft_conv2d_wgrad_workspace_bytes(const E2eftConvDesc* d, int32_t lddy);
 int e2eft_conv2d_wgrad(const E2eftConvDesc* d, const void* dy, int32_t lddy, const void* x1, const void* x2, float* partial, size_t partial_bytes,
                        int32_t* nsplit_out, void* stream);
-/* Fused attention backward (head dim 64, fp16 / bf16, kv_nseg == 1; autograd of F.scaled_dot_product_attention /
+/* Fused attention backward (head dim 64, fp16 / bf16 / fp32, kv_nseg == 1; autograd of F.scaled_dot_product_attention /
  * xformers.memory_efficient_attention in diffusers Attention processors, attention.py:338-343,375-380): dq [B,Nq,heads*64],
  * dk / dv [B,Nk,heads*64] (row strides lddq / lddk / lddv), from q, k, v, the forward output `out` (desc ldo), its gradient
  * dout and the forward's lse.  No Nq x Nk matrix is materialised.  workspace: batch*heads*nq floats. */

@@ -1,0 +1,113 @@
+"""Training-input throughput ("nothing measures the loader"): how many Hypersim samples per second reach the GPU ready for
+training.e2e_ft_loss, against what 8 GPUs consume (8 x ~65 images/s at configs[2]'s bf16 step, 8 x ~9 in the reference's fp32 recipe).
+
+    python scripts/loader_bench.py [--samples 24] [--workers 16] [--batch 8] [--epochs 3] [--height 768 --width 1024]
+
+Writes `--samples` synthetic Hypersim-format samples (full-size PNGs: rgb, 16-bit depth, normals; tests/dataset_fixture.py) into a temporary directory, then times
+  reference_cpu   what the reference's `Hypersim.__getitem__` does per sample on ONE core (its DataLoader default num_workers = 0, train.py:143-149): Pillow decode,
+                  align_normals (numpy float64), Pillow resizes, torch.quantile, normalisation — restated with the same library calls (oracle/dataprep_ref.py);
+  decode_only     data.Hypersim.__getitem__ (decode only) on `--workers` threads;
+  device_loader   data.DeviceLoader end to end (decode threads -> pinned staging -> upload -> e2eft_align_normals_u8 / aug / quantile / prepare kernels), when a GPU
+                  is present: images/s of batches ready on the device, and the device time of the preparation alone.
+One JSON line on stdout."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def reference_cpu_sample(pr, near=1e-5, far=65.0):
+    from PIL import Image
+    from oracle import dataprep_ref
+    rgb = Image.open(pr["rgb_path"]).convert("RGB")
+    depth = np.array(Image.open(pr["depth_path"])) / 1000
+    dimg = Image.fromarray(depth)
+    nimg = Image.open(pr["normal_path"]).convert("RGB")
+    nimg = Image.fromarray(dataprep_ref.align_normals_u8_ref(np.array(nimg), np.array(dimg)))
+    rgb, nimg, dimg = rgb.resize((640, 480), Image.BILINEAR), nimg.resize((640, 480), Image.BILINEAR), dimg.resize((640, 480), Image.NEAREST)
+    tt = lambda im: torch.from_numpy(np.array(im)).permute(2, 0, 1).float().div(255)
+    return dataprep_ref.prepare_sample_ref(tt(rgb), torch.from_numpy(np.array(dimg, np.float32))[None], tt(nimg), near, far)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--samples", type=int, default=24)
+    ap.add_argument("--workers", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--height", type=int, default=768)
+    ap.add_argument("--width", type=int, default=1024)
+    args = ap.parse_args()
+    import dataset_fixture as dfx
+    from diffusion_e2e_ft_amd import data
+    out = {"samples": args.samples, "resolution": [args.height, args.width], "workers": args.workers, "batch": args.batch, "host_cores": os.cpu_count(),
+           "consumers_images_per_s": {"8 GPUs x bf16 step (66 images/s each)": 528, "8 GPUs x fp32 recipe (8.8 images/s each)": 70}}
+    with tempfile.TemporaryDirectory() as tmp:
+        t0 = time.perf_counter()
+        root_dir, split_path = dfx.make_hypersim_tree(tmp, n=args.samples, H=args.height, W=args.width)
+        out["fixture_seconds"] = round(time.perf_counter() - t0, 1)
+        ds = data.Hypersim(root_dir, transform=True, split_path=split_path)
+        assert len(ds) == args.samples
+        # (1) the reference's per-sample CPU work, one core
+        torch.set_num_threads(1)
+        n_ref = min(8, len(ds))
+        reference_cpu_sample(ds.pairs[0])
+        t0 = time.perf_counter()
+        for i in range(n_ref):
+            reference_cpu_sample(ds.pairs[i])
+        out["reference_cpu"] = {"images_per_s_per_core": n_ref / (time.perf_counter() - t0), "cores": 1,
+                                "what": "Pillow decode + align_normals (numpy) + Pillow resize + torch.quantile + normalisation, as load.py:214-283"}
+        # (2) decode only, thread pool
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(args.workers) as ex:
+            list(ex.map(ds.__getitem__, range(min(len(ds), args.workers))))
+            t0 = time.perf_counter()
+            for _ in range(args.epochs):
+                list(ex.map(ds.__getitem__, range(len(ds))))
+            out["decode_only"] = {"images_per_s": args.epochs * len(ds) / (time.perf_counter() - t0), "threads": args.workers}
+        # (3) end to end on the device
+        if torch.cuda.is_available():
+            dev = torch.device("cuda", 0)
+            loader = data.DeviceLoader(ds, batch_size=args.batch, device=dev, shuffle=True, drop_last=True, workers=args.workers, prefetch=3)
+            for b in loader:        # warm-up epoch: tables, allocator, kernels
+                last = b
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 0
+            for _ in range(args.epochs):
+                for b in loader:
+                    n += b["rgb"].shape[0]
+                    last = b
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["device_loader"] = {"images_per_s": n / dt, "batches": n // args.batch, "output": {k: list(v.shape) for k, v in last.items() if isinstance(v, torch.Tensor)}}
+            # the device preparation alone (inputs resident)
+            samples = [ds[i] for i in range(args.batch)]
+            st = loader._stage(samples)
+            dv = {k: v.to(dev) for k, v in st.items()}
+            flips = [i % 2 == 0 for i in range(args.batch)]
+            for _ in range(3):
+                data.finish_samples(dv["rgb_u8"], dv["depth"], dv["normal_u8"], "hypersim", flip=flips)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                data.finish_samples(dv["rgb_u8"], dv["depth"], dv["normal_u8"], "hypersim", flip=flips)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            out["device_prepare"] = {"ms_per_batch": ms, "images_per_s": args.batch / ms * 1e3, "what": "align_normals + flip / Pillow-exact resize + quantiles + prepare, batch resident"}
+            loader.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
