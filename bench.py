@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--micro-batch", type=int, default=None, help="--train: images per micro-step per rank (default: 32 in bf16 = the whole "
                     "configs[2] batch in one pass, 122 GB of the 288 GB HBM; 16 in fp32)")
     ap.add_argument("--accum", type=int, default=None, help="--train: gradient-accumulation micro-steps per optimizer step (default 32 / micro-batch)")
+    ap.add_argument("--c4", action="store_true", help="--train preset = BASELINE.json configs[3]'s per-GPU share: 2 images per GPU at 768x768, one micro-step, activation "
+                    "recompute on (`--gradient_checkpointing`, train_marigold_e2e_ft_depth.sh:11); with --gpus 8 that is the configuration itself.  The line carries the "
+                    "exposed all-reduce time per gradient slice and the per-micro-step loss all-gather of train.py:559")
     ap.add_argument("--modality", default="depth", choices=["depth", "normals"])
     ap.add_argument("--no-direct-grads", action="store_true", help="--train, A/B: FlatAdamW(direct_grads=False) — gradients accumulated by autograd into a cleared flat buffer (round 3) instead of written into it by the backward kernels")
     ap.add_argument("--grad-ckpt", action="store_true", help="--train: activation recompute in the UNet blocks and the frozen decoder "
@@ -73,6 +76,10 @@ def parse():
         import _options
         left = _options.take(args.set_option)
         assert not left, "unknown --set-option %s" % left
+    if args.c4:
+        args.train = True
+        args.res = args.res or 768
+        args.micro_batch, args.accum, args.grad_ckpt = args.micro_batch or 2, args.accum or 1, True
     if args.res is None:
         args.res = 576 if args.train else 768
     hw = str(args.res).lower().split("x")
@@ -286,10 +293,11 @@ def run_train(args, rank, world, dev):
     mb, acc = train_batching(args)
     text = 0.5 * torch.randn((1, 77, unet.config.cross_attention_dim), generator=torch.Generator(device=dev).manual_seed(0), device=dev)
     batches = [training.synthetic_batch(mb, R, R, dev, seed=1000 * rank + i, dtype=cdt) for i in range(acc)]
-    sched = training.IterExponential(20000 * world, 0.01, 100 * world)
+    sched = training.lr_lambda_for_world(20000, 100, num_processes=world)      # train.py:356: both lengths x num_processes
 
     def step(i):
-        return training.train_step(unet, vae, opt, batches, text, args.modality, lr_scale=sched(i))
+        # world > 1: every micro-step's loss is averaged over the ranks for logging, as train.py:559 does (one small all-gather, no host sync)
+        return training.train_step(unet, vae, opt, batches, text, args.modality, lr_scale=sched(i), gather_loss=world > 1)
 
     for i in range(args.warmup):
         loss = step(i)
