@@ -206,6 +206,33 @@ def packed_conv_weight_dgrad(conv, dtype):
     return cached(conv, "packed_dgrad_%s" % dtype, (w,), build)
 
 
+UPCONV_DGRAD_4X4 = True     # tests / A-B: False sends the data gradient of upsample-convolutions through the 3x3 dgrad on the upsampled grid + e2eft_upsample_nearest_bwd
+
+
+def upconv_dgrad_weight(conv, dtype):
+    """The data gradient of `nearest-2x upsample -> conv 3x3 / pad 1` w.r.t. the LOW-resolution input is ONE 4x4 / stride-2 / pad-1 convolution of dY:
+        dX[Y, X, ci] = sum_{u, v in 0..3, co} wt[ci][u][v][co] * dY[2Y - 1 + u, 2X - 1 + v, co],   wt[ci][u][v][co] = sum_{ky in S(u), kx in S(v)} w[co][ci][ky][kx],
+    S(0) = {2}, S(1) = {1, 2}, S(2) = {0, 1}, S(3) = {0}: source pixel (Y, X) was read by the output pixels (2Y + a - ky + 1, ...), a in {0, 1} — the transpose of
+    autograd.phase_conv_weight's four 2x2 phases.  16 / 36 = 4/9 of the multiply-adds of the 3x3 dgrad on the upsampled grid, and the fold-back pass
+    (e2eft_upsample_nearest_bwd) disappears.  -> [Ci_pad, 4 * 4 * Co_pad] rows (u, v, co), summed in fp32 from the master weights, cached per parameter version."""
+    w = conv.weight
+
+    def build():
+        Co, Ci = w.shape[:2]
+        e = ops.epc(dtype)
+        cip, cop = ops.round_up(Ci, e), ops.round_up(Co, e)
+        w32 = w.detach().to(torch.float64 if w.dtype == torch.float64 else torch.float32)      # [Co, Ci, 3, 3]
+        S = ((2,), (1, 2), (0, 1), (0,))
+        out = torch.zeros((cip, 4, 4, cop), dtype=w32.dtype, device=w32.device)
+        for u in range(4):
+            rows = sum(w32[:, :, ky, :] for ky in S[u])                 # [Co, Ci, 3]
+            for v in range(4):
+                out[:Ci, u, v, :Co] = sum(rows[:, :, kx] for kx in S[v]).t()
+        return out.reshape(cip, 16 * cop).to(dtype).contiguous()
+
+    return cached(conv, "upconv_dgrad_%s" % dtype, (w,), build)
+
+
 def _dense_nhwc(g, cpad):
     """gradient tensor [B,H,W,C] -> pixel-dense NHWC view/copy whose channel extent is padded to `cpad` with zeros"""
     B, H, W, Cc = g.shape
@@ -305,9 +332,14 @@ class _Conv2dFn(torch.autograd.Function):
                 else:
                     dbias = s.sum(0).to(bias.dtype)
         if need[0] or (x2 is not None and need[1]):
-            dxl = ops.conv2d_dgrad(dyp, packed_conv_weight_dgrad(conv, dt), (B, H, W, c1), c2, kh, kw, stride, pad, up_to, alpha)
-            if up_to is not None:
-                dxl = ops.upsample_nearest_bwd(dxl, H, W)
+            if (UPCONV_DGRAD_4X4 and up_to is not None and x2 is None and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1)
+                    and tuple(up_to) == (2 * H, 2 * W) and tuple(dyp.shape[1:3]) == (2 * H, 2 * W)):
+                # upsampler: one 4x4 / stride-2 convolution of dY lands directly on the low-resolution grid (4/9 of the multiply-adds, no fold-back pass)
+                dxl = ops.conv2d(dyp, upconv_dgrad_weight(conv, dt), None, c1, 4, 4, 2, (1, 1, 1, 1), alpha=alpha)
+            else:
+                dxl = ops.conv2d_dgrad(dyp, packed_conv_weight_dgrad(conv, dt), (B, H, W, c1), c2, kh, kw, stride, pad, up_to, alpha)
+                if up_to is not None:
+                    dxl = ops.upsample_nearest_bwd(dxl, H, W)
             if need[0]:
                 dx = dxl[..., :c_orig]
             if x2 is not None and need[1]:

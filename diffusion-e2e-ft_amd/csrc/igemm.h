@@ -159,6 +159,8 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, char* 
             sm2[q] = f2{0.f, 0.f};
             sq2[q] = f2{0.f, 0.f};
         }
+        // p.out_seg > 0 (e2eft_upconv2x_fwd: one parity phase of a 2x-upsampled image): GEMM row m lands on output row m + (m / out_seg) * out_seg
+        auto seg_off = [&](const int row) -> long { return p.out_seg > 0 ? (long)((m0 + row) / p.out_seg) * p.out_seg * p.ldo : 0L; };
         auto run = [&](auto has_res, auto has_ra) {
             constexpr bool HAS_RES = decltype(has_res)::value, HAS_RA = decltype(has_ra)::value;
 #pragma unroll
@@ -198,7 +200,7 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, char* 
                     Vec16<T> o;
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(x2[(q * EPC + e) >> 1][(q * EPC + e) & 1]);
-                    st16(orow + pass * ostep + q * EPC, o);
+                    st16(orow + pass * ostep + seg_off(row) + q * EPC, o);
                 }
                 if (stats) {   // uniform: shifted sums about a per-column pivot shared by the whole tile (sm2 = sum, sq2 = sum of squares)
 #pragma unroll
@@ -296,7 +298,7 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, char* 
                 Vec16<T> o;
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) o.e[e] = from_f<T>(v[q * EPC + e]);
-                st16(out + (long)m * p.ldo + n + q * EPC, o);
+                st16(out + ((long)m + (p.out_seg > 0 ? (long)(m / p.out_seg) * p.out_seg : 0L)) * p.ldo + n + q * EPC, o);
                 if (stats) {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {   // statistics of what GroupNorm will read back: the rounded value
@@ -315,7 +317,7 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, char* 
                     if (ra) x += to_f(ra[e]);
                     x *= p.alpha;
                     if (res) x += to_f(res[(long)m * p.ldr + n + e]);
-                    out[(long)m * p.ldo + n + e] = from_f<T>(x);
+                    out[((long)m + (p.out_seg > 0 ? (long)(m / p.out_seg) * p.out_seg : 0L)) * p.ldo + n + e] = from_f<T>(x);
                 }
             }
         }

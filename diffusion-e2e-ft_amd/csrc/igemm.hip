@@ -247,22 +247,28 @@ static int conv2d_core(const E2eftConvDesc* d, const void* x1, const void* x2, c
 // rows, the 3x3 taps that fall on the same source pixel can be added up front.  Per parity phase (py, px) the layer is a 2x2 convolution (pad_t = 1 - py, pad_l = 1 - px)
 // with weights w_phase[2 py + px][co][(i, j, ci)] = sum of the 3x3 taps that map to source offset (i, j) — 4/9 of the multiply-adds of the fused-upsample form, same
 // zero padding (the upsampled image's border IS the source's border).  The phases write interleaved pixels of the full-resolution output: IgemmParams.out_seg.
-static bool upconv2x_shape_ok(const E2eftConvDesc* d) {
-    return d && (d->dtype == E2EFT_F16 || d->dtype == E2EFT_BF16) && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->c2 == 0 &&
-           d->hl == 2 * d->hin && d->wl == 2 * d->win && d->hout == d->hl && d->wout == d->wl && d->batch > 0 && d->hin > 0 && d->c1 > 0 && d->c1 % 64 == 0 &&
-           d->win % 16 == 0 && d->cout % 8 == 0 && ((long)d->batch * d->hin * d->win) % 256 == 0 && ((long)d->hin * d->win) % 256 == 0 && d->ldo % 8 == 0 && d->alpha == 1.0f;
-}
-
 namespace e2eft { int device_cus(); }   // api.hip
-extern "C" int e2eft_upconv2x_fwd_supported(const E2eftConvDesc* d) {
-    if (!upconv2x_shape_ok(d) || !option(E2EFT_OPT_UPCONV_PHASES) || !option(E2EFT_OPT_PERSISTENT)) return 0;
+static bool upconv2x_shape_ok(const E2eftConvDesc* d) {     // the layer is a 2x-upsample + 3x3 / stride-1 / pad-1 convolution whose phases any igemm kernel can run
+    if (!d || d->dtype < 0 || d->dtype > 2) return false;
+    const int bk = 128 / (int)dtype_size(d->dtype);          // one k-tile of the FAST operand path
+    return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->c2 == 0 && d->hl == 2 * d->hin && d->wl == 2 * d->win &&
+           d->hout == d->hl && d->wout == d->wl && d->batch > 0 && d->hin > 0 && d->win > 0 && d->c1 > 0 && d->c1 % bk == 0 && d->cout % (bk / 8) == 0 &&
+           d->ldo % (bk / 8) == 0 && d->alpha == 1.0f && (long)d->batch * d->hin * d->win < 2147483647L &&
+           (long)d->hin * d->win * d->ldx1 * (long)dtype_size(d->dtype) * 3 < 0xD0000000L && (long)128 * 4 * d->c1 * (long)dtype_size(d->dtype) < 0x40000000L;
+}
+// the persistent kernel takes the phases (and emits GroupNorm statistics): 16-bit, whole 256-row tiles inside one image, segments of a multiple of 16 rows, >= 2 tiles per CU
+static bool upconv2x_persistent(const E2eftConvDesc* d) {
+    if (d->dtype == E2EFT_F32 || !option(E2EFT_OPT_PERSISTENT)) return false;
+    if (d->c1 % 64 != 0 || d->win % 16 != 0 || ((long)d->batch * d->hin * d->win) % 256 != 0 || ((long)d->hin * d->win) % 256 != 0) return false;
     int cus = device_cus();
     const int gopt = option(E2EFT_OPT_PERSISTENT_GRID);
     if (gopt >= 8 && gopt < cus) cus = gopt;
-    if (cus <= 0) return 0;
-    const long tiles = ((long)d->batch * d->hin * d->win / 256) * cdiv(d->cout, 128);
-    const long img_bytes = (long)d->hin * d->win * d->ldx1 * 2;
-    return tiles >= 2L * cus && img_bytes * 3 < 0xD0000000L && (long)128 * 4 * d->c1 * 2 < 0x40000000L ? 1 : 0;
+    if (cus <= 0) return false;
+    return ((long)d->batch * d->hin * d->win / 256) * cdiv(d->cout, 128) >= 2L * cus;
+}
+
+extern "C" int e2eft_upconv2x_fwd_supported(const E2eftConvDesc* d) {
+    return upconv2x_shape_ok(d) && option(E2EFT_OPT_UPCONV_PHASES) ? 1 : 0;
 }
 
 extern "C" int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const void* w_phase, const void* bias, void* out, float* gn_partial,
@@ -271,9 +277,11 @@ extern "C" int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const v
     E2EFT_REQUIRE(d && x && w_phase && out, "upconv2x: null pointer");
     if (!e2eft_upconv2x_fwd_supported(d)) return fail(E2EFT_ERR_UNSUPPORTED, "upconv2x: this launch is not eligible (ask e2eft_upconv2x_fwd_supported; e2eft_conv2d_fwd serves it)");
     E2EFT_REQUIRE(al16(x) && al16(w_phase) && al16(out) && (!bias || al16(bias)), "upconv2x: pointers must be 16-byte aligned");
+    const bool pers = upconv2x_persistent(d);                // all four phases take the same kernel: the statistics slabs must agree
     const int rows_img = d->hin * d->win;                    // GEMM rows of one image in ONE phase
     const int slabs = rows_img / 256;
-    if (gn_partial && slab_rows) {
+    const bool stats = pers && gn_partial && slab_rows;      // (igemm2 serves the phases without statistics: the consuming GroupNorm runs its own pass)
+    if (stats) {
         const size_t need = (size_t)d->batch * (size_t)cdiv(4 * rows_img, 128) * (size_t)d->cout * 3 * sizeof(float);
         if (gn_partial_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "upconv2x: gn_partial %zu < %zu bytes", gn_partial_bytes, need);
     }
@@ -294,16 +302,21 @@ extern "C" int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const v
         p.rows_per_img = rows_img;
         p.alpha = 1.f;
         p.nzi = 1;
-        if (gn_partial && slab_rows) {       // the four phases deposit into disjoint slab ranges of one [image][4 * slabs][cout][3] buffer
+        if (stats) {       // the four phases deposit into disjoint slab ranges of one [image][4 * slabs][cout][3] buffer
             p.gn_partial = gn_partial + (size_t)ph * slabs * d->cout * 3;
             p.gn_islabs = 4 * slabs;
         }
-        p.mtiles = p.M / 256; p.ntiles = cdiv(p.N, 128);
-        const int rc = launch_igemm_persistent(d->dtype, 1, p, 1, (hipStream_t)stream);
-        if (rc < 0) return fail(E2EFT_ERR_UNSUPPORTED, "upconv2x: the persistent kernel declined phase %d", ph);
+        int rc;
+        if (pers) {
+            p.mtiles = p.M / 256; p.ntiles = cdiv(p.N, 128);
+            rc = launch_igemm_persistent(d->dtype, 1, p, 1, (hipStream_t)stream);
+            if (rc < 0) return fail(E2EFT_ERR_UNSUPPORTED, "upconv2x: the persistent kernel declined phase %d", ph);
+        } else {
+            rc = launch_igemm_v2(d->dtype, 1, p, 1, (hipStream_t)stream);
+        }
         if (rc) return rc;
     }
-    if (gn_partial && slab_rows) *slab_rows = 256;
+    if (stats) *slab_rows = 256;
     return E2EFT_OK;
 }
 

@@ -285,7 +285,7 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
         assert rowadd.dtype == x.dtype and tuple(rowadd.shape) == (B, cout) and rowadd.is_contiguous()
     want = gn_stats and GN_STATS_ENABLED and cout % 8 == 0
     if (w_phase is not None and UPCONV_PHASES_ENABLED and up_to is not None and x2 is None and rowadd is None and residual is None and norm is None and alpha == 1.0
-            and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1) and (hl, wl) == (2 * H, 2 * W) and x.dtype != torch.float32
+            and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1) and (hl, wl) == (2 * H, 2 * W)
             and _lib.load().e2eft_upconv2x_fwd_supported(C.byref(d)) == 1):
         wp = w_phase()
         assert tuple(wp.shape) == (4, cout, 4 * c1) and wp.is_contiguous() and wp.dtype == x.dtype, (wp.shape, wp.dtype)

@@ -153,9 +153,10 @@ int e2eft_conv2d_fwd_normed_supported(const E2eftConvDesc* d);
  * phase = 2 py + px, row layout (i, j, c) with source offset (i - (1 - py), j - (1 - px)):
  *   w_phase[ph][co][i][j][c] = sum over ky in R(py, i), kx in R(px, j) of w[co][ky][kx][c],   R(0, 0) = {0}, R(0, 1) = {1, 2}, R(1, 0) = {0, 1}, R(1, 1) = {2}
  * (summed in fp32, rounded once: results differ from the fused-upsample form by that rounding and the summation order — inside the 16-bit bar of the path).
- * gn_partial / slab_rows as e2eft_conv2d_fwd_gnstats (statistics of the full-resolution output; *slab_rows = 256).  Served by the persistent kernel only (16-bit,
- * c1 % 64 == 0, win % 16 == 0, batch * hin * win and hin * win multiples of 256, at least two tiles per CU): ask e2eft_upconv2x_fwd_supported (pure host
- * arithmetic) first; E2EFT_ERR_UNSUPPORTED otherwise. */
+ * gn_partial / slab_rows as e2eft_conv2d_fwd_gnstats: statistics of the full-resolution output, emitted when the persistent kernel serves the phases (16-bit,
+ * c1 % 64 == 0, win % 16 == 0, batch * hin * win and hin * win multiples of 256, at least two tiles per CU: *slab_rows = 256); other shapes and fp32 run the
+ * phases on igemm2 without statistics (*slab_rows = 0).  Eligible: fp32 / fp16 / bf16 with c1 a multiple of one 128-byte k-tile (32 floats / 64 halves), cout and
+ * ldo multiples of 16 bytes; ask e2eft_upconv2x_fwd_supported (pure host arithmetic) first; E2EFT_ERR_UNSUPPORTED otherwise. */
 int e2eft_upconv2x_fwd_supported(const E2eftConvDesc* d);
 int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const void* w_phase, const void* bias, void* out, float* gn_partial,
                        size_t gn_partial_bytes, int32_t* slab_rows, void* stream);

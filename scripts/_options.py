@@ -1,5 +1,7 @@
 """Shared by the micro-benchmarks: trailing `name=value` arguments (persistent=0, persistent_grid=8, narrow_conv=0, narrow_mfma=0,
 igemm_general_operands=1, igemm2_waves=4) become e2eft_set_option calls — the library itself never reads the environment."""
+import sys
+
 from diffusion_e2e_ft_amd import _lib
 
 NAMES = {"persistent": _lib.OPT_PERSISTENT, "persistent_grid": _lib.OPT_PERSISTENT_GRID, "narrow_conv": _lib.OPT_NARROW_CONV,
@@ -13,7 +15,7 @@ def take(argv):
         k, _, v = a.partition("=")
         if k in NAMES and v.lstrip("-").isdigit():
             _lib.set_option(NAMES[k], int(v))
-            print("option %s = %s" % (k, v))
+            print("option %s = %s" % (k, v), file=sys.stderr)      # (stderr: bench.py's stdout is ONE JSON line)
         else:
             rest.append(a)
     return rest

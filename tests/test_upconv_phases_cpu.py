@@ -29,3 +29,21 @@ def test_phase_weights_reproduce_upsample_then_conv3x3():
     with torch.no_grad():
         conv.weight.mul_(2.0)
     assert (F.phase_conv_weight(conv, torch.float64) - 2 * wp).abs().max().item() < 1e-12
+
+
+def test_dgrad_is_one_4x4_stride2_convolution_of_dy():
+    """autograd.upconv_dgrad_weight: d(upsample -> conv3x3) / d(low-resolution input) = conv(dY, 4x4, stride 2, pad 1) — against torch autograd in float64"""
+    from diffusion_e2e_ft_amd import autograd as F
+    g = torch.Generator().manual_seed(1)
+    B, Ci, Co, H, W = 2, 8, 16, 5, 7                    # (channel counts that need no padding in float64: epc = 2)
+    conv = torch.nn.Conv2d(Ci, Co, 3, padding=1).double()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g, dtype=torch.float64))
+    x = torch.randn(B, Ci, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(B, Co, 2 * H, 2 * W, generator=g, dtype=torch.float64)
+    conv(TF.interpolate(x, scale_factor=2.0, mode="nearest")).backward(dy)
+    wt = F.upconv_dgrad_weight(conv, torch.float64)                       # [Ci, (u, v, co)]
+    assert tuple(wt.shape) == (Ci, 16 * Co)
+    w4 = wt.reshape(Ci, 4, 4, Co).permute(0, 3, 1, 2)                     # as an OIHW weight: out channels = ci, in channels = co
+    got = TF.conv2d(dy, w4, None, stride=2, padding=1)
+    assert got.shape == x.shape and (got - x.grad).abs().max().item() < 1e-11

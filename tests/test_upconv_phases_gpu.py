@@ -71,24 +71,55 @@ def test_phases_match_torch_and_the_fused_upsample_form(dev, dtype, B, H, W, Ci,
     assert_close(to_nchw(gn), want, dtype, "groupnorm on phase statistics", scale=1.5)
 
 
+def _labels(fn):
+    from diffusion_e2e_ft_amd import ops
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    try:
+        y = fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.TIMER = None
+    return y, [lab[0] if isinstance(lab, tuple) else lab for (_, lab) in timer.by_label()]
+
+
+@pytest.mark.parametrize("dtype,B,H,W,Ci,Co", [(torch.float32, 2, 24, 24, 32, 64), (torch.float32, 1, 18, 40, 64, 96), (torch.float16, 2, 24, 24, 64, 128),
+                                                (torch.float16, 1, 16, 16, 64, 128), (torch.bfloat16, 1, 9, 13, 128, 64)])
+def test_phases_on_the_general_kernel_fp32_odd_widths_few_tiles(dev, dtype, B, H, W, Ci, Co):
+    """shapes the persistent kernel does not take (fp32; widths that are not multiples of 16; fewer than two tiles per CU) run the four phases on igemm2, whose row
+    passes place every row by division — no statistics there (the consuming GroupNorm runs its own pass)"""
+    from diffusion_e2e_ft_amd import ops
+    from util import TOL
+    conv, xd, wd, bd, ref, wph = _case(dev, dtype, B, H, W, Ci, Co, seed=H + W)
+    y, labels = _labels(lambda: ops.conv2d(xd, wd, bd, Co, 3, 3, 1, (1, 1, 1, 1), up_to=(2 * H, 2 * W), gn_stats=True, w_phase=wph))
+    assert any(str(l).startswith("upconv2x") for l in labels), labels
+    assert getattr(y, "_e2eft_gn", None) is None
+    assert_close(to_nchw(y), ref, dtype, "phases on igemm2")
+    y0, labels0 = _labels(lambda: ops.conv2d(xd, wd, bd, Co, 3, 3, 1, (1, 1, 1, 1), up_to=(2 * H, 2 * W), gn_stats=True))      # no phase weights offered: the fused-upsample form
+    assert not any(str(l).startswith("upconv2x") for l in labels0)
+    assert rel_err(to_nchw(y), to_nchw(y0)) <= 2 * TOL[dtype]
+
+
 def test_unsupported_shapes_fall_back_and_the_entry_point_says_so(dev):
     from diffusion_e2e_ft_amd import ops, _lib
     dtype = torch.float16
-    # width 24 (not a multiple of 16) and 8 input channels: the fused-upsample form serves them, silently
-    for (B, H, W, Ci, Co) in [(2, 24, 24, 64, 128), (1, 32, 32, 8, 128)]:
-        conv, xd, wd, bd, ref, wph = _case(dev, dtype, B, H, W, Ci, Co, seed=3)
-        with _lib.option(_lib.OPT_PERSISTENT_GRID, 8):
-            y = ops.conv2d(ops.pad_channels(xd), wd, bd, Co, 3, 3, 1, (1, 1, 1, 1), up_to=(2 * H, 2 * W), w_phase=wph)
-        assert_close(to_nchw(y), ref, dtype, "fallback")
-    # too few tiles for the persistent kernel without the test grid: supported() answers 0 and the direct call reports UNSUPPORTED
-    conv, xd, wd, bd, ref, wph = _case(dev, dtype, 1, 16, 16, 64, 128, seed=4)
-    d = ops._conv_desc(xd, None, 128, 3, 3, 1, (1, 1, 1, 1), (32, 32), 1.0, ldo=128)
+    # 8 input channels (less than one k-tile of the FAST operand path): the fused-upsample form serves it, silently
+    conv, xd, wd, bd, ref, wph = _case(dev, dtype, 1, 32, 32, 8, 128, seed=3)
+    y, labels = _labels(lambda: ops.conv2d(ops.pad_channels(xd), wd, bd, 128, 3, 3, 1, (1, 1, 1, 1), up_to=(64, 64), w_phase=wph))
+    assert_close(to_nchw(y), ref, dtype, "fallback")
+    assert not any(str(l).startswith("upconv2x") for l in labels), labels
+    d = ops._conv_desc(xd, None, 128, 3, 3, 1, (1, 1, 1, 1), (64, 64), 1.0, ldo=128)
     import ctypes as C
     lib = _lib.load()
     assert lib.e2eft_upconv2x_fwd_supported(C.byref(d)) == 0
-    out = torch.empty((1, 32, 32, 128), dtype=dtype, device=dev)
-    rc = lib.e2eft_upconv2x_fwd(C.byref(d), xd.data_ptr(), wph().data_ptr(), None, out.data_ptr(), None, 0, None, None)
+    out = torch.empty((1, 64, 64, 128), dtype=dtype, device=dev)
+    rc = lib.e2eft_upconv2x_fwd(C.byref(d), xd.data_ptr(), xd.data_ptr(), None, out.data_ptr(), None, 0, None, None)
     assert rc == 4 and b"not eligible" in lib.e2eft_last_error()
+    with _lib.option(_lib.OPT_UPCONV_PHASES, 0):      # the switch: supported() answers 0 for an eligible shape
+        conv, xd, wd, bd, ref, wph = _case(dev, dtype, 2, 32, 32, 64, 256, seed=5)
+        d2 = ops._conv_desc(xd, None, 256, 3, 3, 1, (1, 1, 1, 1), (64, 64), 1.0, ldo=256)
+        assert lib.e2eft_upconv2x_fwd_supported(C.byref(d2)) == 0
+    assert lib.e2eft_upconv2x_fwd_supported(C.byref(d2)) == 1
 
 
 def test_vae_decoder_upsampler_at_full_width_runs_in_phases_and_matches(dev):
