@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--c4", action="store_true", help="--train preset = BASELINE.json configs[3]'s per-GPU share: 2 images per GPU at 768x768, one micro-step, activation "
                     "recompute on (`--gradient_checkpointing`, train_marigold_e2e_ft_depth.sh:11); with --gpus 8 that is the configuration itself.  The line carries the "
                     "exposed all-reduce time per gradient slice and the per-micro-step loss all-gather of train.py:559")
+    ap.add_argument("--round4-paths", action="store_true", help="A/B: the round-4 forms of what round 5 replaced — fp32 attention as GEMM + softmax launches, 2x-upsample "
+                    "convolutions fused into a 3x3 operand fetch (forward) and 3x3 dgrad + fold-back (backward)")
     ap.add_argument("--modality", default="depth", choices=["depth", "normals"])
     ap.add_argument("--no-direct-grads", action="store_true", help="--train, A/B: FlatAdamW(direct_grads=False) — gradients accumulated by autograd into a cleared flat buffer (round 3) instead of written into it by the backward kernels")
     ap.add_argument("--grad-ckpt", action="store_true", help="--train: activation recompute in the UNet blocks and the frozen decoder "
@@ -71,6 +73,9 @@ def parse():
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B runs: e2eft_set_option before anything is launched (names: scripts/_options.py, e.g. patch_conv=0, fused_norm=0); recorded in the line's config")
     args = ap.parse_args()
+    if args.round4_paths:
+        from diffusion_e2e_ft_amd import autograd as _F, ops as _ops
+        _F.FUSED_FP32_ATTENTION, _F.UPCONV_DGRAD_4X4, _ops.UPCONV_PHASES_ENABLED = False, False, False
     if args.set_option:
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import _options
