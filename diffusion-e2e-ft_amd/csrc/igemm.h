@@ -52,7 +52,7 @@ struct IgemmParams {
     int gn_islabs;       // > 0: statistics slabs per image in gn_partial (the image stride), when it differs from gn_nslabs (four phases share one buffer)
     int debug_flags;     // instrumented build (-DE2EFT_STAMPS) only: bit 0 / 1 / 2 = the persistent kernel issues its A-operand LDS-DMA never / on the
                          // first tap of a filter row only / on the first tap of a 64-channel chunk only (WRONG results; the price of operand
-                         // delivery, scripts/experiments/README: "what an A-reuse scheme could buy at most")
+                         // delivery: profiles/r03d_a_operand_delivery_probe.txt, "what an A-reuse scheme could buy at most")
 };
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@
 // fused nearest upsample, fused channel concat of two sources), conv1x1, nn.Linear and the batched attention matmuls of the unfused
 // path.  The kernels live in igemm5.hip (persistent workgroups, the big 16-bit launches) and igemm2.hip (everything else, incl. exact
 // fp32 on v_mfma_f32_32x32x2_f32).  (Round 1's register-staged 128x128 kernel and round 2's row-strip kernel igemm4 were retired in
-// round 3: neither was on any production path; their text is kept in scripts/experiments/.)
+// round 3: neither was on any production path; their text is in the history: git show 964b305:scripts/experiments/.)
 #include "common.h"
 #include "igemm.h"
 
