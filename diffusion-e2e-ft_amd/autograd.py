@@ -355,7 +355,7 @@ class _Conv2dFn(torch.autograd.Function):
             dwp = ops.conv2d_wgrad(dyp, xp, x2, Co, kh, kw, stride, pad, alpha, out=None if wsink is None else wsink[0]) if up_to is None else None
             if dwp is None:
                 P = dyp.shape[0] * dyp.shape[1] * dyp.shape[2]
-                nsplit, kc = ops.splitk_plan(Co, kh * kw * (c1 + c2), P)
+                nsplit, kc = ops.splitk_plan(Co, kh * kw * (c1 + c2), P, dt)
                 dyT = ops.transpose(ops._as_rows(dyp), rows_pad=nsplit * kc)        # [cop, Pp]
                 col, _, _ = ops.im2col_t(xp, x2, kh, kw, stride, pad, up_to, Pp=nsplit * kc)   # [kh*kw*cin, Pp]
                 dwp = ops.gemm_splitk(dyT[:Co], col, nsplit, kc, alpha=alpha)       # [Co, kh*kw*cin] = OHWI
@@ -475,7 +475,7 @@ class _LinearFn(torch.autograd.Function):
                 wsink = grad_sink(*ctx.psrc[1])
             dw = ops.linear_wgrad(g, _rows(xp), alpha, out=None if wsink is None else wsink[0]) if M >= 512 else None      # csrc/wgrad.hip (1x1 case); None -> the transposes + GEMM below
             if dw is None:
-                nsplit, kc = ops.splitk_plan(N, kp, M)
+                nsplit, kc = ops.splitk_plan(N, kp, M, dt)
                 gT = ops.transpose(g, rows_pad=nsplit * kc)             # [N, Mp]
                 xT = ops.transpose(_rows(xp), rows_pad=nsplit * kc)     # [kp, Mp]
                 dw = ops.gemm_splitk(gT, xT, nsplit, kc, alpha=alpha)   # [N, kp]

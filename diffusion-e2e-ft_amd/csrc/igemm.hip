@@ -268,7 +268,14 @@ static bool upconv2x_persistent(const E2eftConvDesc* d) {
 }
 
 extern "C" int e2eft_upconv2x_fwd_supported(const E2eftConvDesc* d) {
-    return upconv2x_shape_ok(d) && option(E2EFT_OPT_UPCONV_PHASES) ? 1 : 0;
+    if (!upconv2x_shape_ok(d) || !option(E2EFT_OPT_UPCONV_PHASES)) return 0;
+    if (upconv2x_persistent(d)) return 1;
+    // igemm2 runs the phases as four plain launches: that only beats ONE fused-upsample launch (on igemm6 / igemm5 for 16-bit) when every phase fills the machine —
+    // at 12^2 -> 24^2 with 8 images a phase is 90 workgroups and four of them cost 0.34 ms against 0.14 ms (r05c); same bar as the persistent kernel: two tiles per CU
+    int cus = device_cus();
+    const int gopt = option(E2EFT_OPT_PERSISTENT_GRID);
+    if (gopt >= 8 && gopt < cus) cus = gopt;
+    return cus > 0 && cdiv((long)d->batch * d->hin * d->win, 256) * cdiv(d->cout, 128) >= 2L * cus ? 1 : 0;
 }
 
 extern "C" int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const void* w_phase, const void* bias, void* out, float* gn_partial,

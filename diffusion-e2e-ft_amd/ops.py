@@ -785,10 +785,29 @@ def dgrad_weight_from_packed(pk, cout, taps, cp):
     return out
 
 
-def splitk_plan(M, N, K):
+def splitk_plan(M, N, K, dtype=None, cus=256):
     """(nsplit, kc): weight-gradient GEMMs are [Cout x kh*kw*Cin] outputs contracted over 10^4..10^5 pixels — a handful of output
     tiles.  Split the contraction into nsplit chunks of kc (multiple of 64) columns so that >= ~512 workgroups exist; the
-    operands are zero padded to nsplit*kc columns by their producers (transpose / im2col_t)."""
+    operands are zero padded to nsplit*kc columns by their producers (transpose / im2col_t).
+    fp32 (round 5): the batched GEMM runs on igemm2's 8-wave kernel — 256 x 128 tiles, ONE workgroup per CU — so what matters is whole ROUNDS of `cus`
+    tiles: nsplit is the chunk count (chunks of >= 512 columns) whose tile total fills its last round best (z9 x 30 tiles = 270 on 256 CUs ran two rounds at
+    53 %; 8 or 17 chunks fill theirs to 94 / 99.6 %), the smallest such count among near-ties (fewer partials for the reduction pass)."""
+    if dtype == torch.float32:
+        tiles = ((M + 255) // 256) * ((N + 127) // 128)
+        if tiles * 1 >= cus // 2 and K < 1024:
+            return 1, round_up(K, 64)
+        best = None
+        for ns in range(1, max(1, K // 512) + 1):
+            tot = tiles * ns
+            if tot > 8 * cus and best is not None:
+                break
+            rounds = (tot + cus - 1) // cus
+            eff = tot / (rounds * cus)
+            if best is None or eff > best[0] + 0.02:
+                best = (eff, ns)
+        want = best[1]
+        kc = round_up((K + want - 1) // want, 64)
+        return (K + kc - 1) // kc, kc
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     want = max(1, min((512 + tiles - 1) // tiles, K // 512))
     kc = round_up((K + want - 1) // want, 64)

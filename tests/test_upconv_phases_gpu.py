@@ -83,21 +83,25 @@ def _labels(fn):
     return y, [lab[0] if isinstance(lab, tuple) else lab for (_, lab) in timer.by_label()]
 
 
-@pytest.mark.parametrize("dtype,B,H,W,Ci,Co", [(torch.float32, 2, 24, 24, 32, 64), (torch.float32, 1, 18, 40, 64, 96), (torch.float16, 2, 24, 24, 64, 128),
-                                                (torch.float16, 1, 16, 16, 64, 128), (torch.bfloat16, 1, 9, 13, 128, 64)])
-def test_phases_on_the_general_kernel_fp32_odd_widths_few_tiles(dev, dtype, B, H, W, Ci, Co):
-    """shapes the persistent kernel does not take (fp32; widths that are not multiples of 16; fewer than two tiles per CU) run the four phases on igemm2, whose row
-    passes place every row by division — no statistics there (the consuming GroupNorm runs its own pass)"""
-    from diffusion_e2e_ft_amd import ops
+@pytest.mark.parametrize("dtype,B,H,W,Ci,Co", [(torch.float32, 4, 32, 32, 32, 64), (torch.float32, 6, 24, 40, 64, 128), (torch.float16, 8, 24, 24, 64, 128),
+                                                (torch.bfloat16, 16, 9, 30, 128, 128)])
+def test_phases_on_the_general_kernel_fp32_and_odd_widths(dev, dtype, B, H, W, Ci, Co):
+    """shapes the persistent kernel does not take (fp32; widths that are not multiples of 16) run the four phases on igemm2, whose row passes place every row by
+    division — no statistics there (the consuming GroupNorm runs its own pass).  (Like the persistent route it wants two tiles per CU: the test grid of 8 CUs.)"""
+    from diffusion_e2e_ft_amd import ops, _lib
     from util import TOL
     conv, xd, wd, bd, ref, wph = _case(dev, dtype, B, H, W, Ci, Co, seed=H + W)
-    y, labels = _labels(lambda: ops.conv2d(xd, wd, bd, Co, 3, 3, 1, (1, 1, 1, 1), up_to=(2 * H, 2 * W), gn_stats=True, w_phase=wph))
+    with _lib.option(_lib.OPT_PERSISTENT_GRID, 8):
+        y, labels = _labels(lambda: ops.conv2d(xd, wd, bd, Co, 3, 3, 1, (1, 1, 1, 1), up_to=(2 * H, 2 * W), gn_stats=True, w_phase=wph))
+        y0, labels0 = _labels(lambda: ops.conv2d(xd, wd, bd, Co, 3, 3, 1, (1, 1, 1, 1), up_to=(2 * H, 2 * W), gn_stats=True))      # no phase weights offered: the fused-upsample form
     assert any(str(l).startswith("upconv2x") for l in labels), labels
     assert getattr(y, "_e2eft_gn", None) is None
     assert_close(to_nchw(y), ref, dtype, "phases on igemm2")
-    y0, labels0 = _labels(lambda: ops.conv2d(xd, wd, bd, Co, 3, 3, 1, (1, 1, 1, 1), up_to=(2 * H, 2 * W), gn_stats=True))      # no phase weights offered: the fused-upsample form
     assert not any(str(l).startswith("upconv2x") for l in labels0)
     assert rel_err(to_nchw(y), to_nchw(y0)) <= 2 * TOL[dtype]
+    # the same shape without the test grid: fewer than two tiles per CU of the real machine -> the fused-upsample form, silently
+    y1, labels1 = _labels(lambda: ops.conv2d(xd, wd, bd, Co, 3, 3, 1, (1, 1, 1, 1), up_to=(2 * H, 2 * W), w_phase=wph))
+    assert not any(str(l).startswith("upconv2x") for l in labels1) and rel_err(to_nchw(y1), to_nchw(y0)) <= TOL[dtype]
 
 
 def test_unsupported_shapes_fall_back_and_the_entry_point_says_so(dev):
