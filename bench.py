@@ -503,15 +503,17 @@ def kernel_mix(symbols):
     return mix
 
 
-def pmc_traffic(mix, want):
+def pmc_traffic(mix, want, prof_dir=None, build_id=None):
     """HBM bytes per launch of the dominant family from the PMC counters.  rocprofv3 --pmc cannot wrap its own process, so the counters are
     collected offline on exactly this workload (scripts/pmc_traffic.py) and committed under profiles/ together with the BUILD ID of the library
     they were collected on (`e2eft_build_id()`: hash of csrc/, the headers and the flags) and the launch counts per kernel of the family.  The
     figure is printed only when the committed profile's build id equals the id of the library THIS process runs (round 4 matched launch counts
     only and cited a round-3 profile as "the same build") and the launch counts agree; else null with the reason."""
-    from diffusion_e2e_ft_amd import _lib
-    mine = _lib.build_id()
-    prof = os.path.join(ROOT, "profiles")
+    if build_id is None:
+        from diffusion_e2e_ft_amd import _lib
+        build_id = _lib.build_id()
+    mine = build_id
+    prof = prof_dir or os.path.join(ROOT, "profiles")
     files = sorted((f for f in os.listdir(prof) if f.endswith("_pmc_hbm_traffic.json")), reverse=True) if os.path.isdir(prof) else []
     if not want:
         return None, None, "no PMC profile for this workload", {}

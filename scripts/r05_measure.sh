@@ -21,6 +21,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o p -- 
 cp $(find /tmp/prof_train -name "*kernel_stats.csv" | head -1) $O/${TAG}_train_rocprofv3_kernel_stats.csv
 timeout 300 python bench.py --c4 --steps 10 --warmup 2 > $O/${TAG}_bench_c4_bf16_n1.json 2>/dev/null
 timeout 300 python bench.py --c4 --dtype fp32 --steps 5 --warmup 1 > $O/${TAG}_bench_c4_fp32_n1.json 2>/dev/null
+timeout 300 python bench.py --train --dtype bf16 --grad-ckpt --steps 6 --warmup 2 > $O/${TAG}_bench_train_bf16_ckpt.json 2>/dev/null
+timeout 400 python scripts/loader_bench.py --samples 24 --workers 64 --batch 8 --epochs 4 > $O/${TAG}_loader_bench.json 2> $O/${TAG}_loader_bench.err
 cat $O/${TAG}_build_id.txt; tail -4 $O/${TAG}_gpu_tests.log; tail -2 $O/${TAG}_smoke.log; tail -3 $O/${TAG}_pmc_traffic.log
 python - <<PY
 import json
@@ -31,7 +33,10 @@ print("other", json.dumps({k:(round(v["ms_per_step"],2), round(v.get("tflops",0)
 for k in ("train_step","train_step_fp32","train_step_fp32_ckpt"):
     t=j.get(k,{}); print(k, t.get("value"), t.get("median_ms_per_step"), t.get("peak_mem_gib"), (t.get("roofline") or {}).get("frac"), t.get("error"))
 print("latency", j.get("latency_b1_576x768",{}).get("value"), "geo", j.get("geowizard",{}).get("value"), "cpu", j["cpu_baseline"]["value"], "build", j.get("build_id"))
-for n in ("c4_bf16_n1","c4_fp32_n1"):
+try:
+    l=json.load(open("gpurun_out/${TAG}_loader_bench.json")); print("loader", {k: (round(v.get("images_per_s", v.get("images_per_s_per_core", 0)),1) if isinstance(v, dict) else v) for k,v in l.items() if k in ("reference_cpu","decode_only","device_loader","device_prepare","host_cores","workers")})
+except Exception as e: print("loader failed", e)
+for n in ("c4_bf16_n1","c4_fp32_n1","train_bf16_ckpt"):
     try:
         c=json.load(open("gpurun_out/${TAG}_bench_%s.json"%n)); print(n, c["value"], c.get("median_ms_per_step"), c["peak_mem_gib"])
     except Exception as e: print(n, "failed", e)

@@ -328,10 +328,10 @@ def test_aa_bilinear_tables_are_atens_weights():
         assert bad.mean() < 2e-3 and (np.abs(want[bad] - np.floor(want[bad]) - 0.5) < 1e-3).all()
 
 
-def test_bench_prints_pmc_traffic_only_for_the_profiled_kernel_population():
-    """bench.py's roofline.traffic comes from a committed PMC profile: it must be attached only when the profile's launch counts per kernel of the igemm
-    family equal the run's (the committed bench line of the final build is the example), and the fraction over the launches without a fused GroupNorm
-    must exclude exactly igemm6's NORM symbols"""
+def test_bench_prints_pmc_traffic_only_for_the_profiled_build_and_kernel_population(tmp_path):
+    """bench.py's roofline.traffic comes from a committed PMC profile: it is attached only when the profile was collected ON THE BUILD THAT RUNS (its `build_id` =
+    e2eft_build_id() of the loaded library: VERDICT r4 — round 4 cited a round-3 profile as "the same build" on launch counts alone) AND its launch counts per kernel
+    of the igemm family equal the run's; the fraction over the launches without a fused GroupNorm must exclude exactly igemm6's NORM symbols"""
     import json
     import bench
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -339,11 +339,20 @@ def test_bench_prints_pmc_traffic_only_for_the_profiled_kernel_population():
     symbols = line["roofline"]["by_symbol"]
     mix = bench.kernel_mix(symbols)
     assert mix == {"igemm6_kernel": 62.0, "igemm5_kernel": 74.0, "igemm2_kernel": 126.0, "conv3x3_narrow": 1.0, "conv_thin_in_kernel": 3.0}, mix
-    traffic, source, note, others = bench.pmc_traffic(mix, True)
-    assert source and "r03s_pmc_hbm_traffic.json" in source and abs(traffic - line["roofline"]["traffic"]) < 1.0
+    # the committed round-3 profile carries no build id: never attached any more, whatever the launch counts say
+    t0, s0, n0, _ = bench.pmc_traffic(mix, True, build_id="0123456789abcdef")
+    assert t0 is None and s0 is None and "no committed PMC profile was collected on this build" in n0 and "0123456789abcdef" in n0
+    # the same profile stamped with a build id (what scripts/pmc_traffic.py writes since round 5)
+    prof = json.load(open(os.path.join(root, "profiles", "r03s_pmc_hbm_traffic.json")))
+    prof["build_id"] = "feedfacecafebeef"
+    with open(tmp_path / "r99_pmc_hbm_traffic.json", "w") as f:
+        json.dump(prof, f)
+    traffic, source, note, others = bench.pmc_traffic(mix, True, prof_dir=str(tmp_path), build_id="feedfacecafebeef")
+    assert source and "r99_pmc_hbm_traffic.json" in source and "feedfacecafebeef" in source and abs(traffic - line["roofline"]["traffic"]) < 1.0
     assert "attn_fwd" in others and "gn_apply" in others
+    assert bench.pmc_traffic(mix, True, prof_dir=str(tmp_path), build_id="another0build0id")[0] is None
     for changed in (dict(mix, igemm6_kernel=61.0, igemm5_kernel=75.0), dict(mix, conv_thin_in_kernel=2.0, igemm2_kernel=127.0), {k: v for k, v in mix.items() if k != "conv3x3_narrow"}):
-        t2, s2, n2, _ = bench.pmc_traffic(changed, True)      # same total, another population / one launch missing: no figure
+        t2, s2, n2, _ = bench.pmc_traffic(changed, True, prof_dir=str(tmp_path), build_id="feedfacecafebeef")      # same build, another population / one launch missing: no figure
         assert t2 is None and s2 is None and "no committed PMC profile" in n2, (changed, n2)
     assert bench.pmc_traffic(mix, False)[0] is None           # another workload: never
     extra = bench.plain_launch_fraction(symbols, 2500.0)
