@@ -536,6 +536,9 @@ def pmc_traffic(mix, want, prof_dir=None, build_id=None):
             others = {g: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "launches_per_step": v.get("launches_per_step")} for g, v in pj["kernels"].items() if g != "igemm"}
             return (k["hbm_bytes_per_launch"], "static: profiles/%s (rocprofv3 --pmc passes over this workload on build id %s = the id of the library this run loaded; launches per step %s there and here)"
                     % (fn, mine, {kk: vv for kk, vv in theirs.items() if vv}), pj["source"], others)
+    same_build = [x for x in seen if "build id" not in x and "no launch counts" not in x]
+    if same_build:
+        return None, None, "no committed PMC profile of this build (library id %s) has this run's igemm launches per step %s (%s)" % (mine, {kk: vv for kk, vv in mix.items() if vv}, "; ".join(same_build[:3])), {}
     return None, None, "no committed PMC profile was collected on this build (library id %s; %s)" % (mine, "; ".join(seen[:4])), {}
 
 

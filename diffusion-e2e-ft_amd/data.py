@@ -278,7 +278,7 @@ class VirtualKITTI2(_DecodedDataset):
                 for camera in ("Camera_0", "Camera_1"):
                     rgb_dir, depth_dir, normal_dir = (os.path.join(r, scene, weather, "frames", k, camera) for r, k in zip(roots, ("rgb", "depth", "normal")))
                     if os.path.exists(rgb_dir) and os.path.exists(depth_dir):
-                        for f in os.listdir(rgb_dir):
+                        for f in sorted(os.listdir(rgb_dir)):      # (the reference walks os.listdir's order, which differs between file systems; sorted: reproducible index -> file map)
                             if f.endswith(".jpg"):
                                 stem = f[3:]
                                 pairs.append((os.path.join(rgb_dir, "rgb" + stem), os.path.join(depth_dir, "depth" + stem.replace(".jpg", ".png")),

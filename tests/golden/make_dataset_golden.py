@@ -92,6 +92,7 @@ def run_reference(tmp):
     finally:
         os.chdir(cwd)
     vk = ref.VirtualKITTI2(root_dir=vroot, transform=True)
+    vk.pairs.sort()              # the reference keeps os.listdir's order (file-system dependent); the product sorts: same index -> file map on every box
     rel = lambda p, base: os.path.relpath(p, base)
     out["hypersim_pairs"] = [{k: rel(v, root_dir) for k, v in pr.items()} for pr in hs.pairs]
     out["vkitti_pairs"] = sorted(tuple(rel(p, vroot) for p in pr) for pr in vk.pairs)

@@ -119,11 +119,14 @@ def test_unsupported_shapes_fall_back_and_the_entry_point_says_so(dev):
     out = torch.empty((1, 64, 64, 128), dtype=dtype, device=dev)
     rc = lib.e2eft_upconv2x_fwd(C.byref(d), xd.data_ptr(), xd.data_ptr(), None, out.data_ptr(), None, 0, None, None)
     assert rc == 4 and b"not eligible" in lib.e2eft_last_error()
-    with _lib.option(_lib.OPT_UPCONV_PHASES, 0):      # the switch: supported() answers 0 for an eligible shape
-        conv, xd, wd, bd, ref, wph = _case(dev, dtype, 2, 32, 32, 64, 256, seed=5)
-        d2 = ops._conv_desc(xd, None, 256, 3, 3, 1, (1, 1, 1, 1), (64, 64), 1.0, ldo=256)
-        assert lib.e2eft_upconv2x_fwd_supported(C.byref(d2)) == 0
-    assert lib.e2eft_upconv2x_fwd_supported(C.byref(d2)) == 1
+    conv, xd, wd, bd, ref, wph = _case(dev, dtype, 2, 32, 32, 64, 256, seed=5)
+    d2 = ops._conv_desc(xd, None, 256, 3, 3, 1, (1, 1, 1, 1), (64, 64), 1.0, ldo=256)
+    assert lib.e2eft_upconv2x_fwd_supported(C.byref(d2)) == 0          # 16 tiles per phase: fewer than two per CU of the real machine
+    with _lib.option(_lib.OPT_PERSISTENT_GRID, 8):
+        assert lib.e2eft_upconv2x_fwd_supported(C.byref(d2)) == 1      # ... enough for the 8-CU test grid
+        with _lib.option(_lib.OPT_UPCONV_PHASES, 0):                    # the switch: supported() answers 0 for an eligible shape
+            assert lib.e2eft_upconv2x_fwd_supported(C.byref(d2)) == 0
+        assert lib.e2eft_upconv2x_fwd_supported(C.byref(d2)) == 1
 
 
 def test_vae_decoder_upsampler_at_full_width_runs_in_phases_and_matches(dev):
