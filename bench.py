@@ -54,6 +54,8 @@ def parse():
                     "exposed all-reduce time per gradient slice and the per-micro-step loss all-gather of train.py:559")
     ap.add_argument("--round4-paths", action="store_true", help="A/B: the round-4 forms of what round 5 replaced — fp32 attention as GEMM + softmax launches, 2x-upsample "
                     "convolutions fused into a 3x3 operand fetch (forward) and 3x3 dgrad + fold-back (backward)")
+    ap.add_argument("--no-cross-attn-fold", action="store_true", help="A/B: the two-token cross-attention as q-projection + attention kernel + out-projection (rounds 1-4) "
+                    "instead of its folded form (modules.Attention._fold)")
     ap.add_argument("--modality", default="depth", choices=["depth", "normals"])
     ap.add_argument("--no-direct-grads", action="store_true", help="--train, A/B: FlatAdamW(direct_grads=False) — gradients accumulated by autograd into a cleared flat buffer (round 3) instead of written into it by the backward kernels")
     ap.add_argument("--grad-ckpt", action="store_true", help="--train: activation recompute in the UNet blocks and the frozen decoder "
@@ -73,6 +75,9 @@ def parse():
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B runs: e2eft_set_option before anything is launched (names: scripts/_options.py, e.g. patch_conv=0, fused_norm=0); recorded in the line's config")
     args = ap.parse_args()
+    if args.no_cross_attn_fold:
+        from diffusion_e2e_ft_amd import modules as _M
+        _M.CROSS_ATTN_FOLD = False
     if args.round4_paths:
         from diffusion_e2e_ft_amd import autograd as _F, ops as _ops
         _F.FUSED_FP32_ATTENTION, _F.UPCONV_DGRAD_4X4, _ops.UPCONV_PHASES_ENABLED = False, False, False
@@ -703,6 +708,10 @@ def main():
                        **({"options": args.set_option} if args.set_option else {})},
             "roofline": {"bound": "mfma", "kernel": "igemm6_kernel (persistent, halo-patch 3x3 conv; ten launches also apply the GroupNorm + SiLU of their input) + igemm5_kernel (persistent) + igemm2_kernel + conv_in / conv_out kernels: implicit-GEMM conv/linear, all launches of the timed region",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         # `achieved` counts what the kernels MULTIPLY.  The 2x-upsample convolutions run as four 2x2 phase convolutions (4/9 of the reference
+                         # formulation's multiply-adds); counted in the reference's formulation (SURVEY.md 8d's per-image GFLOP) the family does:
+                         "achieved_reference_formulation": ig.get("flops_nominal", ig["flops"]) / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0,
+                         "frac_reference_formulation": (ig.get("flops_nominal", ig["flops"]) / (ig["ms"] * 1e-3) / 1e12 / peak) if ig["ms"] > 0 else 0.0,
                          "traffic_over_algorithmic": (traffic / alg_bpl) if traffic else None,
                          "traffic_source": traffic_source, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg_bpl,
                          "launches_per_step": lps, "kernel_ms_per_step": ig["ms"] / args.steps,

@@ -78,13 +78,14 @@ __global__ __launch_bounds__(256) void silu_kernel(long n, const T* __restrict__
     for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < n; it += (long)gridDim.x * 256) y[it] = from_f<T>(silu_f(to_f(x[it])));
 }
 
-// y = act(x) on a flat buffer, 16-byte vectors + scalar tail.  kind: 0 quick_gelu x*sigmoid(1.702x) (CLIP), 1 gelu (erf), 2 silu
+// y = act(x) on a flat buffer, 16-byte vectors + scalar tail.  kind: 0 quick_gelu x*sigmoid(1.702x) (CLIP), 1 gelu (erf), 2 silu, 3 sigmoid (the two-key softmax of the folded cross-attention)
 template <typename T>
 __global__ __launch_bounds__(256) void act_kernel(int kind, long n, const T* __restrict__ x, T* __restrict__ y) {
     constexpr int EPC = 16 / (int)sizeof(T);
     auto f = [kind](float v) {
         if (kind == 0) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
         if (kind == 1) return gelu_erf_f(v);
+        if (kind == 3) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
         return silu_f(v);
     };
     const long nv = n / EPC;
@@ -210,7 +211,7 @@ extern "C" int e2eft_silu(int32_t dtype, int64_t n, const void* x, void* y, void
 
 extern "C" int e2eft_activation(int32_t dtype, int32_t kind, int64_t n, const void* x, void* y, void* stream) {
     E2EFT_REQUIRE(x && y && n > 0, "activation: bad args");
-    E2EFT_REQUIRE(kind >= 0 && kind <= 2, "activation: kind %d (0 quick_gelu, 1 gelu, 2 silu)", (int)kind);
+    E2EFT_REQUIRE(kind >= 0 && kind <= 3, "activation: kind %d (0 quick_gelu, 1 gelu, 2 silu, 3 sigmoid)", (int)kind);
     E2EFT_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "activation: buffers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = grid_for(n / 4 + 1);

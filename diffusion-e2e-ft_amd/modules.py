@@ -75,11 +75,16 @@ class TimeCond:
 
 
 class CtxCond:
-    """encoder_hidden_states plus the k | v projections of it for every cross-attention layer from one GEMM (same idea as TimeCond)"""
-    __slots__ = ("ctx", "kv")
+    """encoder_hidden_states plus the k | v projections of it for every cross-attention layer from one GEMM (same idea as TimeCond).
+    shared: every image of the batch attends to the SAME context (the pipelines hand the one empty-prompt embedding to the UNet as a stride-0 expand);
+    `src` is then that one context [1, L, X] as the caller holds it (a stable tensor: the key of Attention._fold's cache)."""
+    __slots__ = ("ctx", "kv", "shared", "src")
 
-    def __init__(self, ctx, kv=None):
-        self.ctx, self.kv = ctx, (kv or {})
+    def __init__(self, ctx, kv=None, shared=False, src=None):
+        self.ctx, self.kv, self.shared, self.src = ctx, (kv or {}), shared, src
+
+
+CROSS_ATTN_FOLD = True     # tests / A-B: False keeps the two-token cross-attention on q-projection + attention kernel + out-projection
 
 
 class Conv2d(nn.Conv2d):
@@ -249,11 +254,16 @@ class Attention(nn.Module):
         d = C // self.heads
         out = self.to_out[0]
         kv_pre = None
+        shared_src = None
         if isinstance(ctx, CtxCond):
             kv_pre = ctx.kv.get(id(self))
+            shared_src = ctx.src if ctx.shared else None
             ctx = ctx.ctx
         if F.needs_grad(x, ctx, self.to_q.weight, self.to_k.weight, self.to_v.weight, out.weight):
             return out(self._forward_train(x, ctx), residual=residual)
+        if (CROSS_ATTN_FOLD and shared_src is not None and shared_src.shape[1] == 2 and not self.joint and self.to_q.bias is None and self.to_k.bias is None
+                and self.to_v.bias is None and self.heads <= 64):
+            return self._folded(x, shared_src, residual)
         fused = F.fused_attention_ok(x.dtype, d)
         dt = x.dtype
         if fused:
@@ -273,6 +283,46 @@ class Attention(nn.Module):
             a = attention_unfused(x, src, cw(self.to_q), F._vec(self.to_q.bias, dt), cw(self.to_k), F._vec(self.to_k.bias, dt), cw(self.to_v),
                                   F._vec(self.to_v.bias, dt), self.heads, self.scale, joint=self.joint)
         return out(a, residual=residual)
+
+    def _fold(self, src, dt):
+        """Cross-attention to TWO context tokens shared by the whole batch (the empty prompt of the E2E-FT path: `<|startoftext|><|endoftext|>`,
+        marigold_pipeline.py:356-369; attention.py:338-343 is then softmax over two keys) collapses algebraically.  Per head h, with k_j / v_j the projected tokens:
+            p1 = softmax([s1, s2])[0] = sigmoid(s1 - s2) = sigmoid(x . g_h),   g_h = scale * Wq[h]^T (k1 - k2)_h            (a C-vector per head)
+            attn_h = v2_h + p1 (v1 - v2)_h,   to_out(attn) = c0 + sum_h p1_h Delta_h,   Delta_h = Wo[:, h] (v1 - v2)_h,  c0 = Wo v2 + b_o
+        i.e. two GEMMs whose inner / outer dimension is the number of HEADS (5 ... 20) instead of C (320 ... 1280) and a sigmoid: no q projection, no attention
+        launch, no out projection — the activation is read once and written once.  -> (G [Hp, C], DeltaT [C, Hp], c0 [C]) in `dt`, built in fp32 once per
+        (context, weights) and cached; Hp = heads padded to a 16-byte multiple with zero rows (sigmoid(0) = 0.5 times a zero row of Delta)."""
+        out = self.to_out[0]
+        ws = [w for w in (self.to_q.weight, self.to_k.weight, self.to_v.weight, out.weight, out.bias) if w is not None]
+        key = (src.data_ptr(), src._version, tuple(src.shape), str(src.device), dt, F._key(*ws))
+        hit = self.__dict__.get("_fold_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        with torch.no_grad():
+            h, C = self.heads, self.to_q.weight.shape[0]
+            d = C // h
+            c32 = src[0].detach().float()                                            # [2, X]
+            k = c32 @ self.to_k.weight.detach().float().t()                         # [2, C]
+            v = c32 @ self.to_v.weight.detach().float().t()
+            dk, dv = (k[0] - k[1]).view(h, d), (v[0] - v[1]).view(h, d)
+            wq = self.to_q.weight.detach().float().view(h, d, C)                    # rows of head h
+            G = self.scale * torch.einsum("hd,hdc->hc", dk, wq)                     # [h, C]
+            wo = out.weight.detach().float().view(C, h, d)
+            delta = torch.einsum("chd,hd->hc", wo, dv)                              # [h, C]
+            c0 = out.weight.detach().float() @ v[1] + (out.bias.detach().float() if out.bias is not None else 0.0)
+            hp = ops.round_up(h, ops.epc(dt))
+            Gp = torch.zeros((hp, C), dtype=torch.float32, device=G.device)
+            Gp[:h] = G
+            Dt = torch.zeros((C, hp), dtype=torch.float32, device=G.device)
+            Dt[:, :h] = delta.t()
+            val = (Gp.to(dt).contiguous(), Dt.to(dt).contiguous(), c0.to(dt).contiguous())
+        self.__dict__["_fold_cache"] = (key, val)
+        return val
+
+    def _folded(self, x, src, residual):
+        G, Dt, c0 = self._fold(src, x.dtype)
+        p = ops.activation(ops.linear(x, G), "sigmoid")                              # [B, N, Hp]
+        return ops.linear(p, Dt, c0, residual=residual)
 
     def _forward_train(self, x, ctx):
         """differentiable path: fused projections -> attention core (autograd.py _AttentionFn)"""

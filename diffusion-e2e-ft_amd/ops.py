@@ -20,15 +20,17 @@ class KernelTimer:
         self.rec = {}
         self.only = only      # None: every instrumented launch; else a set of family names ("igemm", ...): the others run un-instrumented
 
-    def add(self, name, start, end, flops, nbytes, label=None, launches=1):
-        self.rec.setdefault(name, []).append((start, end, flops, nbytes, label, launches))      # launches: kernels of the family behind ONE library call (e2eft_upconv2x_fwd: four)
+    def add(self, name, start, end, flops, nbytes, label=None, launches=1, flops_nominal=None):
+        # flops: what the kernels multiply; flops_nominal: the layer's work in the reference's formulation when that is more (e2eft_upconv2x_fwd multiplies 4/9 of it)
+        self.rec.setdefault(name, []).append((start, end, flops, nbytes, label, launches, flops if flops_nominal is None else flops_nominal))      # launches: kernels of the family behind ONE library call (e2eft_upconv2x_fwd: four)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for name, lst in self.rec.items():
             ms = sum(r[0].elapsed_time(r[1]) for r in lst)
-            out[name] = dict(launches=sum(r[5] for r in lst), ms=ms, flops=float(sum(r[2] for r in lst)), bytes=float(sum(r[3] for r in lst)))
+            out[name] = dict(launches=sum(r[5] for r in lst), ms=ms, flops=float(sum(r[2] for r in lst)), bytes=float(sum(r[3] for r in lst)),
+                             flops_nominal=float(sum(r[6] for r in lst)))
         return out
 
     def by_label(self):
@@ -49,8 +51,8 @@ TIMER = None  # set to a KernelTimer to record
 
 
 class _timed:
-    def __init__(self, name, flops=0.0, nbytes=0.0, label=None, launches=1):
-        self.name, self.flops, self.nbytes, self.label, self.launches = name, flops, nbytes, label, launches
+    def __init__(self, name, flops=0.0, nbytes=0.0, label=None, launches=1, flops_nominal=None):
+        self.name, self.flops, self.nbytes, self.label, self.launches, self.flops_nominal = name, flops, nbytes, label, launches, flops_nominal
 
     def __enter__(self):
         self.on = TIMER is not None and (TIMER.only is None or self.name in TIMER.only)
@@ -66,7 +68,7 @@ class _timed:
             label = self.label
             if self.name == "igemm":     # which kernel symbol the library's dispatch picked for this launch (debug entry, not in e2eft.h)
                 label = (label, _last_kernel())
-            TIMER.add(self.name, self.s, self.e, self.flops, self.nbytes, label, self.launches)
+            TIMER.add(self.name, self.s, self.e, self.flops, self.nbytes, label, self.launches, self.flops_nominal)
         return False
 
 
@@ -292,7 +294,8 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
         if bias is not None:
             assert bias.dtype == x.dtype and bias.numel() == cout and bias.is_contiguous()
         nbp = (B * H * W * c1 + B * hout * wout * cout + 4 * cout * 4 * c1) * x.element_size()
-        with _timed("igemm", 2.0 * B * H * W * 4 * cout * 4 * c1, nbp, label="upconv2x(4 phases) B%d %dx%d %d->%d" % (B, hout, wout, c1, cout), launches=4):
+        with _timed("igemm", 2.0 * B * H * W * 4 * cout * 4 * c1, nbp, label="upconv2x(4 phases) B%d %dx%d %d->%d" % (B, hout, wout, c1, cout), launches=4,
+                    flops_nominal=2.0 * B * hout * wout * cout * 9 * c1):
             buf, nbytes = _gn_buffer(B, hout * wout, cout, x.device) if want else (None, 0)
             slab = C.c_int32(0)
             check(_lib.load().e2eft_upconv2x_fwd(C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), _ptr(buf), nbytes, C.byref(slab), _stream()))
@@ -664,7 +667,7 @@ def silu(x):
     return out
 
 
-ACT_KINDS = {"quick_gelu": 0, "gelu": 1, "silu": 2}
+ACT_KINDS = {"quick_gelu": 0, "gelu": 1, "silu": 2, "sigmoid": 3}
 
 
 def activation(x, kind):

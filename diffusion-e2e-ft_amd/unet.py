@@ -274,7 +274,7 @@ class UNet2DConditionModel(nn.Module):
         m.load_state_dict(load_weights(d, cls.weights_name, variant))
         return m.to(torch_dtype) if torch_dtype is not None else m
 
-    def _batch_small_gemms(self, temb_act, ctx):
+    def _batch_small_gemms(self, temb_act, ctx, shared_src=None):
         """Inference only (no autograd graph).  The 22 `time_emb_proj` Linears (unet_2d_blocks.py: every ResnetBlock2D) all read the same
         [B, 1280] embedding and the 16 cross-attention `to_k` / `to_v` pairs all read the same [B, L, 1024] context: as separate launches
         they are ~40 GEMMs with 8-16 rows, each a 25-30 us latency-bound k-loop on a handful of workgroups (~1 ms of a 112 ms step).
@@ -303,7 +303,9 @@ class UNet2DConditionModel(nn.Module):
                 rows[id(m)] = out[:, o:o + c].contiguous()
                 o += c
             tc = TimeCond(temb_act, rows)
-        if att and dt != torch.float32:
+        from . import modules as _M
+        fold = _M.CROSS_ATTN_FOLD and shared_src is not None and shared_src.shape[1] == 2 and not self.config.joint_attention
+        if att and dt != torch.float32 and not fold:
             ws = tuple(w for m in att for w in (m.to_k.weight, m.to_v.weight))
             kv = F.linear(ctx, ws, owner=self, name="w_ctx_kv_all")      # [B, L, sum 2C]
             kvs, o = {}, 0
@@ -312,6 +314,8 @@ class UNet2DConditionModel(nn.Module):
                 kvs[id(m)] = kv[..., o:o + c2]
                 o += c2
             cc = CtxCond(ctx, kvs)
+        elif fold:
+            cc = CtxCond(ctx, None, shared=True, src=shared_src)       # (no k | v GEMM: the folding layers project the two tokens themselves, once per context)
         return tc, cc
 
     # ---- forward ----
@@ -337,9 +341,12 @@ class UNet2DConditionModel(nn.Module):
                 raise ValueError("class_labels should be provided for class_embed_type='projection'")
             emb = F.add(emb, self.class_embedding(class_labels.to(dt).contiguous()))
         temb_act = F.silu(emb)  # every ResnetBlock2D applies SiLU before its time_emb_proj
-        ctx = encoder_hidden_states.to(dt).contiguous()
+        # one context for the whole batch (the pipelines pass the empty-prompt embedding as a stride-0 expand): cross-attention layers may fold it (modules.Attention._fold)
+        ehs = encoder_hidden_states
+        shared_src = ehs[:1] if (ehs.dim() == 3 and ehs.dtype == dt and (B == 1 or ehs.stride(0) == 0)) else None
+        ctx = ehs.to(dt).contiguous()
         if not torch.is_grad_enabled():
-            temb_act, ctx = self._batch_small_gemms(temb_act, ctx)
+            temb_act, ctx = self._batch_small_gemms(temb_act, ctx, shared_src)
         n_up = len(cfg.block_out_channels) - 1
         forward_upsample_size = any(s % (2 ** n_up) != 0 for s in sample.shape[-2:])
         # 2-3. conv_in, down

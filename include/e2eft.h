@@ -301,7 +301,8 @@ int e2eft_timestep_embedding(int32_t dtype, int32_t batch, int32_t dim, const in
 int e2eft_silu(int32_t dtype, int64_t n, const void* x, void* y, void* stream);
 /* y = act(x) on [n] contiguous, 16-byte aligned.  kind 0: quick_gelu x * sigmoid(1.702 x) — the MLP activation of the CLIP ViT-L/14
  * image encoder on GeoWizard's per-image path (/root/reference/GeoWizard/geowizard/models/geowizard_pipeline.py:232-248, module
- * transformers CLIPVisionModelWithProjection); 1: gelu (erf); 2: silu. */
+ * transformers CLIPVisionModelWithProjection); 1: gelu (erf); 2: silu; 3: sigmoid (softmax over TWO keys = sigmoid of the score difference: the cross-attention
+ * to the two-token empty prompt, modules.Attention._fold). */
 int e2eft_activation(int32_t dtype, int32_t kind, int64_t n, const void* x, void* y, void* stream);
 /* Depth head: decoder output NHWC [pixels, ldx>=3] -> depth[pixels].  to_unit 0: clip(mean_c(x), -1, 1) (train.py:533-534);
  * 1: the same mapped to [0, 1] by * 0.5 + 0.5 (marigold_pipeline.py:518,476-477); 2: the bare channel mean that
