@@ -281,8 +281,11 @@ class UNet2DConditionModel(nn.Module):
         Here each family is ONE GEMM over the weights concatenated along the output dimension (the same dot products, element for
         element); the consumers pick up their slice (`ResnetBlock2D.nhwc`, `Attention.forward`)."""
         from .modules import ResnetBlock2D, Attention
+        from . import modules as _M
+        # a two-token context shared by the whole batch: the cross-attention layers fold it (modules.Attention._fold) — independent of the batching switch below
+        fold = _M.CROSS_ATTN_FOLD and shared_src is not None and shared_src.shape[1] == 2 and not self.config.joint_attention
         if not BATCHED_PROJECTIONS:    # A/B switch
-            return temb_act, ctx
+            return temb_act, (CtxCond(ctx, None, shared=True, src=shared_src) if fold else ctx)
         dt = temb_act.dtype
         fam = self.__dict__.get("_small_gemm_family")
         if fam is None:
@@ -303,8 +306,6 @@ class UNet2DConditionModel(nn.Module):
                 rows[id(m)] = out[:, o:o + c].contiguous()
                 o += c
             tc = TimeCond(temb_act, rows)
-        from . import modules as _M
-        fold = _M.CROSS_ATTN_FOLD and shared_src is not None and shared_src.shape[1] == 2 and not self.config.joint_attention
         if att and dt != torch.float32 and not fold:
             ws = tuple(w for m in att for w in (m.to_k.weight, m.to_v.weight))
             kv = F.linear(ctx, ws, owner=self, name="w_ctx_kv_all")      # [B, L, sum 2C]

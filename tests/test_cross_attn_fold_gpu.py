@@ -81,13 +81,13 @@ def test_unet_folds_a_stride0_context_and_not_a_materialised_one(dev):
             a = unet(x, t, ctx1.expand(2, -1, -1)).sample
             torch.cuda.synchronize()
             ops.TIMER = None
-            n_attn_folded = sum(v["launches"] for (name, lab), v in timer.by_label().items() if name == "attn" and "Nk2" in str(lab))
+            n_attn_folded = sum(v["launches"] for (name, lab), v in timer.by_label().items() if name == "attn" and str(lab).endswith("Nk2"))
             timer = ops.KernelTimer()
             ops.TIMER = timer
             b = unet(x, t, ctx1.repeat(2, 1, 1)).sample
             torch.cuda.synchronize()
             ops.TIMER = None
-            n_attn_plain = sum(v["launches"] for (name, lab), v in timer.by_label().items() if name == "attn" and "Nk2" in str(lab))
+            n_attn_plain = sum(v["launches"] for (name, lab), v in timer.by_label().items() if name == "attn" and str(lab).endswith("Nk2"))
         assert rel_err(a, b) <= tol, (dtype, rel_err(a, b))
         if dtype != torch.float32:
             assert n_attn_folded == 0 and n_attn_plain > 0, (n_attn_folded, n_attn_plain)

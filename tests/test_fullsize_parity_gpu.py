@@ -129,7 +129,7 @@ def test_batched_time_and_context_projections_are_bit_identical(dev, models, dty
         fam = m.__dict__["_small_gemm_family"]
         assert len(fam[0]) == 22 and len(fam[1]) == 16
         assert all(not any(k.startswith(("_rowadd", "_kv")) for k in r.__dict__) for r in fam[0] + fam[1])   # the slices travel as call arguments: nothing parked on a module
-        m._batch_small_gemms = lambda temb_act, ctx_: (temb_act, ctx_)
+        m._batch_small_gemms = lambda temb_act, ctx_, *unused: (temb_act, ctx_)
         b = m(x, 999, c).sample
     assert torch.isfinite(a.float()).all() and torch.equal(a, b)
 
