@@ -10,6 +10,7 @@ import torch.nn.functional as TF
 from util import assert_close, nhwc, pack_conv_weight, q, rel_err, to_nchw
 
 pytestmark = pytest.mark.gpu
+GRID_FROM_ENV = "E2EFT_TEST_PERSISTENT_GRID" in __import__("os").environ      # tests/conftest.py: the whole-suite variant that sends small problems through the persistent kernels
 
 
 def _launches():
@@ -99,6 +100,8 @@ def test_phases_on_the_general_kernel_fp32_and_odd_widths(dev, dtype, B, H, W, C
     assert_close(to_nchw(y), ref, dtype, "phases on igemm2")
     assert not any(str(l).startswith("upconv2x") for l in labels0)
     assert rel_err(to_nchw(y), to_nchw(y0)) <= 2 * TOL[dtype]
+    if GRID_FROM_ENV:
+        return          # (a process-wide test grid — the suite's E2EFT_TEST_PERSISTENT_GRID variant — leaves no "real machine" to fall back on)
     # the same shape without the test grid: fewer than two tiles per CU of the real machine -> the fused-upsample form, silently
     y1, labels1 = _labels(lambda: ops.conv2d(xd, wd, bd, Co, 3, 3, 1, (1, 1, 1, 1), up_to=(2 * H, 2 * W), w_phase=wph))
     assert not any(str(l).startswith("upconv2x") for l in labels1) and rel_err(to_nchw(y1), to_nchw(y0)) <= TOL[dtype]
@@ -121,7 +124,8 @@ def test_unsupported_shapes_fall_back_and_the_entry_point_says_so(dev):
     assert rc == 4 and b"not eligible" in lib.e2eft_last_error()
     conv, xd, wd, bd, ref, wph = _case(dev, dtype, 2, 32, 32, 64, 256, seed=5)
     d2 = ops._conv_desc(xd, None, 256, 3, 3, 1, (1, 1, 1, 1), (64, 64), 1.0, ldo=256)
-    assert lib.e2eft_upconv2x_fwd_supported(C.byref(d2)) == 0          # 16 tiles per phase: fewer than two per CU of the real machine
+    if not GRID_FROM_ENV:
+        assert lib.e2eft_upconv2x_fwd_supported(C.byref(d2)) == 0      # 16 tiles per phase: fewer than two per CU of the real machine
     with _lib.option(_lib.OPT_PERSISTENT_GRID, 8):
         assert lib.e2eft_upconv2x_fwd_supported(C.byref(d2)) == 1      # ... enough for the 8-CU test grid
         with _lib.option(_lib.OPT_UPCONV_PHASES, 0):                    # the switch: supported() answers 0 for an eligible shape
