@@ -33,20 +33,28 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build libe2eft.so for gfx950)")
 
 
+HEADERS = ["common.h", "igemm.h", "attn512_regs.inc", "igemm_persistent_epilogue.inc"]      # csrc files that are included, not compiled
+
+
+def _inputs():
+    """every file that determines the binary: the compiled sources, the included csrc files, the public headers — by NAME (a stray editor backup or a
+    subdirectory in csrc/ changes nothing and breaks nothing; tests/test_host_logic.py checks that no csrc file is missing from these lists)"""
+    inc = os.path.join(HERE, "..", "include")
+    return [os.path.join(CSRC, f) for f in sorted(SOURCES + HEADERS)] + [os.path.join(inc, "e2eft.h"), os.path.join(inc, "e2eft_debug.h")]
+
+
 def _newest_source_mtime():
-    paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "e2eft.h"), os.path.join(HERE, "..", "include", "e2eft_debug.h"), os.path.abspath(__file__)]
-    return max(os.path.getmtime(p) for p in paths)
+    return max(os.path.getmtime(p) for p in _inputs() + [os.path.abspath(__file__)])
 
 
 ID_MARK = b"E2EFT_BUILD_ID="      # api.hip embeds "E2EFT_BUILD_ID=<16 hex>" in the binary: the id can be read without loading the library
 
 
 def source_id():
-    """sha256 (first 16 hex digits) over everything that determines the binary: every file of csrc/, the public headers, the flags.  Stamped into the
+    """sha256 (first 16 hex digits) over everything that determines the binary: the sources and included files of csrc/ (by name), the public headers, the flags.  Stamped into the
     library (-DE2EFT_BUILD_ID, `e2eft_build_id()`); a measurement made with one build and quoted by another process carries it."""
     h = hashlib.sha256()
-    inc = os.path.join(HERE, "..", "include")
-    for path in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(inc, "e2eft.h"), os.path.join(inc, "e2eft_debug.h")]:
+    for path in _inputs():
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as f:
             h.update(f.read())
@@ -76,16 +84,30 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    hipcc = _hipcc()
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
+    # one builder at a time per tree: under a multi-rank launch every rank may find the library stale at once (`_lib.load()` rebuilds on an id mismatch)
+    # and would run hipcc into the same build/ and lib/ directories; the others wait on the lock and then find the library current
+    import fcntl
+    with open(os.path.join(OBJDIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
+    hipcc = _hipcc()
     sid = source_id()
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
         stamp = ['-DE2EFT_BUILD_ID="%s"' % sid] if src == "api.hip" else []      # api.hip carries the id: it is recompiled on every build (2 s)
-        deps = [srcp, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm.h"), os.path.join(CSRC, "attn512_regs.inc"), os.path.join(CSRC, "igemm_persistent_epilogue.inc"), os.path.join(HERE, "..", "include", "e2eft.h"), os.path.join(HERE, "..", "include", "e2eft_debug.h"), os.path.abspath(__file__)]
+        deps = [srcp] + [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(HERE, "..", "include", "e2eft.h"), os.path.join(HERE, "..", "include", "e2eft_debug.h"), os.path.abspath(__file__)]
         if not force and not stamp and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(d) for d in deps):
             return obj
         cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + stamp + ["-c", srcp, "-o", obj]

@@ -322,7 +322,7 @@ def _to_tensor(u8):
 class DeviceLoader:
     """`torch.utils.data.DataLoader(dataset, shuffle=True, batch_size=B, num_workers=0)` (train.py:364-365) for Hypersim / VirtualKITTI2 above, with the
     work split MI355X-first: indices from torch's own RandomSampler / BatchSampler (the reference's order for the same torch RNG state), the flip coin
-    per sample from Python's `random` in sample order (load.py:76,134), files decoded by `workers` threads `prefetch` batches ahead, one pinned staging
+    per sample from Python's `random` in sample order (load.py:76,134; for ONE loader: see `__iter__`), files decoded by `workers` threads `prefetch` batches ahead, one pinned staging
     buffer set per in-flight batch, upload + `finish_samples` on a side stream so that both hide under the training step.  Iterating yields batch dicts
     on `device` (the consumer's current stream waits for the batch's event)."""
 
@@ -373,10 +373,18 @@ class DeviceLoader:
         return iter(self._batches)
 
     def __iter__(self):
+        """`iter(loader)` draws the iterator's `base_seed` EAGERLY, as `DataLoader.__iter__` does (torch's `_BaseDataLoaderIter.__init__`); the permutation seed is
+        drawn by the sampler at the first `next()`.  So `MixedDataLoader`'s `iter(loader1), iter(loader2)` followed by interleaved `next()` calls consumes torch's
+        RNG in the reference's order.  What does NOT carry over to mixed loaders is the flip coin: the reference draws it inside `__getitem__` at
+        `next()` time from the global `random`, this loader draws it `prefetch` batches ahead — a single loader reproduces the reference's sequence, two
+        interleaved loaders reproduce it only in distribution."""
+        it = self.index_batches()
+        return self._generate(it)
+
+    def _generate(self, it):
         if self._pool is None:
             self._pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="e2eft-decode")
         pending = []          # [(futures of one batch, flips)]
-        it = self.index_batches()
 
         def submit():
             idx = next(it, None)

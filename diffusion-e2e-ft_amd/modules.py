@@ -299,24 +299,32 @@ class Attention(nn.Module):
         if hit is not None and hit[0] == key:
             return hit[1]
         with torch.no_grad():
+            # fp32 through the library's own exact-fp32 MFMA GEMM (ops.gemm): no vendor BLAS anywhere in an inference process
             h, C = self.heads, self.to_q.weight.shape[0]
             d = C // h
-            c32 = src[0].detach().float()                                            # [2, X]
-            k = c32 @ self.to_k.weight.detach().float().t()                         # [2, C]
-            v = c32 @ self.to_v.weight.detach().float().t()
-            dk, dv = (k[0] - k[1]).view(h, d), (v[0] - v[1]).view(h, d)
-            wq = self.to_q.weight.detach().float().view(h, d, C)                    # rows of head h
-            G = self.scale * torch.einsum("hd,hdc->hc", dk, wq)                     # [h, C]
-            wo = out.weight.detach().float().view(C, h, d)
-            delta = torch.einsum("chd,hd->hc", wo, dv)                              # [h, C]
-            c0 = out.weight.detach().float() @ v[1] + (out.bias.detach().float() if out.bias is not None else 0.0)
+            f32 = lambda w: w.detach().float().contiguous()
+            wq, wk, wv, wo = f32(self.to_q.weight), f32(self.to_k.weight), f32(self.to_v.weight), f32(out.weight)
+            c32 = f32(src[0])                                                        # [2, X]
+            k = ops.gemm(c32, wk)                                                    # [2, C]
+            v = ops.gemm(c32, wv)
+            # per-head contractions as ONE GEMM each: row h of a block-diagonal [h, C] matrix carries (k1 - k2)_h / (v1 - v2)_h in head h's columns
+            ar = torch.arange(h, device=k.device)
+            Mk = torch.zeros((h, h, d), dtype=torch.float32, device=k.device)
+            Mv = torch.zeros((h, h, d), dtype=torch.float32, device=k.device)
+            Mk[ar, ar] = (k[0] - k[1]).view(h, d) * self.scale
+            Mv[ar, ar] = (v[0] - v[1]).view(h, d)
+            G = ops.gemm(Mk.view(h, C), wq.t().contiguous())                         # [h, C]: G[h, c] = scale * sum_d (k1 - k2)[h, d] Wq[(h, d), c]
+            delta = ops.gemm(Mv.view(h, C), wo)                                      # [h, C]: Delta[h, c] = sum_d Wo[c, (h, d)] (v1 - v2)[h, d]
+            c0 = ops.gemm(v[1:2].contiguous(), wo, f32(out.bias) if out.bias is not None else None)[0]
             hp = ops.round_up(h, ops.epc(dt))
             Gp = torch.zeros((hp, C), dtype=torch.float32, device=G.device)
             Gp[:h] = G
             Dt = torch.zeros((C, hp), dtype=torch.float32, device=G.device)
             Dt[:, :h] = delta.t()
             val = (Gp.to(dt).contiguous(), Dt.to(dt).contiguous(), c0.to(dt).contiguous())
-        self.__dict__["_fold_cache"] = (key, val)
+        # the entry keeps `src` ALIVE: the key holds its address, and the caching allocator hands a freed address to the next tensor of that size
+        # (two different fresh [1, 2, X] contexts on successive calls would otherwise hit a stale entry)
+        self.__dict__["_fold_cache"] = (key, val, src)
         return val
 
     def _folded(self, x, src, residual):

@@ -528,7 +528,9 @@ class EMAModel:
         self.cur_decay_value = decay
         omd = 1 - decay
         src = self._flat_source(parameters) if self._shadow_flat is not None else None
-        if src is not None and src[1].numel() == self._shadow_flat.numel():
+        # the one-launch form updates EVERY slot; diffusers copies a parameter that does not require a gradient instead of averaging it (below):
+        # the flat kernel therefore runs only when every parameter of the buffer is trainable
+        if src is not None and src[1].numel() == self._shadow_flat.numel() and all(p.requires_grad for p in parameters):
             with ops.on_device_of(src[1]):
                 ops.ema_step_(self._shadow_flat, src[1], omd)
             return
@@ -561,7 +563,15 @@ class EMAModel:
             raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
         parameters = list(parameters)
         if isinstance(self.temp_stored_params, torch.Tensor):
-            self._flat_source(parameters)[1].copy_(self.temp_stored_params)
+            src = self._flat_source(parameters)
+            if src is not None and src[1].numel() == self.temp_stored_params.numel():
+                src[1].copy_(self.temp_stored_params)
+            else:   # `parameters` are not (any more) the optimizer's list in its order: per-slot copies out of the stored flat buffer, in the stored order
+                owner = self._flat[0]
+                if len(parameters) != len(owner.params):
+                    raise ValueError("restore(): %d parameters were stored, %d given" % (len(owner.params), len(parameters)))
+                for i, param in enumerate(parameters):
+                    param.data.copy_(owner._slot(self.temp_stored_params, i))
         else:
             for c_param, param in zip(self.temp_stored_params, parameters):
                 param.data.copy_(c_param.data)
@@ -629,10 +639,12 @@ def lr_lambda_for_world(lr_total_iter_length, lr_exp_warmup_steps, num_processes
     return IterExponential(total_iter_length=lr_total_iter_length * num_processes, final_ratio=final_ratio, warmup_steps=lr_exp_warmup_steps * num_processes)
 
 
-def train_step(unet, vae, optimizer, batches, empty_encoding, modality="depth", lr_scale=1.0, gather_loss=False):
+def train_step(unet, vae, optimizer, batches, empty_encoding, modality="depth", lr_scale=1.0, gather_loss=False, train_batch_size=1):
     """One optimizer step over `batches` (a list of micro-batches = gradient accumulation, train.py:470,559-566): returns the
     mean micro-loss as a device tensor.  gather_loss=True: every micro-step's loss is averaged over the ranks as train.py:559 does for logging
-    (`dist.gather_mean`: one small all-gather per micro-step, no host synchronisation)."""
+    (`dist.gather_mean`: one small all-gather per micro-step, no host synchronisation).  train_batch_size: the CONFIGURED per-rank batch size the
+    reference repeats the loss by (`args.train_batch_size`, a constant — never the size of the batch at hand: a ragged last batch would make the ranks'
+    all-gather sizes differ; the repeat does not change the mean)."""
     from . import dist as D
     n = len(batches)
     total = None
@@ -641,7 +653,7 @@ def train_step(unet, vae, optimizer, batches, empty_encoding, modality="depth", 
         loss = e2e_ft_loss(unet, vae, batch, empty_encoding, modality)
         (loss / n).backward()
         if gather_loss:
-            loss = D.gather_mean(loss, batch["rgb"].shape[0])
+            loss = D.gather_mean(loss, train_batch_size)
         total = loss.detach() if total is None else total + loss.detach()
     optimizer.step(lr_scale=lr_scale)
     optimizer.zero_grad()

@@ -60,6 +60,31 @@ def test_folded_cross_attention_matches_float64_and_the_unfolded_route(dev, dtyp
     assert rel_err(y3, _ref(att, x.float(), ctx1.float(), res.float()).float()) <= tol
 
 
+def test_fold_cache_cannot_go_stale_when_a_fresh_context_reuses_the_address(dev):
+    """the fold is cached under the context tensor's (address, version, shape); factory-made tensors all have version 0 and the caching allocator hands
+    a freed block to the next tensor of that size, so the cache entry has to keep the context ALIVE.  Ten different fresh [1, 2, X] contexts in a row, each
+    dropped before the next is made: every output must be the one of ITS context (and no two of the contexts may share an address while the cache holds one)."""
+    from diffusion_e2e_ft_amd import modules as M
+    torch.manual_seed(0)
+    heads, C, N = 5, 320, 64
+    att = M.Attention(C, heads=heads, cross_attention_dim=1024).to(dev, torch.float32).eval()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, N, C, generator=g).to(dev)
+    res = torch.zeros(1, N, C, device=dev)
+    held = None
+    for i in range(10):
+        c_host = 0.5 * torch.randn(1, 2, 1024, generator=g)
+        ctx1 = c_host.to(dev)                                  # fresh tensor, _version 0
+        assert held is None or ctx1.data_ptr() != held        # the previous context is still referenced by the cache: its block was not recycled
+        with torch.no_grad():
+            y = att(x, M.CtxCond(ctx1, None, shared=True, src=ctx1), residual=res)
+        torch.cuda.synchronize()
+        e = rel_err(y, _ref(att, x, c_host, res).float())
+        assert e <= 1e-5, (i, e)
+        held = ctx1.data_ptr()
+        del ctx1
+
+
 def test_unet_folds_a_stride0_context_and_not_a_materialised_one(dev):
     """the UNet recognises the shared context by its stride-0 batch dimension (what the pipelines pass); a per-image context of the same values takes the
     attention kernels — the two outputs agree inside the fp16 bar, and the fp32 pair to 1e-5"""

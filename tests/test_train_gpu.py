@@ -507,6 +507,48 @@ def test_ema_on_the_flat_buffer(dev):
         assert training.e2e_ft_loss(unet, vae, batch, text, "depth").item() == live_loss
 
 
+def test_ema_frozen_parameters_are_copied_and_restore_survives_a_reordered_list(dev):
+    """(i) diffusers' EMAModel.step COPIES a parameter that does not require a gradient (it only averages trainable ones) — the one-launch flat
+    form averages every slot, so it must step aside when a parameter of the buffer is frozen; (ii) `restore()` with a parameter list that is not the
+    optimizer's own list object order (here: reversed) falls back to per-slot copies instead of failing."""
+    from diffusion_e2e_ft_amd import training
+    unet, _ = _models(dev)
+    opt = training.FlatAdamW(unet.parameters(), lr=1e-3)
+    params = list(unet.parameters())
+    ema = training.EMAModel(params, decay=0.5)
+    frozen = params[3]
+    frozen.requires_grad_(False)
+    with torch.no_grad():
+        opt.flat_param.mul_(1.5)
+    ref = [s_.detach().clone() for s_ in ema.shadow_params]
+    ema.step(params)
+    ema.step(params)                       # second step: decay = min(2 / 11, 0.5) > 0, so averaging and copying differ
+    decay = ema.cur_decay_value
+    assert 0.0 < decay < 1.0
+    torch.cuda.synchronize()
+    for i, (s_, r, p) in enumerate(zip(ema.shadow_params, ref, params)):
+        if p is frozen:
+            assert torch.equal(s_, p.detach()), i
+        else:
+            want = r.clone()
+            want.sub_(1.0 * (want - p.detach()))                  # step 1: decay 0
+            want.sub_((1 - decay) * (want - p.detach()))          # step 2
+            assert torch.equal(s_, want), i
+    frozen.requires_grad_(True)
+    live = opt.flat_param.detach().clone()
+    ema.store(params)
+    ema.copy_to(params)
+    assert not torch.equal(opt.flat_param, live)
+    ema.restore(list(params))              # the same parameters through a NEW list object: the flat path
+    assert torch.equal(opt.flat_param, live)
+    ema.store(params)
+    ema.copy_to(params)
+    other = [torch.nn.Parameter(torch.empty_like(p)) for p in params]      # parameters that do not live in the buffer: per-slot copies
+    ema.restore(other)
+    for o, want in zip(other, (opt._slot(live, i) for i in range(len(params)))):
+        assert torch.equal(o.detach(), want)
+
+
 @pytest.mark.parametrize("cdt,ckpt", [(torch.bfloat16, False), (torch.float32, False), (torch.bfloat16, True)], ids=["bf16", "fp32", "bf16_recompute"])
 def test_gradients_are_born_in_the_flat_buffer_and_steps_are_bit_equal(dev, cdt, ckpt):
     """FlatAdamW(direct_grads=True) (round 4): after zero_grad() every .grad is None, the backward kernels' reductions write each parameter's first gradient of
