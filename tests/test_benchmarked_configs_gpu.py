@@ -86,13 +86,15 @@ def test_config1_batch8_768_fp16_every_image_against_oracle(dev, marigold_fp16, 
         e = rel_err(depth[i:i + 1], want_d)
         mae = (depth[i:i + 1] - want_d).abs().mean().item()
         # fp16 drift where the north star defines parity: x0 latent against the fp32 oracle's, max-abs / max-ref and relative L2.
-        # The fp32 product meets 1e-3 on this quantity (test_fullsize_parity_gpu.py: 5e-6 measured); fp16 storage with fp32 accumulation is a STATED looser bar.
+        # The fp32 product meets 1e-3 on this quantity at this resolution (test_fullsize_parity_gpu.py::test_config1_768_fp32_latent_and_depth: 7.2e-6 measured);
+        # fp16 storage with fp32 accumulation is a STATED looser bar.
         lat = rel_err(latent[i:i + 1], x0)
         lat2 = ((latent[i:i + 1] - x0).norm() / x0.norm()).item()
         print("configs[1] batch 8, image %d: x0 latent max rel err %.3e, rel L2 %.3e; depth max rel err %.3e, mean abs err %.3e; normals mean angle %.3f deg" % (i, lat, lat2, e, mae, ang))
         assert e <= 2e-2 and mae <= 2e-3, (i, e, mae)
         assert ang <= 1.0, (i, ang)
-        assert lat <= 3e-2 and lat2 <= 1.5e-2, (i, lat, lat2)
+        # bars = 2 x the worst image measured on the round-6 build (profiles/r06a_parity_768_tests.log: max-abs / max 3.24e-3, relative L2 2.61e-3)
+        assert lat <= 6.5e-3 and lat2 <= 5.2e-3, (i, lat, lat2)
         worst = dict(e=max(worst["e"], e), mae=max(worst["mae"], mae), ang=max(worst["ang"], ang), lat=max(worst["lat"], lat), lat2=max(worst["lat2"], lat2))
     print("configs[1] batch 8 worst image: x0 latent max rel err %.3e (rel L2 %.3e), depth max rel err %.3e, mean abs err %.3e, normals mean angle %.3f deg"
           % (worst["lat"], worst["lat2"], worst["e"], worst["mae"], worst["ang"]))

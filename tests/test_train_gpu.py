@@ -521,19 +521,22 @@ def test_ema_frozen_parameters_are_copied_and_restore_survives_a_reordered_list(
     with torch.no_grad():
         opt.flat_param.mul_(1.5)
     ref = [s_.detach().clone() for s_ in ema.shadow_params]
-    ema.step(params)
-    ema.step(params)                       # second step: decay = min(2 / 11, 0.5) > 0, so averaging and copying differ
+    p1 = [p.detach().clone() for p in params]
+    ema.step(params)                       # step 1: decay 0 (the shadow takes the parameters)
+    with torch.no_grad():
+        opt.flat_param.mul_(0.5)           # the parameters move on, so that averaging and copying differ in step 2
+    ema.step(params)                       # step 2: decay = min(2 / 11, 0.5) > 0
     decay = ema.cur_decay_value
     assert 0.0 < decay < 1.0
     torch.cuda.synchronize()
-    for i, (s_, r, p) in enumerate(zip(ema.shadow_params, ref, params)):
+    for i, (s_, r, a, p) in enumerate(zip(ema.shadow_params, ref, p1, params)):
         if p is frozen:
             assert torch.equal(s_, p.detach()), i
         else:
             want = r.clone()
-            want.sub_(1.0 * (want - p.detach()))                  # step 1: decay 0
+            want.sub_(1.0 * (want - a))                           # step 1
             want.sub_((1 - decay) * (want - p.detach()))          # step 2
-            assert torch.equal(s_, want), i
+            assert torch.equal(s_, want) and not torch.equal(s_, p.detach()), i
     frozen.requires_grad_(True)
     live = opt.flat_param.detach().clone()
     ema.store(params)
