@@ -316,7 +316,8 @@ extern "C" int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const v
         int rc;
         if (pers) {
             p.mtiles = p.M / 256; p.ntiles = cdiv(p.N, 128);
-            rc = launch_igemm_persistent(d->dtype, 1, p, 1, (hipStream_t)stream);
+            rc = launch_igemm_patch(d->dtype, 1, p, 1, (hipStream_t)stream);      // round 6: 2x2-tap halo-patch kernel (8 x 32-pixel tiles; same 256-row statistics slabs)
+            if (rc < 0) rc = launch_igemm_persistent(d->dtype, 1, p, 1, (hipStream_t)stream);
             if (rc < 0) return fail(E2EFT_ERR_UNSUPPORTED, "upconv2x: the persistent kernel declined phase %d", ph);
         } else {
             rc = launch_igemm_v2(d->dtype, 1, p, 1, (hipStream_t)stream);

@@ -39,20 +39,30 @@ namespace e2eft {
 
 namespace patchk {
 constexpr int BM = 256, BN = 128, NW = 8;
-constexpr int TH = 8, TW = 32, PW = TW + 2, PROWS = (TH + 2) * PW;     // 340 patch rows
-constexpr int PPIECES = (PROWS + 7) / 8;                                // 43 one-KiB pieces
-constexpr int PATCH = PPIECES * 1024;                                   // 44,032 B
+constexpr int TH = 8, TW = 32;
 constexpr int B_STAGE = BN * 128;
-constexpr int OFF_B = 2 * PATCH;
-constexpr int OFF_DEP = OFF_B + 3 * B_STAGE;
 constexpr int DEP = NW * 64 * 3 * 4;
-constexpr int OFF_DUMP = OFF_DEP + DEP;
-constexpr int LDS = OFF_DUMP + NW * 1024;                               // 151,552 B
 constexpr int NORM_CMAX = 640;                                          // NORM: input channels the (a, mean, beta) table of one image holds
-constexpr int OFF_TAB = LDS, OFF_TABM = OFF_TAB + NORM_CMAX * 4, OFF_TABB = OFF_TABM + NORM_CMAX * 4;   // a[C], mean[C], beta[C] (fp32) of the loader's image
-constexpr int LDS_NORM = OFF_TABB + NORM_CMAX * 4;                      // 159,232 B
 constexpr unsigned int OOB = 0xF0000000u;
 constexpr unsigned int RECORDS = 0xE0000000u;
+// KT x KT taps (3: the 3x3 / pad-1 convolutions; 2: round 6, the 2x2 parity phases of the 2x-upsampler convolutions, e2eft_upconv2x_fwd)
+template <int KT> struct Geo {
+    static constexpr int NT = KT * KT;                                      // k-tiles per 64-channel chunk
+    static constexpr int PW = TW + KT - 1, PH = TH + KT - 1, PROWS = PH * PW;   // 340 (3x3) / 297 (2x2) patch rows
+    static constexpr int PPIECES = (PROWS + 7) / 8;                         // 43 / 38 one-KiB pieces
+    static constexpr int NPI = (PPIECES + NW - 1) / NW;                     // pieces per wave: 6 / 5
+    static constexpr int PATCH = PPIECES * 1024;                            // 44,032 / 38,912 B
+    static constexpr int OFF_B = 2 * PATCH;
+    static constexpr int OFF_DEP = OFF_B + 3 * B_STAGE;
+    static constexpr int OFF_DUMP = OFF_DEP + DEP;
+    static constexpr int LDS = OFF_DUMP + NW * 1024;                        // 151,552 / 141,312 B
+    static constexpr int OFF_TAB = LDS, OFF_TABM = OFF_TAB + NORM_CMAX * 4, OFF_TABB = OFF_TABM + NORM_CMAX * 4;   // a[C], mean[C], beta[C] (fp32) of the loader's image
+    static constexpr int LDS_NORM = OFF_TABB + NORM_CMAX * 4;               // 159,232 B
+    // A pieces a wave issues in k-tile t of a chunk (the next chunk's patch): 3x3 — one in k-tiles 0-5; 2x2 — two in k-tiles 0 and 1, one in k-tile 2.  Never in the
+    // chunk's LAST k-tile: the wait that closes it may leave only that k-tile's own two weight pieces in flight (the next chunk reads the patch right after it)
+    static constexpr int a_count(int t) { return KT == 3 ? (t < 6 ? 1 : 0) : (t < 2 ? 2 : t == 2 ? 1 : 0); }
+    static constexpr int a_first(int t) { return KT == 3 ? t : 2 * t; }
+};
 }  // namespace patchk
 
 template <typename T> struct Mma6;
@@ -81,10 +91,14 @@ __device__ __forceinline__ int fast_div6(int n, int d) {   // float estimate + o
 // NORM: the input is read through GroupNorm(+SiLU) — the statistics exist (e2eft_groupnorm_fwd_stats), the apply pass does not: every lane normalises, in
 // place in LDS, exactly the 16-byte units of the patch it fetched itself (k-tile t of a chunk: piece t - 2, landed since the previous k-tile's wait), with the
 // arithmetic of gn_apply_kernel (norm.hip) — the convolution's result is bit-identical to GroupNorm followed by igemm6.  Padding rows stay zero.
-template <typename T, bool RES, bool NORM>
+template <typename T, bool RES, bool NORM, int KT>
 __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const int total_tiles) {
     using namespace patchk;
-    __shared__ __attribute__((aligned(128))) char smem[NORM ? LDS_NORM : LDS];
+    using G = Geo<KT>;
+    static_assert(KT == 3 || (KT == 2 && !NORM), "taps: 3x3, or 2x2 without the fused GroupNorm");
+    constexpr int NT = G::NT, PW = G::PW, PROWS = G::PROWS, PPIECES = G::PPIECES, NPI = G::NPI, PATCH = G::PATCH, OFF_B = G::OFF_B, OFF_DEP = G::OFF_DEP, OFF_DUMP = G::OFF_DUMP;
+    constexpr int OFF_TAB = G::OFF_TAB, OFF_TABM = G::OFF_TABM, OFF_TABB = G::OFF_TABB;
+    __shared__ __attribute__((aligned(128))) char smem[NORM ? G::LDS_NORM : G::LDS];
     typedef float f2 __attribute__((ext_vector_type(2)));
 
     const int tid = threadIdx.x;
@@ -97,6 +111,10 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     const int Hs = p.hin, Ws = p.win;
     const bool up2 = p.hl != p.hin;
     const int tw = W / TW, tpi = (H / TH) * tw;   // tiles per image row / per image
+    // p.out_seg > 0 (= W; e2eft_upconv2x_fwd): this launch is ONE parity phase of a 2x-upsampled image — p.out points at the phase's first pixel, p.ldo is twice the pixel
+    // pitch of the full-resolution tensor (GEMM rows x, x + 1 are two output pixels apart) and every image row y starts 2 W such strides after row y - 1
+    const int Wo = (KT == 2 && p.out_seg > 0) ? 2 * W : W;
+    const int pad_t = KT == 3 ? 1 : p.pad_t, pad_l = KT == 3 ? 1 : p.pad_l;   // (3x3: compile-time; a 2x2 phase: 1 - py, 1 - px)
 
     // ---- tile sequence of this workgroup: as igemm5 (eight contiguous chunks of the tile range, one per XCD)
     const int nslots = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
@@ -109,12 +127,12 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     // ---- loader state
     // A: piece j = wave + 8 i (i = 0..5) covers patch rows 8 j .. 8 j + 7; this lane's row and its swizzled 16-byte chunk are fixed
     const int jc16 = ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7)) * 16;   // ((patch row >> 1) & 7 = (4 j + (lane >> 4)) & 7, 32 i = 0 mod 8)
-    int pyx[6];                               // (patch y << 16) | patch x of the lane's row in piece i; y = 0x4000 for rows beyond the patch
-    int pix[6];                               // pixel index of that row inside the loader's image, -1 = padding / no tile
+    int pyx[NPI];                             // (patch y << 16) | patch x of the lane's row in piece i; y = 0x4000 for rows beyond the patch
+    int pix[NPI];                             // pixel index of that row inside the loader's image, -1 = padding / no tile
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NPI; ++i) {
         const int prow = 8 * (wave + 8 * i) + (lane >> 3);
-        const int py = (prow * 241) >> 13;    // prow / 34 for prow < 1000
+        const int py = prow / PW;             // (once per launch)
         pyx[i] = prow < PROWS ? (py << 16) | (prow - PW * py) : (0x4000 << 16);
     }
     // B: as igemm5 (rows lrow, lrow + 64 of the 128-row weight stage)
@@ -139,8 +157,8 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     };
     auto set_a = [&](const bool valid) {      // A address state of the loader's tile (d_*): pixel indices of the six rows, image descriptors
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int iy = d_oy0 - 1 + (pyx[i] >> 16), ix = d_ox0 - 1 + (pyx[i] & 0xffff);
+        for (int i = 0; i < NPI; ++i) {
+            const int iy = d_oy0 - pad_t + (pyx[i] >> 16), ix = d_ox0 - pad_l + (pyx[i] & 0xffff);
             const bool ok = valid && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             pix[i] = !ok ? -1 : up2 ? (iy >> 1) * Ws + (ix >> 1) : iy * W + ix;   // (fused upsample: four patch rows fetch the same source pixel — L2 hits)
         }
@@ -178,11 +196,11 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     };
     int pcur = 0, pnext = PATCH;              // patch buffer being multiplied / being filled
     int bs_cur = OFF_B, bs_nxt = OFF_B + B_STAGE, bs_dst = OFF_B + 2 * B_STAGE;
-    auto fire_a = [&](auto ic, const int pdst) {   // piece i (0..5) of the patch being fetched (pieces beyond the 43rd: zeros into the dump kilobyte)
+    auto fire_a = [&](auto ic, const int pdst) {   // piece i (0 .. NPI-1) of the patch being fetched (pieces beyond the last: zeros into the dump kilobyte)
         constexpr int i = decltype(ic)::value;
         unsigned off = OOB;
         int dst = OFF_DUMP + wave * 1024;
-        if constexpr (i < 6) {
+        if constexpr (i < NPI) {
             off = pix[i] < 0 ? OOB : (unsigned)pix[i] * a_ldb + a_coff;
             const int j = wave + 8 * i;
             if (j < PPIECES) dst = pdst + j * 1024;   // (wave-uniform)
@@ -286,6 +304,21 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(ov) : "memory");
     };
 
+    // "all but the newest n vector-memory operations of this wave are complete, and every LDS read has returned": immediates only, n is a compile-time constant
+    // everywhere except the one k-tile per tile that also requests the epilogue's operands (uniform npre)
+    auto wait_vm = [&](const int n) {
+        switch (n) {
+        case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+        }
+    };
     floatx16 acc[2][2];
     // B fragment byte offsets inside a stage (read-side swizzle as igemm2.hip); A: computed per k-tile from the patch row
     int bofs[4];
@@ -317,9 +350,9 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         c_n0 = d_n0; c_img = d_img; c_mt = d_mt;
         c_colok = c_n0 + wn * 64 + ec * 8 < p.N;
         c_ncl = c_colok ? c_n0 + wn * 64 + ec * 8 : c_n0;
-        const long px0 = ((long)d_img * H + d_oy0 + 2 * wm) * W + d_ox0 + er;
-        c_orow = px0 * p.ldo + c_ncl;
-        c_rrow = px0 * p.ldr + c_ncl;
+        const long py0 = (long)d_img * H + d_oy0 + 2 * wm;
+        c_orow = (py0 * Wo + d_ox0 + er) * p.ldo + c_ncl;
+        c_rrow = (py0 * W + d_ox0 + er) * p.ldr + c_ncl;
         nxt = u_dma + nslots < cend;
         if (nxt) tile_coords(u_dma + nslots);
     };
@@ -330,11 +363,12 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     // 0-5 one piece of the next patch as well.  The synchronisation that opens the next k-tile sits in front of the last two MFMA groups (igemm5.hip).
     auto ktile = [&](auto tc, auto ckc, const int c) {
         constexpr int t = decltype(tc)::value, CK = decltype(ckc)::value;
-        constexpr int TS = (t / 3) * PW + (t % 3);
+        constexpr int TS = (t / KT) * PW + (t % KT);
+        constexpr int AN = G::a_count(t), AF = G::a_first(t);   // A pieces of the next patch this k-tile issues
         unsigned kofs;                         // byte offset in a weight row of k-tile + 2 (uniform)
-        if constexpr (t < 7) kofs = (unsigned)((t + 2) * p.cin + c * 64) * (unsigned)sizeof(T);
-        else if constexpr (CK == 2) kofs = (unsigned)((t - 7) * p.cin) * (unsigned)sizeof(T);
-        else kofs = (unsigned)((t - 7) * p.cin + (c + 1) * 64) * (unsigned)sizeof(T);
+        if constexpr (t + 2 < NT) kofs = (unsigned)((t + 2) * p.cin + c * 64) * (unsigned)sizeof(T);
+        else if constexpr (CK == 2) kofs = (unsigned)((t + 2 - NT) * p.cin) * (unsigned)sizeof(T);
+        else kofs = (unsigned)((t + 2 - NT) * p.cin + (c + 1) * 64) * (unsigned)sizeof(T);
         const int pr0 = rbase + TS, pr1 = pr0 + PW;
         const int A0 = pcur + pr0 * 128 + ((((pr0 >> 1) & 7) ^ h) << 4);
         const int A1 = pcur + pr1 * 128 + ((((pr1 >> 1) & 7) ^ h) << 4);
@@ -356,7 +390,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NRM) norm_ready();
         rd(IC6<2>{}, IC6<2>{});
-        if constexpr (!(CK == 2 && t == 7)) fire_b(bs_dst, kofs);
+        if constexpr (!(CK == 2 && t == NT - 2)) fire_b(bs_dst, kofs);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (CK == 1 && t == 0) {
             const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
             if constexpr (CK == 2) { set_a(nxt); set_chunk(0); }
             else set_chunk(c + 1);
         }
-        if constexpr (CK == 2 && t == 7) {
+        if constexpr (CK == 2 && t == NT - 2) {
             // every lane requests (columns beyond N read the tile's first chunk instead: the count of VMEM instructions must not depend on exec)
             if (has_res) {
 #pragma unroll
@@ -394,23 +428,17 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
             fire_b(bs_dst, kofs);
         }
         rd(IC6<3>{}, IC6<0>{});
-        if constexpr (t < 6) fire_a(IC6<t>{}, pnext);   // k-tiles 6-8 of a chunk issue the two weight pieces only
+        if constexpr (AN >= 1) fire_a(IC6<AF>{}, pnext);   // (3x3: k-tiles 6-8 of a chunk issue the two weight pieces only)
+        if constexpr (AN >= 2) fire_a(IC6<AF + 1>{}, pnext);
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[1], a1[1], b0[1], b1[1]);
         if constexpr (NRM) { norm_pair(IC6<0>{}, IC6<1>{}); interleave4(); }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NRM) norm_issue2();                // coefficients of the last four channels: back before the barrier (its lgkmcnt(0))
         // lgkmcnt(0): this wave's reads of the current stage have RETURNED before the barrier lets others overwrite it
-        if constexpr (CK == 2 && t == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        else if constexpr (CK == 2 && t == 7) {   // younger than the previous k-tile's pieces: this k-tile's operand requests + its two weight pieces
-            if (npre == 0) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-            else if (npre == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-            else if (npre == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else if (npre == 4) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-            else if (npre == 5) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        } else if constexpr (t < 6) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        if constexpr (CK == 2 && t == NT - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if constexpr (CK == 2 && t == NT - 2) wait_vm(2 + AN + npre);   // younger than the previous k-tile's pieces: this k-tile's operand requests + its weight / patch pieces
+        else wait_vm(2 + AN);                                               // all but this k-tile's own pieces have landed
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (NRM) norm_mark();
@@ -421,17 +449,18 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         if constexpr (NRM) { norm_pair(IC6<1>{}, IC6<1>{}); interleave4(); __builtin_amdgcn_sched_barrier(0); norm_store(IC6<t - 2>{}); }
         asm volatile("" ::: "memory");
         { const int x = bs_cur; bs_cur = bs_nxt; bs_nxt = bs_dst; bs_dst = x; }
-        if constexpr (t == 8) { const int x = pcur; pcur = pnext; pnext = x; }
+        if constexpr (t == NT - 1) { const int x = pcur; pcur = pnext; pnext = x; }
     };
     auto chunk = [&](auto ckc, const int c) {
-        ktile(IC6<0>{}, ckc, c); ktile(IC6<1>{}, ckc, c); ktile(IC6<2>{}, ckc, c);
-        ktile(IC6<3>{}, ckc, c); ktile(IC6<4>{}, ckc, c); ktile(IC6<5>{}, ckc, c);
-        ktile(IC6<6>{}, ckc, c); ktile(IC6<7>{}, ckc, c); ktile(IC6<8>{}, ckc, c);
+        ktile(IC6<0>{}, ckc, c); ktile(IC6<1>{}, ckc, c); ktile(IC6<2>{}, ckc, c); ktile(IC6<3>{}, ckc, c);
+        if constexpr (KT == 3) {
+            ktile(IC6<4>{}, ckc, c); ktile(IC6<5>{}, ckc, c); ktile(IC6<6>{}, ckc, c); ktile(IC6<7>{}, ckc, c); ktile(IC6<8>{}, ckc, c);
+        }
     };
 
     // ---- epilogues and statistics merge: shared with igemm5.hip; rows of a wave's 64-row block are two image rows of 32 pixels here.
     // Packed (no residual): rounds of 16 rows = half an image row; fp32 (residual): slices 4-7 = the wave's second image row.
-    auto epi_rofs = [&](const int r) -> long { return (long)(r & 31) + (long)(r >> 5) * W; };
+    auto epi_rofs = [&](const int r) -> long { return (long)(r & 31) + (long)(r >> 5) * Wo; };
     constexpr int EPI_DEP = OFF_DEP;
 #define EPI_STAMP(i) do { } while (0)
 #include "igemm_persistent_epilogue.inc"
@@ -442,7 +471,8 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     set_b(true);
     set_chunk(0);
     fire_a(IC6<0>{}, pcur); fire_a(IC6<1>{}, pcur); fire_a(IC6<2>{}, pcur);
-    fire_a(IC6<3>{}, pcur); fire_a(IC6<4>{}, pcur); fire_a(IC6<5>{}, pcur);
+    fire_a(IC6<3>{}, pcur); fire_a(IC6<4>{}, pcur);
+    if constexpr (NPI > 5) fire_a(IC6<5>{}, pcur);
     fire_b(bs_cur, 0u);
     fire_b(bs_nxt, (unsigned)p.cin * (unsigned)sizeof(T));
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // the first patch and k-tile 0's weights
@@ -474,12 +504,17 @@ static std::atomic<long> g_patch_launches{0};
 int device_cus();   // api.hip
 
 template <typename T> static int launch6(IgemmParams& p, int total, int grid, hipStream_t s) {
+    if (p.kh == 2) {   // a 2x2 parity phase of an upsampler convolution: no residual, no fused GroupNorm (patch_eligible)
+        hipLaunchKernelGGL((igemm6_kernel<T, false, false, 2>), dim3(grid), dim3(512), 0, s, p, total);
+        tag_kernel("igemm6_kernel<%s, false, false, 2>", std::is_same<T, f16>::value ? "_Float16" : "__bf16");
+        return check_launch("igemm6");
+    }
     if (p.nrm_ad) {
-        if (p.residual) hipLaunchKernelGGL((igemm6_kernel<T, true, true>), dim3(grid), dim3(512), 0, s, p, total);
-        else hipLaunchKernelGGL((igemm6_kernel<T, false, true>), dim3(grid), dim3(512), 0, s, p, total);
+        if (p.residual) hipLaunchKernelGGL((igemm6_kernel<T, true, true, 3>), dim3(grid), dim3(512), 0, s, p, total);
+        else hipLaunchKernelGGL((igemm6_kernel<T, false, true, 3>), dim3(grid), dim3(512), 0, s, p, total);
     } else {
-        if (p.residual) hipLaunchKernelGGL((igemm6_kernel<T, true, false>), dim3(grid), dim3(512), 0, s, p, total);
-        else hipLaunchKernelGGL((igemm6_kernel<T, false, false>), dim3(grid), dim3(512), 0, s, p, total);
+        if (p.residual) hipLaunchKernelGGL((igemm6_kernel<T, true, false, 3>), dim3(grid), dim3(512), 0, s, p, total);
+        else hipLaunchKernelGGL((igemm6_kernel<T, false, false, 3>), dim3(grid), dim3(512), 0, s, p, total);
     }
     tag_kernel("igemm6_kernel<%s, %s, %s>", std::is_same<T, f16>::value ? "_Float16" : "__bf16", p.residual ? "true" : "false", p.nrm_ad ? "true" : "false");
     return check_launch("igemm6");
@@ -490,11 +525,17 @@ static bool patch_eligible(int dtype, int mode, IgemmParams& p, int nz, int& gri
     if (!option(E2EFT_OPT_PATCH_CONV) || !option(E2EFT_OPT_PERSISTENT)) return false;
     if (mode != 1 || nz != 1 || (dtype != E2EFT_F16 && dtype != E2EFT_BF16)) return false;
     if (p.ksplit_taps > 0 || p.bias_along_m) return false;
-    if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad_t != 1 || p.pad_l != 1 || p.zins > 1) return false;
-    const bool same = p.hl == p.hin && p.wl == p.win, up2 = p.hl == 2 * p.hin && p.wl == 2 * p.win;   // plain, or the exact 2x nearest upsample fused into the read
+    if (p.stride != 1 || p.zins > 1) return false;
+    const bool taps3 = p.kh == 3 && p.kw == 3 && p.pad_t == 1 && p.pad_l == 1;
+    // round 6: a 2x2 convolution with top / left pads of 0 or 1 — one parity phase of a 2x-upsampler convolution (e2eft_upconv2x_fwd); its rows may be written as
+    // segments of a full-resolution image (out_seg = the row length)
+    const bool taps2 = p.kh == 2 && p.kw == 2 && (unsigned)p.pad_t <= 1u && (unsigned)p.pad_l <= 1u && !p.residual && !p.nrm_ad && !p.x2 && (p.out_seg == 0 || p.out_seg == p.wl);
+    if (!taps3 && !(taps2 && option(E2EFT_OPT_PATCH_CONV_2X2))) return false;
+    if (taps3 && p.out_seg != 0) return false;
+    const bool same = p.hl == p.hin && p.wl == p.win, up2 = taps3 && p.hl == 2 * p.hin && p.wl == 2 * p.win;   // plain, or the exact 2x nearest upsample fused into the read
     if (!(same || up2) || p.hout != p.hl || p.wout != p.wl) return false;
     if (p.wl % TW != 0 || p.hl % TH != 0) return false;
-    if (p.cin % 64 != 0 || p.c1 % 64 != 0 || p.cin < 128 || p.K != 9 * p.cin) return false;
+    if (p.cin % 64 != 0 || p.c1 % 64 != 0 || p.cin < 128 || p.K != p.kh * p.kw * p.cin) return false;
     if (p.nrm_ad && (p.x2 || p.cin > NORM_CMAX || p.N > BN || !option(E2EFT_OPT_FUSED_NORM))) return false;   // one N tile: every N tile would redo the normalisation
     if (p.N % 8 != 0 || p.ldo % 8 != 0 || (((uintptr_t)p.out) & 15) != 0) return false;
     if (p.ldx1 % 8 != 0 || (((uintptr_t)p.x1) & 15) != 0 || (p.x2 && (p.ldx2 % 8 != 0 || (((uintptr_t)p.x2) & 15) != 0))) return false;

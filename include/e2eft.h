@@ -66,7 +66,8 @@ enum {
     E2EFT_OPT_FUSED_NORM = 8,        /* 1 (default): e2eft_conv2d_fwd_normed_supported may answer 1; 0: it answers 0 (GroupNorm applied by its own pass) */
     E2EFT_OPT_ATTN_DMA = 9,          /* 1 (default since round 5): e2eft_attn_fwd delivers K / V tiles by LDS-DMA into a two-stage ring (K / V below 3.5 GB); 0: staged through registers (bit-identical results) */
     E2EFT_OPT_UPCONV_PHASES = 10,    /* 1 (default): e2eft_upconv2x_fwd_supported may answer 1 (2x-upsample + 3x3 convolutions as four 2x2 phase convolutions); 0: it answers 0 */
-    E2EFT_OPT_COUNT = 11
+    E2EFT_OPT_PATCH_CONV_2X2 = 11,   /* 1 (default, round 6): the 2x2 parity phases of e2eft_upconv2x_fwd (and any eligible 2x2 / stride-1 convolution) on the halo-patch kernel's 2x2-tap variant (igemm6); 0: igemm5 */
+    E2EFT_OPT_COUNT = 12
 };
 int e2eft_set_option(int32_t key, int32_t value);
 int e2eft_get_option(int32_t key);

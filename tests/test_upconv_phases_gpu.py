@@ -18,7 +18,8 @@ def _launches():
     from diffusion_e2e_ft_amd import _lib
     lib = _lib.load()
     lib.e2eft_debug_persistent_launches.restype = ctypes.c_long
-    return lib.e2eft_debug_persistent_launches()
+    lib.e2eft_debug_patch_launches.restype = ctypes.c_long
+    return lib.e2eft_debug_persistent_launches() + lib.e2eft_debug_patch_launches()      # igemm5, or (round 6, eligible shapes) igemm6's 2x2-tap variant
 
 
 def _case(dev, dtype, B, H, W, Ci, Co, seed, bias=True):
