@@ -43,7 +43,7 @@ class AttnDesc(C.Structure):
 
 
 # e2eft_set_option keys (include/e2eft.h)
-OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV, OPT_THIN_INPUT_CONV, OPT_FUSED_NORM, OPT_ATTN_DMA, OPT_UPCONV_PHASES, OPT_PATCH_CONV_2X2 = range(12)
+OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV, OPT_THIN_INPUT_CONV, OPT_FUSED_NORM, OPT_ATTN_DMA, OPT_UPCONV_PHASES, OPT_PATCH_CONV_2X2, OPT_PERSISTENT_MIN_QROUNDS, OPT_GN_APPLY_ITERS = range(14)
 
 _P = C.c_void_p
 _I = C.c_int32

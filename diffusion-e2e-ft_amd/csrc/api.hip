@@ -45,7 +45,7 @@ void tag_kernel(const char* fmt, ...) {
 }
 const char* last_tag() { return g_tag; }
 
-static std::atomic<int> g_opt[E2EFT_OPT_COUNT] = {{1}, {0}, {1}, {1}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {1}};
+static std::atomic<int> g_opt[E2EFT_OPT_COUNT] = {{1}, {0}, {1}, {1}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {1}, {2}, {0}};
 
 int option(int key) { return g_opt[key].load(std::memory_order_relaxed); }
 
@@ -57,6 +57,8 @@ extern "C" int e2eft_set_option(int32_t key, int32_t value) {
     bool ok = value == 0 || value == 1;
     if (key == E2EFT_OPT_PERSISTENT_GRID) ok = value == 0 || (value >= 8 && value % 8 == 0 && value <= 4096);
     if (key == E2EFT_OPT_IGEMM2_WAVES) ok = value == 0 || value == 4 || value == 8;
+    if (key == E2EFT_OPT_PERSISTENT_MIN_QROUNDS) ok = value >= 1 && value <= 64;
+    if (key == E2EFT_OPT_GN_APPLY_ITERS) ok = value >= 0 && value <= 16;
     E2EFT_REQUIRE(ok, "set_option: value %d out of range for key %d", value, key);
     g_opt[key].store(value, std::memory_order_relaxed);
     return E2EFT_OK;

@@ -520,7 +520,7 @@ int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStre
     if (gopt >= 8 && gopt < g_pers_cus) g_pers_cus = gopt;
     const int mtiles = p.M / BM, ntiles = cdiv(p.N, BN);
     const long total = (long)mtiles * ntiles * nz;
-    if (total < 2L * g_pers_cus || total > 2000000000L || mtiles >= (1 << 22)) return -1;   // (tile / row splits use a float reciprocal: quotients below 2^22)
+    if (4 * total < (long)option(E2EFT_OPT_PERSISTENT_MIN_QROUNDS) * g_pers_cus || total > 2000000000L || mtiles >= (1 << 22)) return -1;   // (tile / row splits use a float reciprocal: quotients below 2^22)
     p.mtiles = mtiles;
     p.ntiles = ntiles;
     if (p.gn_partial) {   // statistics need whole tiles inside one image; otherwise igemm2 may still be able to emit them (128-row slabs): fall through

@@ -552,7 +552,7 @@ static bool patch_eligible(int dtype, int mode, IgemmParams& p, int nz, int& gri
     if (gopt >= 8 && gopt < cus) cus = gopt;
     const int mtiles = p.M / BM, ntiles = cdiv(p.N, BN);
     const long total = (long)mtiles * ntiles;
-    if (total < 2L * cus || total > 2000000000L || mtiles >= (1 << 22)) return false;
+    if (4 * total < (long)option(E2EFT_OPT_PERSISTENT_MIN_QROUNDS) * cus || total > 2000000000L || mtiles >= (1 << 22)) return false;
     if (p.gn_partial) {
         if (p.rows_per_img != p.hl * p.wl) return false;
         p.gn_nslabs = p.rows_per_img / BM;

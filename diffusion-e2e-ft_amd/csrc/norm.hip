@@ -274,7 +274,12 @@ static int gn_run(const E2eftGroupNormDesc* d, const GnGeom& g, const void* x1, 
     // profiles/r02_stream_bench.txt); the statistics kernels keep the coarser split, their partials are per slab
     if (!y) return check_launch("groupnorm_stats");   // statistics only: the consumer applies (x - mean) * a + beta itself (e2eft_conv2d_fwd_normed)
     GnGeom ga = g;
-    ga.slab = g.pl * 8;
+    // pixels per thread: 4 x n sixteen-byte loads.  n = 2 streams the big tensors fastest (r02 stream bench; re-measured in round 6: 768^2 C128 453 us against 476 at
+    // n = 4), n = 4 the ones of <= 128 MB (96^2 C512 37.1 -> 34.4 us, 96^2 C320 26.2 -> 24.6: fewer, longer workgroups amortise the coefficient loads;
+    // profiles/r06c_gn_apply_sweep.txt)
+    const int it = option(E2EFT_OPT_GN_APPLY_ITERS);
+    const long tensor_bytes = (long)d->batch * d->hw * g.C * (long)dtype_size(d->dtype);
+    ga.slab = g.pl * 4 * (it > 0 ? it : (tensor_bytes <= (128L << 20) ? 4 : 2));
     ga.nslabs = (d->hw + ga.slab - 1) / ga.slab;
     hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(ga.nslabs, ga.batch, ga.nchb), dim3(256), 0, s, ga, d->silu, d->ldy, (const T*)x1, (const T*)x2, ad, (const T*)beta, (T*)y);
     return check_launch("groupnorm");

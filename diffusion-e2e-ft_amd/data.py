@@ -326,9 +326,14 @@ class DeviceLoader:
     buffer set per in-flight batch, upload + `finish_samples` on a side stream so that both hide under the training step.  Iterating yields batch dicts
     on `device` (the consumer's current stream waits for the batch's event)."""
 
-    def __init__(self, dataset, batch_size=1, device="cuda", shuffle=True, drop_last=False, workers=8, prefetch=2):
+    def __init__(self, dataset, batch_size=1, device="cuda", shuffle=True, drop_last=False, workers=8, prefetch=2, rank=0, world=1):
         self.dataset, self.batch_size, self.device = dataset, int(batch_size), torch.device(device)
         self.shuffle, self.drop_last, self.workers, self.prefetch = shuffle, drop_last, max(1, int(workers)), max(1, int(prefetch))
+        # data-parallel training: one DeviceLoader per rank over the SAME epoch order (same torch RNG state on every rank, as `set_seed(args.seed)` leaves it,
+        # train.py:117-118); rank r takes batches r, r + world, ... of it — accelerate's BatchSamplerShard rule for a prepared DataLoader.  Each rank decodes
+        # only its own batches with its own thread pool and staging buffers: host throughput scales with the ranks (scripts/loader_bench.py --ranks)
+        self.rank, self.world = int(rank), max(1, int(world))
+        assert 0 <= self.rank < self.world
         from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
         self._batches = BatchSampler(RandomSampler(dataset) if shuffle else SequentialSampler(dataset), self.batch_size, drop_last)
         self._pool = None
@@ -336,7 +341,8 @@ class DeviceLoader:
         self._lock = threading.Lock()
 
     def __len__(self):
-        return len(self._batches)
+        n = len(self._batches)
+        return n if self.world == 1 else (n - self.rank + self.world - 1) // self.world
 
     def _stage(self, samples):
         """stack decoded samples into pinned host buffers (one set per call: the upload is asynchronous)"""
@@ -370,7 +376,10 @@ class DeviceLoader:
         """the index lists of one epoch, consuming torch's global RNG exactly as `iter(DataLoader(...))` does: the iterator first draws its `base_seed`
         (an int64 it hands to worker processes; drawn with num_workers = 0 too), then RandomSampler draws the seed of its permutation"""
         torch.empty((), dtype=torch.int64).random_()
-        return iter(self._batches)
+        it = iter(self._batches)
+        if self.world == 1:
+            return it
+        return (b for k, b in enumerate(it) if k % self.world == self.rank)
 
     def __iter__(self):
         """`iter(loader)` draws the iterator's `base_seed` EAGERLY, as `DataLoader.__iter__` does (torch's `_BaseDataLoaderIter.__init__`); the permutation seed is

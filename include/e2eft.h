@@ -67,7 +67,9 @@ enum {
     E2EFT_OPT_ATTN_DMA = 9,          /* 1 (default since round 5): e2eft_attn_fwd delivers K / V tiles by LDS-DMA into a two-stage ring (K / V below 3.5 GB); 0: staged through registers (bit-identical results) */
     E2EFT_OPT_UPCONV_PHASES = 10,    /* 1 (default): e2eft_upconv2x_fwd_supported may answer 1 (2x-upsample + 3x3 convolutions as four 2x2 phase convolutions); 0: it answers 0 */
     E2EFT_OPT_PATCH_CONV_2X2 = 11,   /* 1 (default, round 6): the 2x2 parity phases of e2eft_upconv2x_fwd (and any eligible 2x2 / stride-1 convolution) on the halo-patch kernel's 2x2-tap variant (igemm6); 0: igemm5 */
-    E2EFT_OPT_COUNT = 12
+    E2EFT_OPT_PERSISTENT_MIN_QROUNDS = 12, /* 2 (default since round 6, was 8): the persistent kernels (igemm5 / igemm6) take a launch of at least n / 4 tiles per CU (2 = half a round of the machine, 8 = two rounds); 1 .. 64 */
+    E2EFT_OPT_GN_APPLY_ITERS = 13,   /* 0 (default): the GroupNorm apply pass picks its pixels per thread (4 x n sixteen-byte loads) by tensor size; 1 .. 16: forced n */
+    E2EFT_OPT_COUNT = 14
 };
 int e2eft_set_option(int32_t key, int32_t value);
 int e2eft_get_option(int32_t key);

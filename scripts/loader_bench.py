@@ -38,6 +38,47 @@ def reference_cpu_sample(pr, near=1e-5, far=65.0):
     return dataprep_ref.prepare_sample_ref(tt(rgb), torch.from_numpy(np.array(dimg, np.float32))[None], tt(nimg), near, far)
 
 
+def rank_worker(args):
+    """one data-parallel rank: its shard of every epoch through its own DeviceLoader; prints {"images", "seconds"}"""
+    from diffusion_e2e_ft_amd import data
+    root_dir, split_path = args.tree.split("::")
+    ds = data.Hypersim(root_dir, transform=True, split_path=split_path)
+    dev = torch.device("cuda", args.rank_worker % torch.cuda.device_count())
+    torch.manual_seed(0)
+    loader = data.DeviceLoader(ds, batch_size=args.batch, device=dev, shuffle=True, drop_last=True, workers=args.workers, prefetch=3, rank=args.rank_worker, world=args.ranks)
+    for b in loader:
+        pass
+    torch.cuda.synchronize()
+    # crude start barrier: every rank sleeps until the same wall-clock second
+    t_go = float(os.environ["LOADER_BENCH_GO"])
+    time.sleep(max(0.0, t_go - time.time()))
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(args.epochs):
+        for b in loader:
+            n += b["rgb"].shape[0]
+    torch.cuda.synchronize()
+    print(json.dumps({"rank": args.rank_worker, "images": n, "seconds": time.perf_counter() - t0}))
+    loader.close()
+
+
+def run_ranks(args, root_dir, split_path):
+    import subprocess
+    env = dict(os.environ, LOADER_BENCH_GO=str(time.time() + 45.0))        # imports + the warm-up epoch of every rank fit in 45 s
+    cmd = [sys.executable, os.path.abspath(__file__), "--samples", str(args.samples), "--workers", str(args.workers), "--batch", str(args.batch), "--epochs", str(args.epochs),
+           "--ranks", str(args.ranks), "--tree", root_dir + "::" + split_path]
+    procs = [subprocess.Popen(cmd + ["--rank-worker", str(r)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for r in range(args.ranks)]
+    res = []
+    for pr in procs:
+        o, _ = pr.communicate(timeout=600)
+        lines = [l for l in o.splitlines() if l.startswith("{")]
+        res.append(json.loads(lines[-1]) if lines else {"images": 0, "seconds": 1.0, "failed": True})
+    slowest = max(r["seconds"] for r in res)
+    return {"ranks": args.ranks, "decode_threads_per_rank": args.workers, "images_per_s": sum(r["images"] for r in res) / slowest,
+            "per_rank_images_per_s": [round(r["images"] / r["seconds"], 1) for r in res],
+            "what": "aggregate of N processes, each DeviceLoader(rank=r, world=N) over the same epoch order; total images / slowest rank's time"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=24)
@@ -46,7 +87,13 @@ def main():
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--height", type=int, default=768)
     ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--ranks", type=int, default=1, help="N > 1: N processes, each with its own DeviceLoader(rank=r, world=N) over the same tree (one rank per GPU in "
+                    "training; here they share the visible device(s) round-robin) — the aggregate is what N data-parallel ranks are fed with")
+    ap.add_argument("--rank-worker", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--tree", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.rank_worker >= 0:
+        return rank_worker(args)
     import dataset_fixture as dfx
     from diffusion_e2e_ft_amd import data
     out = {"samples": args.samples, "resolution": [args.height, args.width], "workers": args.workers, "batch": args.batch, "host_cores": os.cpu_count(),
@@ -106,6 +153,8 @@ def main():
             ms = e0.elapsed_time(e1) / 20
             out["device_prepare"] = {"ms_per_batch": ms, "images_per_s": args.batch / ms * 1e3, "what": "align_normals + flip / Pillow-exact resize + quantiles + prepare, batch resident"}
             loader.close()
+            if args.ranks > 1:
+                out["device_loader_ranks"] = run_ranks(args, root_dir, split_path)
     print(json.dumps(out))
 
 

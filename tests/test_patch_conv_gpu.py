@@ -26,6 +26,7 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 _lib.set_option(_lib.OPT_PERSISTENT_GRID, int(os.environ.get("TEST_PERSISTENT_GRID", "0")))
 _lib.set_option(_lib.OPT_PATCH_CONV, int(os.environ.get("TEST_PATCH_CONV", "1")))
+_lib.set_option(_lib.OPT_PERSISTENT_MIN_QROUNDS, 8)   # the eligibility expectations below are "two tiles per workgroup" (round 6's default is half a round: tests/test_persistent_gpu.py)
 lib.e2eft_debug_patch_launches.restype = ctypes.c_long
 EXPECT = int(os.environ.get("TEST_PATCH_CONV", "1"))
 def launches():

@@ -27,6 +27,7 @@ lib = _lib.load()
 _lib.set_option(_lib.OPT_PERSISTENT_GRID, int(os.environ.get("TEST_PERSISTENT_GRID", "0")))
 _lib.set_option(_lib.OPT_PERSISTENT, int(os.environ.get("TEST_PERSISTENT", "1")))
 _lib.set_option(_lib.OPT_PATCH_CONV, 0)      # this file is about igemm5: the halo-patch kernel (tests/test_patch_conv_gpu.py) would take the 3x3 cases
+_lib.set_option(_lib.OPT_PERSISTENT_MIN_QROUNDS, 8)   # the cases below were written against "two tiles per workgroup"; round 6's default is half a round (own test at the end of the file)
 lib.e2eft_debug_persistent_launches.restype = ctypes.c_long
 EXPECT = int(os.environ.get("EXPECT_PERSISTENT", "1"))
 def launches():
@@ -200,3 +201,32 @@ def test_persistent_kernel_on_small_shapes(dev):
 def test_same_cases_without_the_variant(dev):
     """E2EFT_OPT_PERSISTENT = 0: every case runs on igemm2 — the reference numbers of the A/B"""
     _run({"TEST_PERSISTENT": "0", "EXPECT_PERSISTENT": "0"})
+
+
+def test_half_a_round_of_tiles_is_enough_since_round_6(dev):
+    """E2EFT_OPT_PERSISTENT_MIN_QROUNDS (default 2 = half a round of the machine, was two rounds): a launch whose tile count lies between half a round and two
+    rounds runs on the persistent kernel — one tile per workgroup, some workgroups idle: its k-loop (barrier under the last MFMA groups, 1.3-1.45 k cycles per
+    k-tile) is what pays, not the tile overlap (profiles/r06c_min_rounds_sweep.txt: GEMM 18432 x 640 x 640 + residual 467 -> 568 TF/s) — with results equal to
+    igemm2's up to the summation order; below half a round it still falls through."""
+    import ctypes
+    import torch
+    import torch.nn.functional as F
+    from diffusion_e2e_ft_amd import ops, _lib
+    from util import nhwc, to_nchw, pack_conv_weight, q, rel_err, TOL
+    lib = _lib.load()
+    lib.e2eft_debug_persistent_launches.restype = ctypes.c_long
+    dtype = torch.float16
+    assert lib.e2eft_get_option(_lib.OPT_PERSISTENT_MIN_QROUNDS) == 2
+    for (B, H, W, Ci, Co, expect) in [(8, 16, 16, 192, 128, 1), (4, 16, 16, 192, 128, 1), (3, 16, 16, 192, 128, 0)]:     # 8 / 4 / 3 tiles on the 8-workgroup test grid
+        g = torch.Generator().manual_seed(B)
+        x = q(torch.randn(B, Ci, H, W, generator=g), dtype)
+        w = q(torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5, dtype)
+        b = q(torch.randn(Co, generator=g), dtype)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+        with _lib.option(_lib.OPT_PERSISTENT_GRID, 8), _lib.option(_lib.OPT_PATCH_CONV, 0):
+            n0 = lib.e2eft_debug_persistent_launches()
+            y = ops.conv2d(nhwc(x, dtype, dev), pack_conv_weight(w, dtype, dev), b.to(dtype).to(dev), Co, 3, 3, 1, (1, 1, 1, 1))
+            took = lib.e2eft_debug_persistent_launches() - n0
+        torch.cuda.synchronize()
+        assert took == expect, (B, took)
+        assert rel_err(to_nchw(y), ref) <= TOL[dtype]

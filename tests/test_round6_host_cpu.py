@@ -82,3 +82,30 @@ def test_train_step_repeats_the_gathered_loss_by_the_configured_constant(monkeyp
     seen.clear()
     training.train_step(None, None, Opt(), batches, None, gather_loss=True)
     assert seen == [1, 1]
+
+
+def test_device_loader_rank_shards_partition_the_epoch_order():
+    """DeviceLoader(rank=r, world=N): with the same torch RNG state on every rank (set_seed on all of them, train.py:117-118) rank r takes batches r, r + N, ...
+    of the ONE epoch order — accelerate's BatchSamplerShard rule; together the ranks see every batch exactly once"""
+    from diffusion_e2e_ft_amd.data import DeviceLoader
+
+    class DS(torch.utils.data.Dataset):
+        name, transform, near_plane, far_plane = "hypersim", None, 1e-5, 65.0
+
+        def __len__(self):
+            return 23
+
+        def __getitem__(self, i):
+            return i
+
+    torch.manual_seed(11)
+    whole = [list(b) for b in DeviceLoader(DS(), batch_size=3, device="cpu", shuffle=True).index_batches()]
+    assert len(whole) == 8
+    seen = []
+    for r in range(3):
+        torch.manual_seed(11)
+        dl = DeviceLoader(DS(), batch_size=3, device="cpu", shuffle=True, rank=r, world=3)
+        mine = [list(b) for b in dl.index_batches()]
+        assert mine == whole[r::3] and len(dl) == len(mine)
+        seen += mine
+    assert sorted(i for b in seen for i in b) == list(range(23))
