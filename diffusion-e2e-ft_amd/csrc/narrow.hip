@@ -26,6 +26,17 @@ template <> __device__ __forceinline__ float dot2<f16>(unsigned a, unsigned b, f
 template <> __device__ __forceinline__ float dot2<bf16>(unsigned a, unsigned b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b), c, false);
 }
+// 16 bytes of activations times 16 bytes of weights: four 2-way dot products (16-bit) or four fp32 FMAs (round 6: the strict-fp32 training recipe's decoder
+// conv_out 128 -> 3 ran on a 128-wide MFMA tile at 3.3 TF/s, 22.5 ms of the 2.95 s step — training/train.py:241-242 through the frozen decoder)
+template <typename T> __device__ __forceinline__ float dot16(const u32x4& a, const u32x4& b, float s) {
+    if constexpr (sizeof(T) == 4) {
+        const floatx4 fa = __builtin_bit_cast(floatx4, a), fb = __builtin_bit_cast(floatx4, b);
+        s = fmaf(fa[0], fb[0], s); s = fmaf(fa[1], fb[1], s); s = fmaf(fa[2], fb[2], s); s = fmaf(fa[3], fb[3], s);
+    } else {
+        s = dot2<T>(a[0], b[0], s); s = dot2<T>(a[1], b[1], s); s = dot2<T>(a[2], b[2], s); s = dot2<T>(a[3], b[3], s);
+    }
+    return s;
+}
 
 struct NarrowParams {
     const void* x;      // [B][H][W][ldx]
@@ -56,10 +67,11 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const NarrowParams 
     float acc[CO];
 #pragma unroll
     for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+    constexpr int EPC = 16 / (int)sizeof(T), CH = 128 / (int)sizeof(T);      // channels per 16 bytes / per LDS chunk (128 data bytes per halo pixel: 64 halves or 32 floats)
 
-    for (int c0 = 0; c0 < p.cin; c0 += NR_CH) {
-        const int nch = min(NR_CH, p.cin - c0);      // multiple of 8
-        const int ngr = nch >> 3;                     // 16-byte groups per pixel in this chunk
+    for (int c0 = 0; c0 < p.cin; c0 += CH) {
+        const int nch = min(CH, p.cin - c0);          // multiple of EPC
+        const int ngr = nch / EPC;                    // 16-byte groups per pixel in this chunk
         __syncthreads();                              // the previous chunk is consumed
         // ---- stage the halo: 324 pixels x ngr 16-byte groups, zeros outside the image (the convolution's zero padding)
         for (int i = tid; i < NR_H * NR_H * 8; i += 256) {
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const NarrowParams 
             const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
             u32x4 v = {0u, 0u, 0u, 0u};
             if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                v = *reinterpret_cast<const u32x4*>(xb + ((long)iy * p.W + ix) * p.ldx + c0 + g * 8);
+                v = *reinterpret_cast<const u32x4*>(xb + ((long)iy * p.W + ix) * p.ldx + c0 + g * EPC);
             *reinterpret_cast<u32x4*>(halo + pix * NR_PIX + g * 16) = v;
         }
         __syncthreads();
@@ -84,13 +96,8 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const NarrowParams 
                     const u32x4 a = *reinterpret_cast<const u32x4*>(px + g * 16);
 #pragma unroll
                     for (int co = 0; co < CO; ++co) {
-                        const u32x4 b = *(cptr_t)(uintptr_t)(wg + (long)co * p.ldw + wofs + g * 8);
-                        float s = acc[co];
-                        s = dot2<T>(a[0], b[0], s);
-                        s = dot2<T>(a[1], b[1], s);
-                        s = dot2<T>(a[2], b[2], s);
-                        s = dot2<T>(a[3], b[3], s);
-                        acc[co] = s;
+                        const u32x4 b = *(cptr_t)(uintptr_t)(wg + (long)co * p.ldw + wofs + g * EPC);
+                        acc[co] = dot16<T>(a, b, acc[co]);
                     }
                 }
             }
@@ -212,9 +219,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_narrow_mfma_kernel(const Narro
 }
 
 template <typename T> static void launch_narrow_t(const NarrowParams& p, dim3 grid, hipStream_t s) {
-    if (option(E2EFT_OPT_NARROW_MFMA) && p.cin % 32 == 0) {
-        hipLaunchKernelGGL((conv3x3_narrow_mfma_kernel<T>), grid, dim3(256), 0, s, p, (const T*)p.w);
-        return;
+    if constexpr (sizeof(T) == 2) {
+        if (option(E2EFT_OPT_NARROW_MFMA) && p.cin % 32 == 0) {
+            hipLaunchKernelGGL((conv3x3_narrow_mfma_kernel<T>), grid, dim3(256), 0, s, p, (const T*)p.w);
+            return;
+        }
     }
     const T* w = (const T*)p.w;
     switch (p.cout) {
@@ -228,10 +237,12 @@ template <typename T> static void launch_narrow_t(const NarrowParams& p, dim3 gr
 // returns -1 when the problem is not this kernel's (the caller then runs the implicit-GEMM path), else the launch status
 bool conv3x3_narrow_eligible(const E2eftConvDesc* d, bool normed) {   // the descriptor's part of the test (pointers: 16-byte aligned)
     if (!option(E2EFT_OPT_NARROW_CONV)) return false;
-    if (d->dtype != E2EFT_F16 && d->dtype != E2EFT_BF16) return false;
+    if (d->dtype != E2EFT_F16 && d->dtype != E2EFT_BF16 && d->dtype != E2EFT_F32) return false;
+    const int epc = 16 / (int)dtype_size(d->dtype);
+    if (d->dtype == E2EFT_F32 && normed) return false;   // (the fused GroupNorm lives in the 16-bit MFMA form)
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->c2 != 0) return false;
     if (d->cout < 1 || d->cout > NR_CO || d->hl != d->hin || d->wl != d->win || d->hout != d->hin || d->wout != d->win) return false;
-    if (d->c1 % 8 != 0 || d->ldx1 % 8 != 0 || d->ldw % 8 != 0) return false;
+    if (d->c1 % epc != 0 || d->ldx1 % epc != 0 || d->ldw % epc != 0) return false;
     if ((long)d->batch * d->hout * d->wout < 16384) return false;   // tiny problems: launch-bound either way, keep one code path
     if (d->c1 > 128) return false;   // measured: 320 -> 4 at 8 x 96^2 is 0.098 ms here vs 0.087 ms on the MFMA tile (five halo chunks per tile)
     if (normed && !(option(E2EFT_OPT_NARROW_MFMA) && d->c1 % 32 == 0 && option(E2EFT_OPT_FUSED_NORM))) return false;   // the fused norm lives in the MFMA form
@@ -250,8 +261,9 @@ int launch_conv3x3_narrow(const E2eftConvDesc* d, const void* x1, const void* w,
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)d->batch);
     if (d->dtype == E2EFT_F16) launch_narrow_t<f16>(p, grid, s);
-    else launch_narrow_t<bf16>(p, grid, s);
-    tag_kernel("conv3x3_narrow%s_kernel", (option(E2EFT_OPT_NARROW_MFMA) && p.cin % 32 == 0) ? "_mfma" : "");
+    else if (d->dtype == E2EFT_BF16) launch_narrow_t<bf16>(p, grid, s);
+    else launch_narrow_t<float>(p, grid, s);
+    tag_kernel("conv3x3_narrow%s_kernel", (d->dtype != E2EFT_F32 && option(E2EFT_OPT_NARROW_MFMA) && p.cin % 32 == 0) ? "_mfma" : "");
     return check_launch("conv3x3_narrow");
 }
 

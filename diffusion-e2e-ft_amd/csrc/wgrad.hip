@@ -18,8 +18,8 @@
 //     c ^ (((r >> 1) & 1) << 2): the four rows of a transpose read then cover four different 64-byte bank windows (conflict-free), and the key is
 //     constant per lane;
 //   * partial sums leave as fp32 [split][Co][kh kw cin]; e2eft_colsum (the reduction the split-K NT path already used) adds the splits.
-// Eligibility is decided here (returns E2EFT_ERR_UNSUPPORTED and the caller keeps the transpose + im2col_t + GEMM path): 16-bit, cin and c1 multiples
-// of 64, no fused upsample, tensors below 4 GB.
+// Eligibility is decided here (returns E2EFT_ERR_UNSUPPORTED and the caller keeps the transpose + im2col_t + GEMM path): cin and c1 multiples
+// of 64, no fused upsample, tensors below 4 GB.  fp32 (round 6): wgrad32_kernel below, the same decomposition on v_mfma_f32_32x32x2_f32.
 #include "common.h"
 #include <type_traits>
 
@@ -237,12 +237,164 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---- strict fp32 (round 6) -----------------------------------------------------------------------------------------------------------------------------------
+// The reference trains with `--mixed_precision "no"` (training/scripts/train_marigold_e2e_ft_depth.sh:15): its weight gradients are fp32 contractions over the
+// pixels.  Rounds 3-5 kept them on e2eft_transpose + e2eft_conv2d_im2col_t + split-K batched GEMMs (two materialised K-contiguous copies, 9x the input for a 3x3
+// filter, and 256-row GEMM tiles that a 320-channel layer fills to 62 %): 48 + 190 ms of the 2.95 s step at 50-100 TF/s.  The fp32 MFMA (v_mfma_f32_32x32x2_f32,
+// exact fp32 products and sums) takes ONE float per lane and operand — A[i = lane & 31][k = lane >> 5] — so with the contraction index = pixel both operands are
+// plain `ds_read_b32` of the tiles as they lie in HBM:   A = dY[pixel 2 ks + hh][co0 + l31],  B = X[pixel 2 ks + hh (+) tap][ci0 + l31]
+// (32 consecutive floats per half-wave: conflict-free without any swizzle), no transposed image, no transpose read.  Same decomposition as the 16-bit kernel:
+// 128 x 256 (or 256 x 128) tile, 8 waves of 64 x 64, panels [32 pixels][64 channels] of 8 KB filled by LDS-DMA (a wave's 1-KiB piece = 4 pixel rows of 256 B), three
+// stages, six pieces per wave and k-tile (`vmcnt(6)` exact), split over pixels by whole rounds of the machine, fp32 partials reduced by e2eft_colsum.  A k-tile is
+// 16 k-steps of 4 MFMAs x 64 cycles per wave: the matrix pipe is the only thing that is busy.
+namespace wg32 {
+constexpr int BK = 32;                     // pixels per k-tile
+constexpr int PANEL = 32 * 256;            // [32 pixels][64 channels] of fp32
+constexpr int STAGE = 6 * PANEL;
+constexpr int NSTAGE = 3;
+constexpr int LDS = NSTAGE * STAGE;        // 147,456 B
+}  // namespace wg32
+
+template <int NA>
+__global__ __launch_bounds__(512) void wgrad32_kernel(const WgradParams p) {
+    using namespace wg32;
+    constexpr int NB = 6 - NA, BM = 64 * NA, BN = 64 * NB;
+    __shared__ __attribute__((aligned(16))) char smem[LDS];
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = NA == 2 ? wave >> 2 : wave >> 1, wn = NA == 2 ? wave & 3 : wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int k_begin = blockIdx.z * p.kchunk, k_end = min(p.P, k_begin + p.kchunk);
+    const unsigned OOB = 0xFFFFFFF0u;
+
+    const int cpt = p.cin >> 6;
+    int ci0[NB], ky[NB], kx[NB];
+    bool cok[NB], src2[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int q = (n0 >> 6) + j;
+        cok[j] = q * 64 < p.N;
+        const int tap = cok[j] ? q / cpt : 0;
+        ci0[j] = cok[j] ? (q - tap * cpt) * 64 : 0;
+        ky[j] = tap / p.kw; kx[j] = tap - ky[j] * p.kw;
+        src2[j] = ci0[j] >= p.c1;
+    }
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)(((long)(p.P - 1) * p.ldy + p.M) * 4L), 0x00020000);
+    const long xpix = (long)p.batch * p.hin * p.win;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, (unsigned)(((xpix - 1) * p.ldx1 + p.c1) * 4L), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 ? p.x2 : p.x1), 0,
+                                                                         (unsigned)(((xpix - 1) * (p.x2 ? p.ldx2 : p.ldx1) + (p.x2 ? p.cin - p.c1 : p.c1)) * 4L), 0x00020000);
+    const unsigned lds0 = (unsigned)(uintptr_t)((lptr_t)smem);
+
+    // ---- loader: wave w moves piece w (pixel rows 4 w .. 4 w + 3 of the k-tile) of all six panels; lane l: row 4 w + (l >> 4), channels 4 (l & 15) .. + 3 of the chunk
+    const int r_kt = 4 * wave + (lane >> 4);
+    const int sc4 = (lane & 15) * 4;
+    const int hw_out = p.hout * p.wout;
+    int pix = k_begin + r_kt;
+    int bimg = fdiv_w(pix, hw_out);
+    int rem = pix - bimg * hw_out;
+    unsigned ycol[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const int col = m0 + 64 * a + sc4;
+        ycol[a] = col < p.M ? (unsigned)col * 4u : OOB;
+    }
+    const unsigned ldyb = (unsigned)p.ldy * 4u;
+    auto issue = [&](const int stage) {
+        const bool pok = pix < k_end;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(stage * STAGE + wave * 1024)));
+        const unsigned yrow = (unsigned)pix * ldyb;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) dma_piece_w(rsy, (pok && ycol[a] != OOB) ? yrow + ycol[a] : OOB, dst + (unsigned)(a * PANEL));
+        const int oy = fdiv_w(rem, p.wout), ox = rem - oy * p.wout;
+        const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+        const int irow0 = bimg * p.hin;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const int iy = iy0 + ky[c], ix = ix0 + kx[c];
+            const bool ok = pok && cok[c] && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
+            const unsigned ipix = (unsigned)((irow0 + iy) * p.win + ix);
+            if (src2[c]) {      // (uniform branch)
+                dma_piece_w(rs2, ok ? (ipix * (unsigned)p.ldx2 + (unsigned)(ci0[c] - p.c1 + sc4)) * 4u : OOB, dst + (unsigned)((NA + c) * PANEL));
+            } else {
+                dma_piece_w(rs1, ok ? (ipix * (unsigned)p.ldx1 + (unsigned)(ci0[c] + sc4)) * 4u : OOB, dst + (unsigned)((NA + c) * PANEL));
+            }
+        }
+        pix += BK;
+        rem += BK;
+        while (rem >= hw_out) { rem -= hw_out; ++bimg; }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // operand of k-step ks (pixels 2 ks, 2 ks + 1), 32-channel block blk: one float per lane
+    const int fo = hh * 256 + l31 * 4;
+    auto opnd = [&](const char* panel, const int blk, const int ks) -> float { return *reinterpret_cast<const float*>(panel + fo + ks * 512 + blk * 128); };
+
+    const int nkt = (k_end - k_begin + BK - 1) / BK;
+    if (nkt > 0) {
+        issue(0);
+        issue(1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int st = 0, st2 = 2;
+        for (int kt = 0; kt < nkt; ++kt) {
+            issue(st2);
+            const char* pa = smem + st * STAGE + wm * PANEL;
+            const char* pb = smem + st * STAGE + (NA + wn) * PANEL;
+            float fa[2][2], fb[2][2];
+            fa[0][0] = opnd(pa, 0, 0); fa[0][1] = opnd(pa, 1, 0); fb[0][0] = opnd(pb, 0, 0); fb[0][1] = opnd(pb, 1, 0);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int c = ks & 1, n = c ^ 1;
+                if (ks < 15) { fa[n][0] = opnd(pa, 0, ks + 1); fa[n][1] = opnd(pa, 1, ks + 1); fb[n][0] = opnd(pb, 0, ks + 1); fb[n][1] = opnd(pb, 1, ks + 1); }
+                if (ks == 15) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // this wave's pieces of k-tile kt + 1 have landed; its reads of k-tile kt have returned
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");
+            st2 = st;
+            st = st == NSTAGE - 1 ? 0 : st + 1;
+        }
+    }
+    float* out = p.out + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + 32 * j + l31;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (m < p.M) out[(long)m * p.N + n] = acc[i][j][r] * p.alpha;
+            }
+    }
+}
+
 int device_cus();   // api.hip
 
 // pixel split: one workgroup per CU and round.  Among the split counts that leave >= 8 k-tiles per workgroup the one with the best product of
 // (filled fraction of the last round) x (k-tiles / (k-tiles + 3): the pipeline fill of a workgroup) — e.g. conv 320 -> 320 3x3 at 32 x 72^2:
 // 36 tiles x 7 splits = 252 workgroups = 0.98 rounds, not 36 x 22 = 3.09.
-static void wgrad_plan(long M, long N, long P, int& nsplit, int& kchunk, int& na) {
+static void wgrad_plan(long M, long N, long P, int& nsplit, int& kchunk, int& na, const int bk = wg::BK) {
     // tile shape: the one whose grid multiplies less padding (a 1x1 layer with 320 input and 2560 output channels: 10 x 3 tiles of 256 x 128 = 83 % useful
     // against 20 x 2 tiles of 128 x 256 = 62 %); ties keep 128 x 256
     const long area2 = cdiv(M, 128) * 128L * cdiv(N, 256) * 256L, area4 = cdiv(M, 256) * 256L * cdiv(N, 128) * 128L;
@@ -250,7 +402,7 @@ static void wgrad_plan(long M, long N, long P, int& nsplit, int& kchunk, int& na
     const long tiles = na == 2 ? (long)cdiv(M, 128) * cdiv(N, 256) : (long)cdiv(M, 256) * cdiv(N, 128);
     int cus = device_cus();
     if (cus <= 0) cus = 256;
-    const long ktiles = cdiv(P, wg::BK);
+    const long ktiles = cdiv(P, bk);
     long cap = ktiles / 8;
     if (cap < 1) cap = 1;
     if (cap > 4L * cus) cap = 4L * cus;
@@ -263,7 +415,7 @@ static void wgrad_plan(long M, long N, long P, int& nsplit, int& kchunk, int& na
         const double score = (double)w / (double)(rounds * cus) * (double)kt / (double)(kt + 3);
         if (score > best * 1.0000001) { best = score; best_ns = real_ns; }
     }
-    kchunk = (int)(cdiv(ktiles, best_ns) * wg::BK);
+    kchunk = (int)(cdiv(ktiles, best_ns) * bk);
     nsplit = (int)cdiv(P, kchunk);
 }
 
@@ -273,7 +425,9 @@ using namespace e2eft;
 
 static int wgrad_check(const E2eftConvDesc* d, int lddy) {
     if (!d) return fail(E2EFT_ERR_BAD_ARG, "wgrad: null descriptor");
-    if (d->dtype != E2EFT_F16 && d->dtype != E2EFT_BF16) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: 16-bit only (fp32 keeps the transpose + GEMM path)");
+    if (d->dtype != E2EFT_F16 && d->dtype != E2EFT_BF16 && d->dtype != E2EFT_F32) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: dtype %d", d->dtype);
+    const long es = (long)dtype_size(d->dtype);
+    const int epc = (int)(16 / es);
     const int cin = d->c1 + d->c2;
     if (cin % 64 != 0 || d->c1 % 64 != 0) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: channel counts (%d, %d) must be multiples of 64", d->c1, d->c2);
     if (d->hl != d->hin || d->wl != d->win) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: fused upsample not supported");
@@ -281,10 +435,10 @@ static int wgrad_check(const E2eftConvDesc* d, int lddy) {
         return fail(E2EFT_ERR_BAD_ARG, "wgrad: geometry");
     const long P = (long)d->batch * d->hout * d->wout, xpix = (long)d->batch * d->hin * d->win;
     const long ldx = d->ldx1 > d->ldx2 ? d->ldx1 : d->ldx2;
-    if (P * lddy * 2 >= 0xFFFF0000L || xpix * ldx * 2 >= 0xFFFF0000L) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: tensors of 4 GB and more");
+    if (P * lddy * es >= 0xFFFF0000L || xpix * ldx * es >= 0xFFFF0000L) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: tensors of 4 GB and more");
     if (P >= (1L << 24)) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: more than 2^24 output pixels (the pixel split uses float reciprocals)");
     if ((long)d->hout * d->wout >= (1L << 22)) return fail(E2EFT_ERR_UNSUPPORTED, "wgrad: image too large for the index arithmetic");
-    if (d->ldx1 % 8 != 0 || (d->c2 > 0 && d->ldx2 % 8 != 0) || lddy % 8 != 0 || lddy < d->cout) return fail(E2EFT_ERR_BAD_ARG, "wgrad: row strides");
+    if (d->ldx1 % epc != 0 || (d->c2 > 0 && d->ldx2 % epc != 0) || lddy % epc != 0 || lddy < d->cout) return fail(E2EFT_ERR_BAD_ARG, "wgrad: row strides");
     return E2EFT_OK;
 }
 
@@ -292,7 +446,7 @@ extern "C" size_t e2eft_conv2d_wgrad_workspace_bytes(const E2eftConvDesc* d, int
     if (wgrad_check(d, lddy) != E2EFT_OK) return 0;
     int nsplit, kchunk, na;
     const long N = (long)d->kh * d->kw * (d->c1 + d->c2);
-    wgrad_plan(d->cout, N, (long)d->batch * d->hout * d->wout, nsplit, kchunk, na);
+    wgrad_plan(d->cout, N, (long)d->batch * d->hout * d->wout, nsplit, kchunk, na, d->dtype == E2EFT_F32 ? wg32::BK : wg::BK);
     return (size_t)nsplit * d->cout * N * sizeof(float);
 }
 
@@ -309,7 +463,7 @@ extern "C" int e2eft_conv2d_wgrad(const E2eftConvDesc* d, const void* dy, int32_
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
     p.M = d->cout; p.N = d->kh * d->kw * p.cin; p.P = d->batch * d->hout * d->wout;
     int na;
-    wgrad_plan(p.M, p.N, p.P, p.nsplit, p.kchunk, na);
+    wgrad_plan(p.M, p.N, p.P, p.nsplit, p.kchunk, na, d->dtype == E2EFT_F32 ? wg32::BK : wg::BK);
     p.alpha = d->alpha;
     const size_t need = (size_t)p.nsplit * p.M * p.N * sizeof(float);
     if (partial_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "wgrad: partial buffer %zu < %zu bytes", partial_bytes, need);
@@ -317,7 +471,10 @@ extern "C" int e2eft_conv2d_wgrad(const E2eftConvDesc* d, const void* dy, int32_
     dim3 grid(cdiv(p.N, na == 2 ? 256 : 128), cdiv(p.M, na == 2 ? 128 : 256), p.nsplit);
     E2EFT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "wgrad: grid");
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == E2EFT_F16) {
+    if (d->dtype == E2EFT_F32) {
+        if (na == 2) hipLaunchKernelGGL((wgrad32_kernel<2>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((wgrad32_kernel<4>), grid, dim3(512), 0, s, p);
+    } else if (d->dtype == E2EFT_F16) {
         if (na == 2) hipLaunchKernelGGL((wgrad_kernel<f16, 2>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((wgrad_kernel<f16, 4>), grid, dim3(512), 0, s, p);
     } else {

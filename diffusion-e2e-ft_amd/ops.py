@@ -845,6 +845,7 @@ def im2col_t(x, x2, kh, kw, stride, pad, up_to=None, Pp=None):
 
 
 WGRAD_DIRECT = True   # tests / A-B: False keeps every weight gradient on the transpose + im2col_t + split-K GEMM path
+WGRAD_DIRECT_FP32 = True   # round 6: strict-fp32 weight gradients straight from the NHWC tensors too (csrc/wgrad.hip::wgrad32_kernel); False: the round-5 path
 
 
 def conv2d_wgrad(dy, x, x2, cout, kh, kw, stride, pad, alpha, out=None):
@@ -854,7 +855,7 @@ def conv2d_wgrad(dy, x, x2, cout, kh, kw, stride, pad, alpha, out=None):
     itself when it does not split — writes there, no copy / add afterwards).
     The kernel addresses each operand through ONE 32-bit buffer descriptor, so tensors of 4 GB and more (configs[2] as benchmarked: 32 images of
     576^2 x 256 channels = 5.4 GB) are cut along the batch into launches below that limit; every launch adds its split partials to the same reduction."""
-    if not WGRAD_DIRECT or dy.dtype == torch.float32:
+    if not WGRAD_DIRECT or (dy.dtype == torch.float32 and not WGRAD_DIRECT_FP32):
         return None
     _check_cuda(dy, x, x2)
     B = x.shape[0]
@@ -894,7 +895,7 @@ def conv2d_wgrad(dy, x, x2, cout, kh, kw, stride, pad, alpha, out=None):
 def linear_wgrad(dy2d, x2d, alpha=1.0, out=None):
     """dW [N, K] fp32 = alpha * dy2d^T x2d for row views dy2d [M, N], x2d [M, K] (K a multiple of 64) — the 1x1 case of conv2d_wgrad; None = fall back.
     out: see conv2d_wgrad"""
-    if not WGRAD_DIRECT or dy2d.dtype == torch.float32 or x2d.shape[1] % 64 != 0:
+    if not WGRAD_DIRECT or (dy2d.dtype == torch.float32 and not WGRAD_DIRECT_FP32) or x2d.shape[1] % 64 != 0:
         return None
     M, N = dy2d.shape
     K = x2d.shape[1]
@@ -902,7 +903,7 @@ def linear_wgrad(dy2d, x2d, alpha=1.0, out=None):
         ldy, ldx = _rows_ld(dy2d), _rows_ld(x2d)
     except ValueError:
         return None
-    if ldy % 8 != 0 or ldx % 8 != 0 or dy2d.data_ptr() % 16 != 0 or x2d.data_ptr() % 16 != 0:
+    if ldy % epc(dy2d.dtype) != 0 or ldx % epc(dy2d.dtype) != 0 or dy2d.data_ptr() % 16 != 0 or x2d.data_ptr() % 16 != 0:
         return None
     xv = x2d.as_strided((1, 1, M, K), (M * ldx, M * ldx, ldx, 1))
     dv = dy2d.as_strided((1, 1, M, N), (M * ldy, M * ldy, ldy, 1))

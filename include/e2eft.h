@@ -264,7 +264,7 @@ int e2eft_attn512_fwd(const E2eftAttnDesc* d, const void* q, const void* k, cons
  * — torch autograd of nn.Conv2d / nn.Linear w.r.t. the weight (training/train.py:563).  dy: [batch*hout*wout][lddy] (cout columns used), x1 / x2: the
  * forward's input(s).  The pixel sum is split over the grid; `partial` receives fp32 [nsplit][cout][kh*kw*(c1+c2)] and *nsplit_out the number of
  * splits to add up (e2eft_colsum).  e2eft_conv2d_wgrad_workspace_bytes: the size of `partial`, or 0 when this kernel does not serve the problem
- * (fp32, channel counts not multiples of 64, fused upsample, >= 4 GB tensors): the caller then uses e2eft_transpose + e2eft_conv2d_im2col_t +
+ * (channel counts not multiples of 64, fused upsample, >= 4 GB tensors; fp32 is served since round 6, on v_mfma_f32_32x32x2_f32): the caller then uses e2eft_transpose + e2eft_conv2d_im2col_t +
  * e2eft_gemm; e2eft_conv2d_wgrad itself returns E2EFT_ERR_UNSUPPORTED for those. */
 size_t e2eft_conv2d_wgrad_workspace_bytes(const E2eftConvDesc* d, int32_t lddy);
 int e2eft_conv2d_wgrad(const E2eftConvDesc* d, const void* dy, int32_t lddy, const void* x1, const void* x2, float* partial, size_t partial_bytes,

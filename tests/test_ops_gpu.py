@@ -103,6 +103,24 @@ def test_conv3x3_basic(ops, dev, dtype):
     _conv_case(ops, dev, dtype, 3, 320, 320, 12, 12, 3, 1, (1, 1, 1, 1), rowadd=True)
 
 
+def test_conv3x3_narrow_output_fp32(ops, dev):
+    """round 6: the strict-fp32 recipe's decoder conv_out (128 -> 3 at full resolution, training/train.py:241-242) on the LDS-halo kernel's fp32 form
+    (v_fma_f32 with scalar-loaded weights; 32-channel chunks) instead of a 128-wide MFMA tile: exact-fp32 bar, the kernel name checked"""
+    import ctypes
+    from diffusion_e2e_ft_amd import _lib
+    lib = _lib.load()
+    lib.e2eft_debug_last_kernel.restype = ctypes.c_char_p
+    dtype = torch.float32
+    _conv_case(ops, dev, dtype, 2, 128, 3, 96, 96, 3, 1, (1, 1, 1, 1))
+    assert lib.e2eft_debug_last_kernel().decode() == "conv3x3_narrow_kernel", lib.e2eft_debug_last_kernel()
+    _conv_case(ops, dev, dtype, 2, 128, 4, 100, 90, 3, 1, (1, 1, 1, 1), alpha=0.7)
+    _conv_case(ops, dev, dtype, 1, 72, 1, 131, 127, 3, 1, (1, 1, 1, 1))        # a 32-, a 32- and an 8-channel chunk
+    _conv_case(ops, dev, dtype, 3, 64, 2, 80, 80, 3, 1, (1, 1, 1, 1))
+    _conv_case(ops, dev, dtype, 1, 4, 3, 128, 130, 3, 1, (1, 1, 1, 1))
+    _conv_case(ops, dev, dtype, 2, 320, 4, 100, 90, 3, 1, (1, 1, 1, 1))        # Cin > 128 stays on the MFMA kernel
+    assert "narrow" not in lib.e2eft_debug_last_kernel().decode()
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_conv3x3_narrow_output(ops, dev, dtype):
     """<= 4 output channels on >= 16k pixels take the LDS-halo kernels (csrc/narrow.hip; MFMA 16x16x32 form when Cin % 32 == 0, packed

@@ -9,7 +9,7 @@ import torch.nn.functional as TF
 from util import rel_err
 
 pytestmark = pytest.mark.gpu
-TOL = {torch.float16: 3e-3, torch.bfloat16: 2e-2}
+TOL = {torch.float16: 3e-3, torch.bfloat16: 2e-2, torch.float32: 2e-5}      # fp32 (round 6, wgrad32_kernel): exact fp32 products and sums, another summation order than torch's
 
 
 def _conv_case(dev, dtype, B, H, W, c1, c2, Co, k, stride, seed):
@@ -31,7 +31,7 @@ def _conv_case(dev, dtype, B, H, W, c1, c2, Co, k, stride, seed):
     return rel_err(got, want)
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("B,H,W,c1,c2,Co,k,stride", [
     (2, 16, 16, 64, 0, 64, 3, 1),          # 512 pixels, one tile
     (1, 24, 40, 128, 0, 320, 3, 1),        # Co = 320 (2.5 row tiles), 960 pixels
@@ -60,13 +60,17 @@ def test_linear_wgrad_and_fallbacks(dev):
     wide = torch.randn(770, 3 * 640, generator=g).half().to(dev)
     got2 = ops.linear_wgrad(wide[:, 640:1280], x.to(dev))
     assert got2 is not None and rel_err(got2, wide[:, 640:1280].float().cpu().t() @ x.float()) <= 3e-3
-    # not this kernel's problems -> None (the caller keeps the GEMM path): fp32, K not a multiple of 64
-    assert ops.linear_wgrad(dy.float().to(dev), x.float().to(dev)) is None
+    # strict fp32 (round 6): the same call on wgrad32_kernel, incl. the strided q | k | v slice
+    got3 = ops.linear_wgrad(dy.float().to(dev), x.float().to(dev), 0.5)
+    assert got3 is not None and rel_err(got3, 0.5 * want) <= 2e-5
+    got4 = ops.linear_wgrad(wide.float()[:, 640:1280], x.float().to(dev))
+    assert got4 is not None and rel_err(got4, wide[:, 640:1280].float().cpu().t() @ x.float()) <= 2e-5
+    # not this kernel's problems -> None (the caller keeps the GEMM path): K not a multiple of 64
     assert ops.linear_wgrad(dy.to(dev), torch.randn(770, 72).half().to(dev)) is None
     assert ops.conv2d_wgrad(torch.zeros(1, 8, 8, 64, device=dev).half(), torch.zeros(1, 8, 8, 8, device=dev).half(), None, 64, 3, 3, 1, (1, 1, 1, 1), 1.0) is None
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 def test_direct_wgrad_equals_the_gemm_path_through_autograd(dev, dtype):
     """the same conv module's weight gradient through autograd with the direct kernel and with the transpose + im2col_t + GEMM path"""
     from diffusion_e2e_ft_amd import ops
@@ -84,4 +88,4 @@ def test_direct_wgrad_equals_the_gemm_path_through_autograd(dev, dtype):
             grads.append(conv.weight.grad.detach().float().clone())
         finally:
             ops.WGRAD_DIRECT = True
-    assert grads[0].is_contiguous() and rel_err(grads[0], grads[1]) <= (2e-3 if dtype == torch.float16 else 1.5e-2)
+    assert grads[0].is_contiguous() and rel_err(grads[0], grads[1]) <= {torch.float16: 2e-3, torch.bfloat16: 1.5e-2, torch.float32: 2e-5}[dtype]
