@@ -62,6 +62,22 @@ template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>&
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // v_rcp_f32: 1 ulp, no division sequence
+// GroupNorm(+SiLU) apply on 16-bit tensors, in the exp2 domain (round 6): with a = rstd * gamma,  a2 = a * log2(e),  d2 = fma(-mean, a, beta) * log2(e)
+//     u = fma(x, a2, d2) = log2(e) * ((x - mean) * a + beta)
+//     SiLU:  u * rcp(fma(exp2(-u), log2(e), log2(e))) = t / (1 + e^-t)            no activation:  u * ln(2) = t
+// — 4 operations per value after the fma (exp2 with a negated operand, fma, rcp, mul) instead of 6 (sub, mul, exp2, add, rcp, mul): the fused form in igemm6's patch
+// staging is VALU-bound, every instruction there is matrix-pipe time.  gn_apply_kernel (norm.hip), the halo staging of narrow.hip and igemm6's
+// in-LDS form use EXACTLY these operations in this order: their results are bit-identical (tests/test_fused_norm_conv_gpu.py).  x * a2 - mean * a2 cancels to
+// ~|mean| / sigma * 2^-24 relative — four decimal orders below a 16-bit output's rounding; fp32 tensors keep (x - mean) * a + beta.
+constexpr float GN_L2E = 1.4426950408889634f, GN_LN2 = 0.6931471805599453f;
+__device__ __forceinline__ void gn_fold(const float a, const float mean, const float beta, float& a2, float& d2) {
+    a2 = a * GN_L2E;
+    d2 = __builtin_fmaf(-mean, a, beta) * GN_L2E;
+}
+__device__ __forceinline__ float gn_act_u(const float u, const bool silu) {
+    const float r = silu ? __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-u), GN_L2E, GN_L2E)) : GN_LN2;
+    return u * r;
+}
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -28,7 +28,7 @@
 // Measured (profiles/r03h_patch_conv_ab.txt, one box, igemm5 -> igemm6, TF/s): 128->128 @768^2 896 -> 1011, 256->256 @384^2 1007 -> 1115, 512->512 @192^2
 // 1065 -> 1182, 256->128 @768^2 1011 -> 1138: +10.7 ... +13.8 %; the step of BASELINE configs[1] 107.0 -> 99.1 ms.
 // NORM variant (inference, cout <= 128; template flag): the input is read through a GroupNorm(+SiLU) that was never applied — see the kernel's comment.
-// LDS: 2 x 43 KiB patch buffers + 3 x 16 KiB weight ring + 6 KiB statistics deposits + 8 KiB dump = 148 KiB (+ 7.5 KiB coefficient table with NORM).
+// LDS: 2 x 43 KiB patch buffers + 3 x 16 KiB weight ring + 6 KiB statistics deposits + 8 KiB dump = 148 KiB (+ 5 KiB coefficient table with NORM).
 // Summation order: per output element k runs (chunk, tap) instead of (tap, chunk) — fp32 accumulation, results differ from igemm5 in the
 // last bits (documented in include/e2eft.h; deterministic run to run).
 #include "igemm.h"
@@ -56,8 +56,8 @@ template <int KT> struct Geo {
     static constexpr int OFF_DEP = OFF_B + 3 * B_STAGE;
     static constexpr int OFF_DUMP = OFF_DEP + DEP;
     static constexpr int LDS = OFF_DUMP + NW * 1024;                        // 151,552 / 141,312 B
-    static constexpr int OFF_TAB = LDS, OFF_TABM = OFF_TAB + NORM_CMAX * 4, OFF_TABB = OFF_TABM + NORM_CMAX * 4;   // a[C], mean[C], beta[C] (fp32) of the loader's image
-    static constexpr int LDS_NORM = OFF_TABB + NORM_CMAX * 4;               // 159,232 B
+    static constexpr int OFF_TAB = LDS, OFF_TABM = OFF_TAB + NORM_CMAX * 4;   // a2[C], d2[C] (fp32; common.h::gn_fold) of the loader's image
+    static constexpr int LDS_NORM = OFF_TABM + NORM_CMAX * 4;               // 156,672 B
     // A pieces a wave issues in k-tile t of a chunk (the next chunk's patch): 3x3 — one in k-tiles 0-5; 2x2 — two in k-tiles 0 and 1, one in k-tile 2.  Never in the
     // chunk's LAST k-tile: the wait that closes it may leave only that k-tile's own two weight pieces in flight (the next chunk reads the patch right after it)
     static constexpr int a_count(int t) { return KT == 3 ? (t < 6 ? 1 : 0) : (t < 2 ? 2 : t == 2 ? 1 : 0); }
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     using G = Geo<KT>;
     static_assert(KT == 3 || (KT == 2 && !NORM), "taps: 3x3, or 2x2 without the fused GroupNorm");
     constexpr int NT = G::NT, PW = G::PW, PROWS = G::PROWS, PPIECES = G::PPIECES, NPI = G::NPI, PATCH = G::PATCH, OFF_B = G::OFF_B, OFF_DEP = G::OFF_DEP, OFF_DUMP = G::OFF_DUMP;
-    constexpr int OFF_TAB = G::OFF_TAB, OFF_TABM = G::OFF_TABM, OFF_TABB = G::OFF_TABB;
+    constexpr int OFF_TAB = G::OFF_TAB, OFF_TABM = G::OFF_TABM;
     __shared__ __attribute__((aligned(128))) char smem[NORM ? G::LDS_NORM : G::LDS];
     typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -171,11 +171,11 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
                 tab_img = d_img;
                 float* ta = reinterpret_cast<float*>(smem + OFF_TAB);
                 float* tm = reinterpret_cast<float*>(smem + OFF_TABM);
-                float* tb = reinterpret_cast<float*>(smem + OFF_TABB);
-                for (int c = tid; c < p.cin; c += 512) {
-                    ta[c] = p.nrm_ad[((long)d_img * p.cin + c) * 2];
-                    tm[c] = p.nrm_ad[((long)d_img * p.cin + c) * 2 + 1];
-                    tb[c] = p.nrm_beta ? to_f(((const T*)p.nrm_beta)[c]) : 0.f;
+                for (int c = tid; c < p.cin; c += 512) {      // (a2, d2) of the exp2-domain form (common.h::gn_fold — the operations gn_apply_kernel performs per thread)
+                    float a2, d2;
+                    gn_fold(p.nrm_ad[((long)d_img * p.cin + c) * 2], p.nrm_ad[((long)d_img * p.cin + c) * 2 + 1], p.nrm_beta ? to_f(((const T*)p.nrm_beta)[c]) : 0.f, a2, d2);
+                    ta[c] = a2;
+                    tm[c] = d2;
                 }
             }
         }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     // covers them —, four values are computed behind each of the last two MFMA groups, then the unit is written back.  Inline-asm DS instructions
     // (in front of LDS accesses it can see the compiler may drain vmcnt: pieces are in flight by design).
     u32x4 n_x;
-    floatx4 n_a, n_m, n_b;      // coefficients of four channels at a time: a, mean, beta (natural register pairs for the packed fp32 instructions)
+    floatx4 n_a, n_m;           // coefficients of four channels at a time: a2, d2 (natural register pairs for the packed fp32 instructions)
     u32x4 n_o;
     unsigned n_addr = 0, n_t = 0;
     bool n_on = false;
@@ -232,56 +232,54 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         n_t = lds_base + (unsigned)OFF_TAB + (unsigned)n_c0 * 4u;
         const unsigned ad = n_addr, ta = n_t;
         u32x4 x0;
-        floatx4 t0, t1, t2;     // (asm outputs into locals: clang does not capture variables that appear only as asm operands of a nested generic lambda)
+        floatx4 t0, t1;         // (asm outputs into locals: clang does not capture variables that appear only as asm operands of a nested generic lambda)
         asm volatile("ds_read_b128 %0, %1" : "=v"(x0) : "v"(ad) : "memory");
         asm volatile("ds_read_b128 %0, %1" : "=v"(t0) : "v"(ta) : "memory");
         asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(t1) : "v"(ta), "n"(NORM_CMAX * 4) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(t2) : "v"(ta), "n"(NORM_CMAX * 8) : "memory");
-        n_x = x0; n_a = t0; n_m = t1; n_b = t2;
+        n_x = x0; n_a = t0; n_m = t1;
     };
     auto norm_issue2 = [&]() {   // the coefficients of the unit's last four channels (into the registers the first half is done with)
         const unsigned ta = n_t;
-        floatx4 t0, t1, t2;
+        floatx4 t0, t1;
         asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(t0) : "v"(ta) : "memory");
         asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(t1) : "v"(ta), "n"(NORM_CMAX * 4 + 16) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(t2) : "v"(ta), "n"(NORM_CMAX * 8 + 16) : "memory");
-        n_a = t0; n_m = t1; n_b = t2;
+        n_a = t0; n_m = t1;
     };
     auto norm_wait = [&]() {
         u32x4 x0 = n_x;
-        floatx4 t0 = n_a, t1 = n_m, t2 = n_b;
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(t0), "+v"(t1), "+v"(t2) :: "memory");
-        n_x = x0; n_a = t0; n_m = t1; n_b = t2;
+        floatx4 t0 = n_a, t1 = n_m;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(t0), "+v"(t1) :: "memory");
+        n_x = x0; n_a = t0; n_m = t1;
     };
-    // the four reads of norm_issue are the OLDEST of the (at most) twelve LDS reads in flight when this runs (eight fragment reads were requested behind them;
+    // the three reads of norm_issue are the OLDEST of the (at most) eleven LDS reads in flight when this runs (eight fragment reads were requested behind them;
     // LDS returns in order, LDS-DMA counts on vmcnt, the loop has no scalar loads): at most eight outstanding = they are back
     auto norm_ready = [&]() {
         u32x4 x0 = n_x;
-        floatx4 t0 = n_a, t1 = n_m, t2 = n_b;
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x0), "+v"(t0), "+v"(t1), "+v"(t2) :: "memory");
-        n_x = x0; n_a = t0; n_m = t1; n_b = t2;
+        floatx4 t0 = n_a, t1 = n_m;
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x0), "+v"(t0), "+v"(t1) :: "memory");
+        n_x = x0; n_a = t0; n_m = t1;
     };
     auto norm_mark = [&]() {    // behind a wait that already covered norm_issue2's reads (the barrier's lgkmcnt(0)): only tells the compiler where the values exist
-        floatx4 t0 = n_a, t1 = n_m, t2 = n_b;
-        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2) :: "memory");
-        n_a = t0; n_m = t1; n_b = t2;
+        floatx4 t0 = n_a, t1 = n_m;
+        asm volatile("" : "+v"(t0), "+v"(t1) :: "memory");
+        n_a = t0; n_m = t1;
     };
-    auto norm_pair = [&](auto hc, auto qc) {   // values 4 hf + 2 q2, + 1 of the unit: gn_apply_kernel's arithmetic (norm.hip) on a natural fp32 pair — packed sub / fma / mul, one v_exp + one v_rcp per value, one packed convert
+    auto norm_pair = [&](auto hc, auto qc) {   // values 4 hf + 2 q2, + 1 of the unit: gn_apply_kernel's arithmetic (norm.hip) on a natural fp32 pair — packed fma / mul, one v_exp + one v_fma + one v_rcp per value, one packed convert (13 VALU instructions; 16 before round 6)
         constexpr int hf = decltype(hc)::value, q2 = decltype(qc)::value;
         typedef T T2 __attribute__((ext_vector_type(2)));
         Vec16<T> v;
         v.raw = n_x;
         constexpr int e = 4 * hf + 2 * q2;
         const f2 xx = {to_f(v.e[e]), to_f(v.e[e + 1])};
-        const f2 aa = {n_a[2 * q2], n_a[2 * q2 + 1]}, mu = {n_m[2 * q2], n_m[2 * q2 + 1]}, be = {n_b[2 * q2], n_b[2 * q2 + 1]};
-        f2 t = __builtin_elementwise_fma(xx - mu, aa, be);
-        {   // silu_f (common.h): t * rcp(1 + exp2(-log2(e) * t)).  The constant operands stay scalar instructions: a packed form would
-            // broadcast them with op_sel — the operand-swizzle family of DESIGN.md §3.6; sub / fma / the last mul run on natural pairs.
-            // Without SiLU the factor is selected to 1 (two v_cndmask instead of a branch: see norm_issue)
-            float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[0] * -1.4426950408889634f));
-            float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[1] * -1.4426950408889634f));
-            if (!n_silu) { r0 = 1.0f; r1 = 1.0f; }
-            t = t * f2{r0, r1};
+        const f2 aa = {n_a[2 * q2], n_a[2 * q2 + 1]}, dd = {n_m[2 * q2], n_m[2 * q2 + 1]};
+        const f2 u = __builtin_elementwise_fma(xx, aa, dd);      // log2(e) * ((x - mean) * a + beta): gn_apply_kernel's exp2-domain arithmetic (common.h)
+        f2 t;
+        {   // gn_act_u (common.h): u * rcp(fma(exp2(-u), log2 e, log2 e)), or u * ln 2 without SiLU (a select, not a branch: see norm_issue).  The constant operands
+            // stay scalar instructions: a packed form would broadcast them with op_sel — the operand-swizzle family of DESIGN.md §3.6; fma / the last mul run on natural pairs
+            float r0 = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-u[0]), GN_L2E, GN_L2E));
+            float r1 = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-u[1]), GN_L2E, GN_L2E));
+            if (!n_silu) { r0 = GN_LN2; r1 = GN_LN2; }
+            t = u * f2{r0, r1};
         }
         n_o[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, T2));
     };
@@ -289,10 +287,12 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     // one MFMA group with one value pair's arithmetic in its shadow: the matrix pipe takes 32 cycles per MFMA, the wave's VALU issues meanwhile — as long as
     // the instructions alternate.  (Round 3 placed each half behind a whole group: the pipe idled while 30 VALU instructions ran, 806-861 TF/s against 1160-1190.)
     auto interleave4 = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four VALU, then three behind each further MFMA (13 per value pair)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four VALU
+        for (int i = 0; i < 3; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         }
     };
     auto norm_store = [&](auto ic) {

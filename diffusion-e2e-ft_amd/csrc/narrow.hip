@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_narrow_mfma_kernel(const Narro
                 na[e] = p.nrm_ad[((long)blockIdx.y * p.cin + c + e) * 2];
                 nm[e] = p.nrm_ad[((long)blockIdx.y * p.cin + c + e) * 2 + 1];
                 nb[e] = p.nrm_beta ? to_f(((const T*)p.nrm_beta)[c + e]) : 0.f;
+                gn_fold(na[e], nm[e], nb[e], na[e], nb[e]);      // (a2, d2): gn_apply_kernel's exp2-domain arithmetic (common.h)
             }
         }
         __syncthreads();                              // the previous chunk is consumed
@@ -180,9 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_narrow_mfma_kernel(const Narro
                 if (nrm) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float t = fmaf(to_f(v.e[e]) - nm[e], na[e], nb[e]);
-                        if (p.nrm_silu) t = silu_f(t);
-                        v.e[e] = from_f<T>(t);
+                        v.e[e] = from_f<T>(gn_act_u(__builtin_fmaf(to_f(v.e[e]), na[e], nb[e]), p.nrm_silu != 0));
                     }
                 }
             }

@@ -189,13 +189,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnGeom g, int silu, int l
         a[e] = ad[((long)b * g.C + c + e) * 2];
         mu[e] = ad[((long)b * g.C + c + e) * 2 + 1];
         be[e] = beta ? to_f(beta[c + e]) : 0.f;
+        if constexpr (sizeof(T) == 2) gn_fold(a[e], mu[e], be[e], a[e], be[e]);      // 16-bit: (a2, d2) of the exp2-domain form (common.h); mu is unused then
     }
     auto one = [&](long row, const Vec16<T>& v) {
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            float t = fmaf(to_f(v.e[e]) - mu[e], a[e], be[e]);
-            if (silu) t = silu_f(t);
+            float t;
+            if constexpr (sizeof(T) == 2) {
+                t = gn_act_u(__builtin_fmaf(to_f(v.e[e]), a[e], be[e]), silu != 0);
+            } else {
+                t = fmaf(to_f(v.e[e]) - mu[e], a[e], be[e]);
+                if (silu) t = silu_f(t);
+            }
             o.e[e] = from_f<T>(t);
         }
         st16(y + row * ldy + c, o);

@@ -46,6 +46,7 @@ def rank_worker(args):
     from concurrent.futures import ThreadPoolExecutor
     from diffusion_e2e_ft_amd import data
     root_dir, split_path = args.tree.split("::")
+    torch.set_num_threads(1)      # (as the parent: N processes with a 256-thread intra-op pool each would measure the OpenMP spin-waits)
     ds = data.Hypersim(root_dir, transform=True, split_path=split_path)
     torch.manual_seed(0)
     loader = data.DeviceLoader(ds, batch_size=args.batch, device="cpu", shuffle=True, drop_last=True, workers=args.workers, prefetch=3, rank=args.rank_worker, world=args.ranks)
@@ -75,7 +76,7 @@ def rank_worker(args):
 
 def run_ranks(args, root_dir, split_path):
     import subprocess
-    env = dict(os.environ, LOADER_BENCH_GO=str(time.time() + 60.0))        # imports + the warm-up epoch of every rank fit in 60 s
+    env = dict(os.environ, LOADER_BENCH_GO=str(time.time() + 60.0), OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")        # imports + the warm-up epoch of every rank fit in 60 s
     cmd = [sys.executable, os.path.abspath(__file__), "--samples", str(args.samples), "--workers", str(args.workers), "--batch", str(args.batch), "--epochs", str(args.epochs),
            "--ranks", str(args.ranks), "--tree", root_dir + "::" + split_path]
     procs = [subprocess.Popen(cmd + ["--rank-worker", str(r)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for r in range(args.ranks)]
