@@ -43,7 +43,7 @@ class AttnDesc(C.Structure):
 
 
 # e2eft_set_option keys (include/e2eft.h)
-OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV, OPT_THIN_INPUT_CONV, OPT_FUSED_NORM, OPT_ATTN_DMA, OPT_UPCONV_PHASES, OPT_PATCH_CONV_2X2, OPT_PERSISTENT_MIN_QROUNDS, OPT_GN_APPLY_ITERS = range(14)
+OPT_PERSISTENT, OPT_PERSISTENT_GRID, OPT_NARROW_CONV, OPT_NARROW_MFMA, OPT_IGEMM_GENERAL_OPERANDS, OPT_IGEMM2_WAVES, OPT_PATCH_CONV, OPT_THIN_INPUT_CONV, OPT_FUSED_NORM, OPT_ATTN_DMA, OPT_UPCONV_PHASES, OPT_PATCH_CONV_2X2, OPT_PERSISTENT_MIN_QROUNDS, OPT_GN_APPLY_ITERS, OPT_F32_SPLIT = range(15)
 
 _P = C.c_void_p
 _I = C.c_int32
@@ -70,6 +70,9 @@ SIGNATURES = {
     "e2eft_conv2d_fwd_normed_supported": (_I, [C.POINTER(ConvDesc)]),
     "e2eft_upconv2x_fwd_supported": (_I, [C.POINTER(ConvDesc)]),
     "e2eft_upconv2x_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int32), _P]),
+    "e2eft_f32_split2": (_I, [_P, _L, _I, _I, _P, _I, _P, _P]),
+    "e2eft_conv2d_fwd_f32split_supported": (_I, [C.POINTER(ConvDesc)]),
+    "e2eft_conv2d_fwd_f32split": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int32), _P]),
     "e2eft_conv2d_fwd_normed": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int32), _P]),
     "e2eft_groupnorm_workspace_bytes": (_Z, [C.POINTER(GroupNormDesc)]),
     "e2eft_groupnorm_fwd": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _Z, _P]),

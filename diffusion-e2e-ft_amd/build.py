@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libe2eft.so")
-SOURCES = ["api.hip", "igemm.hip", "igemm2.hip", "igemm5.hip", "igemm6.hip", "convin.hip", "norm.hip", "attn.hip", "attn32.hip", "attn512.hip", "attn_bwd.hip", "elementwise.hip", "loss.hip", "bwd.hip", "wgrad.hip", "ensemble.hip", "dataprep.hip", "narrow.hip", "dataaug.hip", "evalmetrics.hip", "prepost.hip"]
+SOURCES = ["api.hip", "igemm.hip", "igemm2.hip", "igemm5.hip", "igemm6.hip", "convin.hip", "norm.hip", "attn.hip", "attn32.hip", "attn512.hip", "attn_bwd.hip", "elementwise.hip", "loss.hip", "bwd.hip", "wgrad.hip", "ensemble.hip", "dataprep.hip", "narrow.hip", "dataaug.hip", "evalmetrics.hip", "prepost.hip", "f32split.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]   # exports = what include/*.h declares
 # Per-file flags.  The implicit-GEMM files are built without the SLP vectorizer: it turns the epilogue's per-column fp32
 # arithmetic into v_pk_add_f32 with operand swizzles (op_sel:[0,1] — the low result lane reads the HIGH dword of src1), and on
@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 # MFMA / LDS-DMA k-loop (two 4-wave workgroups per CU).  Found as one GroupNorm-statistics row in ~1e-5 tiles using pivot 0;
 # plain v_sub_f32 / v_add_f32 never showed it (scripts/stress_conv_stats.py).
 # attn.hip / attn512.hip: packed fp32 adds beside MFMAs cost more than the scalar ones they replace (the kernel is one wave per SIMD, every issue slot counts)
-EXTRA_FLAGS = {"attn.hip": ["-fno-slp-vectorize"], "attn32.hip": ["-fno-slp-vectorize"], "attn512.hip": ["-fno-slp-vectorize"], "igemm.hip": ["-fno-slp-vectorize"], "igemm2.hip": ["-fno-slp-vectorize"], "igemm5.hip": ["-fno-slp-vectorize"], "igemm6.hip": ["-fno-slp-vectorize"], "convin.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"attn.hip": ["-fno-slp-vectorize"], "attn32.hip": ["-fno-slp-vectorize"], "attn512.hip": ["-fno-slp-vectorize"], "igemm.hip": ["-fno-slp-vectorize"], "igemm2.hip": ["-fno-slp-vectorize"], "igemm5.hip": ["-fno-slp-vectorize"], "igemm6.hip": ["-fno-slp-vectorize"], "f32split.hip": ["-fno-slp-vectorize"], "convin.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

@@ -45,7 +45,7 @@ void tag_kernel(const char* fmt, ...) {
 }
 const char* last_tag() { return g_tag; }
 
-static std::atomic<int> g_opt[E2EFT_OPT_COUNT] = {{1}, {0}, {1}, {1}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {1}, {2}, {0}};
+static std::atomic<int> g_opt[E2EFT_OPT_COUNT] = {{1}, {0}, {1}, {1}, {0}, {0}, {1}, {1}, {1}, {1}, {1}, {1}, {2}, {0}, {1}};
 
 int option(int key) { return g_opt[key].load(std::memory_order_relaxed); }
 

@@ -50,6 +50,12 @@ struct IgemmParams {
                          // parity phase of a 2x-upsampled image: GEMM rows = low-resolution pixels (b, Y, X), out_seg = W, ldo = 2 * (pixel stride of the full
                          // image), so consecutive X land on every other pixel and consecutive Y on every other row.  Multiple of 16.
     int gn_islabs;       // > 0: statistics slabs per image in gn_partial (the image stride), when it differs from gn_nslabs (four phases share one buffer)
+    // round 6 (igemm6 only, e2eft_conv2d_fwd_f32split): an fp32 convolution on the f16 matrix pipe.  The A operand is the two-term f16 split of an fp32 tensor,
+    // planes [x0 | x1] side by side in one pixel (x * s = x0 + x1 to 22 bits, s a power of two); K runs over THREE blocks of split_c channels per tap — (x0, w0), (x0, w1),
+    // (x1, w0) — so chunk channel ch reads plane channel ch - split_c once ch >= split_c; the weights arrive laid out that way.  Bias / residual / output are fp32:
+    // out = acc * (alpha * *alpha_dev) + bias + residual   (alpha_dev: device scalar 1 / s of the activation split; alpha carries 1 / s_w and the caller's factor)
+    int split_c;         // > 0: channels of one plane (cin = 3 * split_c)
+    const float* alpha_dev;
     int debug_flags;     // instrumented build (-DE2EFT_STAMPS) only: bit 0 / 1 / 2 = the persistent kernel issues its A-operand LDS-DMA never / on the
                          // first tap of a filter row only / on the first tap of a 64-channel chunk only (WRONG results; the price of operand
                          // delivery: profiles/r03d_a_operand_delivery_probe.txt, "what an A-reuse scheme could buy at most")

@@ -181,7 +181,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_narrow_mfma_kernel(const Narro
                 if (nrm) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        v.e[e] = from_f<T>(gn_act_u(__builtin_fmaf(to_f(v.e[e]), na[e], nb[e]), p.nrm_silu != 0));
+                        float t = gn_act_u(__builtin_fmaf(to_f(v.e[e]), na[e], nb[e]), p.nrm_silu != 0);
+                        asm("" : "+v"(t));      // the fp32 product exists before it is rounded to T, as in gn_apply_kernel (mul, then cvt_pk): without this the
+                        v.e[e] = from_f<T>(t);  // compiler emits v_fma_mixlo_f16 (u * r rounded ONCE to fp16) and the two routes differ in the last bit
                     }
                 }
             }

@@ -246,9 +246,75 @@ def _attach_stats(out, buf, slab_rows, images, rows_per_image, cout):
     return out
 
 
+F32_SPLIT_ENABLED = True      # tests / A-B: False keeps fp32 3x3 convolutions on the fp32 matrix instruction (igemm2)
+
+
+def f32_split2(x):
+    """fp32 NHWC [B,H,W,C] (C % 8 == 0) -> (planes f16 [B,H,W,2C] = [x0 | x1] with x * s = x0 + x1 to 2^-22, scale workspace fp32 [4]: [1] = s, [2] = 1 / s).
+    s is the power of two that brings the tensor's maximum into [2^14, 2^15), found on the device (csrc/f32split.hip)."""
+    _check_cuda(x)
+    B, H, W, Cc = x.shape
+    assert x.dtype == torch.float32 and Cc % 8 == 0
+    planes = torch.empty((B, H, W, 2 * Cc), dtype=torch.float16, device=x.device)
+    scale = torch.empty(4, dtype=torch.float32, device=x.device)
+    with _timed("f32split", 0.0, 12.0 * B * H * W * Cc, label="split2 B%d %dx%d C%d" % (B, H, W, Cc), launches=2):
+        check(_lib.load().e2eft_f32_split2(_ptr(x), B * H * W, Cc, _nhwc_ld(x), _ptr(planes), 2 * Cc, _ptr(scale), _stream()))
+    return planes, scale
+
+
+def f32_split_weight(w_packed, taps, c):
+    """fp32 packed weight [cout, taps*c] (rows (tap, c)) -> (f16 [cout, taps*3c] rows (tap, [w0 | w1 | w0]) with w * s_w = w0 + w1, 1 / s_w).  Cached on the packed tensor
+    (autograd.packed_conv_weight hands out one object per parameter version); one host read of the maximum per weight version."""
+    ent = getattr(w_packed, "_e2eft_split", None)
+    if ent is not None and ent[0] == w_packed._version:
+        return ent[1], ent[2]
+    cout = w_packed.shape[0]
+    assert w_packed.dtype == torch.float32 and w_packed.shape[1] == taps * c
+    import math
+    amax = float(w_packed.detach().abs().max())
+    k = 0 if (amax == 0.0 or not math.isfinite(amax)) else 14 - math.frexp(amax)[1] + 1      # amax * 2^k in [2^14, 2^15)
+    k = max(-100, min(100, k))
+    ws = w_packed.detach().view(cout, taps, c) * (2.0 ** k)
+    w0 = ws.to(torch.float16)
+    w1 = (ws - w0.float()).to(torch.float16)
+    wsp = torch.cat([w0, w1, w0], dim=2).reshape(cout, taps * 3 * c).contiguous()
+    w_packed._e2eft_split = (w_packed._version, wsp, 2.0 ** (-k))
+    return wsp, 2.0 ** (-k)
+
+
+def _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label):
+    """The fp32 3x3 / stride-1 / pad-1 convolution through e2eft_conv2d_fwd_f32split, or None when the library declines the shape."""
+    B, H, W, c1 = x.shape
+    d = ConvDesc()
+    d.dtype = _lib.F32
+    d.batch, d.hin, d.win, d.hl, d.wl = B, H, W, H, W
+    d.c1, d.ldx1, d.c2, d.ldx2 = c1, 2 * c1, 0, 0
+    d.kh, d.kw, d.stride, d.pad_t, d.pad_l = 3, 3, 1, 1, 1
+    d.hout, d.wout, d.cout, d.ldo = H, W, cout, _nhwc_ld(out)
+    d.ldr = _nhwc_ld(residual) if residual is not None else 0
+    d.ldw = 27 * c1
+    d.alpha = alpha
+    lib = _lib.load()
+    if (lib.e2eft_conv2d_fwd_f32split_supported(C.byref(d)) != 1 or out.data_ptr() % 16 or (residual is not None and residual.data_ptr() % 16)
+            or (bias is not None and bias.data_ptr() % 16) or x.data_ptr() % 16 or _nhwc_ld(x) % 4 or not w_packed.is_contiguous()):
+        return None
+    wsp, inv_sw = f32_split_weight(w_packed, 9, c1)
+    d.alpha = alpha * inv_sw
+    planes, scale = f32_split2(x)
+    nb = (B * H * W * 2 * c1 * 2 + B * H * W * cout * 4 * (2 if residual is not None else 1) + cout * 27 * c1 * 2)
+    with _timed("igemm", 2.0 * B * H * W * cout * 9 * c1, nb, label=label + " f32split"):
+        buf, nbytes = _gn_buffer(B, H * W, cout, x.device) if want else (None, 0)
+        slab = C.c_int32(0)
+        check(lib.e2eft_conv2d_fwd_f32split(C.byref(d), _ptr(planes), _ptr(scale), _ptr(wsp), _ptr(bias), _ptr(residual), _ptr(out), _ptr(buf), nbytes,
+                                            C.byref(slab), _stream()))
+        if want:
+            _attach_stats(out, buf, slab.value, B, H * W, cout)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None, up_to=None, rowadd=None,
-           residual=None, alpha=1.0, out=None, gn_stats=False, norm=None, w_phase=None):
+           residual=None, alpha=1.0, out=None, gn_stats=False, norm=None, w_phase=None, _label=None):
     """Implicit-GEMM convolution. x: [B,H,W,C1] (C1 % epc == 0), x2: optional [B,H,W,C2] fused channel concat,
     w_packed: [cout, ldw] rows = (ky,kx,c) K-contiguous, pad = (top, bottom, left, right), up_to=(hl,wl) fused
     nearest upsample, rowadd: [B,cout] per-image vector added before alpha, residual: [B,hout,wout,cout].
@@ -317,8 +383,13 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
             x = groupnorm(x, gamma, beta, groups, eps, silu=silu, x2=x2)      # the norm of the CONCATENATED input; its output is one tensor
             x2 = None
             d.c1, d.ldx1, d.c2, d.ldx2 = x.shape[3], _nhwc_ld(x), 0, 0
-    with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2), nb,
-                label="conv%dx%ds%d%s%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", "n" if coeff is not None else "", B, hout, wout, d.c1 + d.c2, cout)):
+    label = _label or "conv%dx%ds%d%s%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", "n" if coeff is not None else "", B, hout, wout, d.c1 + d.c2, cout)
+    if (F32_SPLIT_ENABLED and x.dtype == torch.float32 and coeff is None and not sk and x2 is None and up_to is None and rowadd is None and (kh, kw, stride) == (3, 3, 1)
+            and tuple(pad) == (1, 1, 1, 1) and x.shape[3] % 64 == 0 and w_packed.shape[1] == 9 * x.shape[3]):
+        r = _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label)
+        if r is not None:
+            return r
+    with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2), nb, label=label):
         if coeff is not None:
             buf, nbytes = _gn_buffer(B, hout * wout, cout, x.device) if want else (None, 0)
             slab = C.c_int32(0)
@@ -928,8 +999,16 @@ def conv2d_dgrad(dy, w_dgrad, x_shape, c2, kh, kw, stride, pad, up_to, alpha):
     d.cout, d.alpha = cop, alpha
     cin = c1 + c2
     assert w_dgrad.shape == (cin, kh * kw * cop) and w_dgrad.is_contiguous() and w_dgrad.dtype == dy.dtype
-    dx = new_nhwc(B, hl, wl, cin, dy.dtype, dy.device)
-    with _timed("igemm", 2.0 * B * hl * wl * cin * kh * kw * cop, label="dgrad%dx%ds%d B%d %dx%d %d->%d" % (kh, kw, stride, B, hl, wl, cop, cin)):
+    label = "dgrad%dx%ds%d B%d %dx%d %d->%d" % (kh, kw, stride, B, hl, wl, cop, cin)
+    if (F32_SPLIT_ENABLED and dy.dtype == torch.float32 and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1) and up_to is None and c2 == 0 and cop % 64 == 0
+            and cin % 8 == 0):
+        # the data gradient of a 3x3 / stride-1 / pad-1 convolution IS such a convolution of dY with the flipped, transposed weights: the f16-split route of conv2d
+        dx = new_nhwc(B, hl, wl, cin, dy.dtype, dy.device)
+        if _conv2d_f32split(dy, w_dgrad, None, cin, None, alpha, dx, False, label) is not None:
+            return dx
+    else:
+        dx = new_nhwc(B, hl, wl, cin, dy.dtype, dy.device)
+    with _timed("igemm", 2.0 * B * hl * wl * cin * kh * kw * cop, label=label):
         check(_lib.load().e2eft_conv2d_dgrad(C.byref(d), _ptr(dy), _nhwc_ld(dy), cop, _ptr(w_dgrad), w_dgrad.shape[1], _ptr(dx), _nhwc_ld(dx),
                                              _stream()))
     return dx

@@ -69,7 +69,8 @@ enum {
     E2EFT_OPT_PATCH_CONV_2X2 = 11,   /* 1 (default, round 6): the 2x2 parity phases of e2eft_upconv2x_fwd (and any eligible 2x2 / stride-1 convolution) on the halo-patch kernel's 2x2-tap variant (igemm6); 0: igemm5 */
     E2EFT_OPT_PERSISTENT_MIN_QROUNDS = 12, /* 2 (default since round 6, was 8): the persistent kernels (igemm5 / igemm6) take a launch of at least n / 4 tiles per CU (2 = half a round of the machine, 8 = two rounds); 1 .. 64 */
     E2EFT_OPT_GN_APPLY_ITERS = 13,   /* 0 (default): the GroupNorm apply pass picks its pixels per thread (4 x n sixteen-byte loads) by tensor size; 1 .. 16: forced n */
-    E2EFT_OPT_COUNT = 14
+    E2EFT_OPT_F32_SPLIT = 14,        /* 1 (default, round 6): e2eft_conv2d_fwd_f32split_supported may answer 1 (fp32 3x3 convolutions from two-term f16 splits on the f16 matrix pipe); 0: it answers 0 (v_mfma_f32_32x32x2_f32 on igemm2) */
+    E2EFT_OPT_COUNT = 15
 };
 int e2eft_set_option(int32_t key, int32_t value);
 int e2eft_get_option(int32_t key);
@@ -163,6 +164,23 @@ int e2eft_conv2d_fwd_normed_supported(const E2eftConvDesc* d);
 int e2eft_upconv2x_fwd_supported(const E2eftConvDesc* d);
 int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const void* w_phase, const void* bias, void* out, float* gn_partial,
                        size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
+
+/* fp32 convolutions on the f16 matrix pipe (round 6; csrc/f32split.hip).  The reference runs its training recipe in fp32 (training/scripts/train_marigold_e2e_ft_depth.sh:15,
+ * `--mixed_precision "no"`); the fp32 matrix instruction of gfx950 is a sixteenth of the f16 one.  An fp32 tensor is split EXACTLY (to 2^-22 relative) into two f16 terms after a
+ * power-of-two scaling taken from its own maximum, x s = x0 + x1; a product is x0 w0 + x0 w1 + x1 w0 (three exact f16 products, fp32 accumulation) — error 3 * 2^-22 per
+ * product, below the fp32 accumulation error of the reduction itself (tests/test_f32split_gpu.py measures both routes against float64).
+ *   e2eft_f32_split2: x fp32 [pixels][ldx] (c channels, c % 8 == 0, 16-byte aligned) -> planes f16 [pixels][ldp], channels [0, c) = x0, [c, 2c) = x1 (ldp >= 2c, % 8);
+ *     scale: three device floats of workspace, on return (stream-ordered) scale[1] = s, scale[2] = 1 / s.  No host synchronisation.
+ *   e2eft_conv2d_fwd_f32split: out = alpha / s * (conv3x3(planes, w_split)) + bias + residual in fp32.  `d`: dtype E2EFT_F32, 3x3 / stride 1 / pads 1, c2 = 0,
+ *     c1 = c (% 64 == 0, >= 64), ldx1 = ldp (f16 elements), ldw = row length of w_split in f16 elements (>= 27 c), ldo / ldr in fp32 elements, width % 32 == 0,
+ *     height % 8 == 0; alpha = (the caller's factor) / s_w.  w_split: f16 [cout][3][3][w0 (c) | w1 (c) | w0 (c)] with w s_w = w0 + w1 built once per weight by the
+ *     caller (power-of-two s_w).  scale: the workspace e2eft_f32_split2 filled for these planes.  gn_partial / slab_rows as e2eft_conv2d_fwd_gnstats (statistics of
+ *     the fp32 output).  Ask e2eft_conv2d_fwd_f32split_supported first (pure host arithmetic; E2EFT_OPT_F32_SPLIT = 0 makes it answer 0); E2EFT_ERR_UNSUPPORTED otherwise.
+ *     The data gradient of such a convolution is the same call on dY with the flipped, transposed weights (e2eft_conv2d_dgrad's w_dgrad) split the same way. */
+int e2eft_f32_split2(const float* x, int64_t pixels, int32_t c, int32_t ldx, void* planes, int32_t ldp, float* scale, void* stream);
+int e2eft_conv2d_fwd_f32split_supported(const E2eftConvDesc* d);
+int e2eft_conv2d_fwd_f32split(const E2eftConvDesc* d, const void* planes, const float* scale, const void* w_split, const float* bias, const float* residual,
+                              float* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
 int e2eft_conv2d_fwd_normed(const E2eftConvDesc* d, const void* x1, const float* coeff, const void* beta, int32_t silu, const void* w,
                             const void* bias, const void* rowadd, const void* residual, void* out, float* gn_partial,
                             size_t gn_partial_bytes, int32_t* slab_rows, void* stream);

@@ -5,7 +5,7 @@ import sys
 from diffusion_e2e_ft_amd import _lib
 
 NAMES = {"persistent": _lib.OPT_PERSISTENT, "persistent_grid": _lib.OPT_PERSISTENT_GRID, "narrow_conv": _lib.OPT_NARROW_CONV,
-         "narrow_mfma": _lib.OPT_NARROW_MFMA, "igemm_general_operands": _lib.OPT_IGEMM_GENERAL_OPERANDS, "igemm2_waves": _lib.OPT_IGEMM2_WAVES, "patch_conv": _lib.OPT_PATCH_CONV, "thin_input_conv": _lib.OPT_THIN_INPUT_CONV, "fused_norm": _lib.OPT_FUSED_NORM, "attn_dma": _lib.OPT_ATTN_DMA, "upconv_phases": _lib.OPT_UPCONV_PHASES, "patch_conv_2x2": _lib.OPT_PATCH_CONV_2X2, "persistent_min_qrounds": _lib.OPT_PERSISTENT_MIN_QROUNDS, "gn_apply_iters": _lib.OPT_GN_APPLY_ITERS}
+         "narrow_mfma": _lib.OPT_NARROW_MFMA, "igemm_general_operands": _lib.OPT_IGEMM_GENERAL_OPERANDS, "igemm2_waves": _lib.OPT_IGEMM2_WAVES, "patch_conv": _lib.OPT_PATCH_CONV, "thin_input_conv": _lib.OPT_THIN_INPUT_CONV, "fused_norm": _lib.OPT_FUSED_NORM, "attn_dma": _lib.OPT_ATTN_DMA, "upconv_phases": _lib.OPT_UPCONV_PHASES, "patch_conv_2x2": _lib.OPT_PATCH_CONV_2X2, "persistent_min_qrounds": _lib.OPT_PERSISTENT_MIN_QROUNDS, "gn_apply_iters": _lib.OPT_GN_APPLY_ITERS, "f32_split": _lib.OPT_F32_SPLIT}
 
 
 def take(argv):
