@@ -342,6 +342,35 @@ def run_train(args, rank, world, dev):
         ig = ksum.get("igemm", dict(launches=0, ms=1e-9, flops=0.0, bytes=0.0))
         achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         peak = PEAK_TF[args.dtype]
+        pipes = None
+        if args.dtype == "fp32":
+            # fp32 launches run on TWO instruction families of the one matrix pipe: v_mfma_f32_32x32x2_f32 (157.3 TF/s) and — csrc/f32split.hip, E2EFT_OPT_F32_SPLIT —
+            # v_mfma_f32_32x32x16_f16 on two-term f16 splits (three f16 products per fp32 product; `flops` of those launches = the f16 products).  The roofline prices
+            # both against the f16 peak of the pipe: an fp32-instruction flop occupies it 2500 / 157.3 times as long as an f16 one.
+            split = dict(ms=0.0, flops=0.0, nominal=0.0, launches=0)
+            native = dict(ms=0.0, flops=0.0, launches=0)
+            for nm, lst in timer.rec.items():
+                if nm != "igemm":
+                    continue
+                for r in lst:
+                    is_split = "f32split" in str(r[4])
+                    t = split if is_split else native
+                    t["ms"] += r[0].elapsed_time(r[1])
+                    t["flops"] += r[2]
+                    t["launches"] += r[5]
+                    if is_split:
+                        t["nominal"] += r[6]
+            tot_ms = split["ms"] + native["ms"]
+            if tot_ms > 0:
+                pipe_equiv = (split["flops"] + native["flops"] * (PEAK_TF["fp16"] / PEAK_TF["fp32"])) / (tot_ms * 1e-3) / 1e12
+                pipes = {"f16_products_of_two_term_splits": {"ms_per_step": split["ms"] / args.steps, "launches_per_step": split["launches"] / args.steps,
+                                                             "executed_tflops": split["flops"] / max(split["ms"], 1e-9) / 1e9,
+                                                             "fp32_equivalent_tflops": split["nominal"] / max(split["ms"], 1e-9) / 1e9, "peak": PEAK_TF["fp16"]},
+                         "fp32_matrix_instruction": {"ms_per_step": native["ms"] / args.steps, "launches_per_step": native["launches"] / args.steps,
+                                                     "tflops": native["flops"] / max(native["ms"], 1e-9) / 1e9, "peak": PEAK_TF["fp32"]},
+                         "note": "`achieved` / `peak` / `frac` of this roofline are matrix-pipe time at the f16 rate: f16 products as executed + fp32-instruction flops x (2500 / 157.3); "
+                                 "E2EFT_OPT_F32_SPLIT = 0 (bench.py --set-option f32_split=0) keeps every fp32 launch on the fp32 instruction"}
+                achieved, peak = pipe_equiv, PEAK_TF["fp16"]
         others = {k: dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] / args.steps, gbs=v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else 0)
                   for k, v in ksum.items() if k != "igemm"}
         line = {
@@ -359,7 +388,8 @@ def run_train(args, rank, world, dev):
                                                             "all-reduce (HIP events either side of the wait) = the part of the exchange the backward did not hide"} if world > 1 else None,
             "roofline": {"bound": "mfma", "kernel": "igemm kernels (fwd, dgrad, wgrad GEMMs, attention-backward GEMMs)", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None, "launches_per_step": ig["launches"] / args.steps,
-                         "kernel_ms_per_step": ig["ms"] / args.steps, "algorithmic_gflop_per_step": ig["flops"] / args.steps / 1e9, "other_kernels": others},
+                         "kernel_ms_per_step": ig["ms"] / args.steps, "algorithmic_gflop_per_step": ig.get("flops_nominal", ig["flops"]) / args.steps / 1e9,
+                         "executed_gflop_per_step": ig["flops"] / args.steps / 1e9, **({"pipes": pipes} if pipes else {}), "other_kernels": others},
         }
         return line
     return None

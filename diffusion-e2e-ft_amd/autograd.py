@@ -571,6 +571,89 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, split=False):
     return (y, x) if split else y
 
 
+class _NormConvSplitFn(torch.autograd.Function):
+    """fp32, FROZEN 3x3 / stride-1 / pad-1 convolution of GroupNorm(+SiLU)(x) (+ residual) — the VAE decoder's ResnetBlock2D halves under the fp32 recipe
+    (training/scripts/train_marigold_e2e_ft_depth.sh:15; the VAE carries no gradient: training/train.py:321-323).  Forward: the norm's apply pass writes the f16 split
+    planes (e2eft_groupnorm_fwd_split), the convolution multiplies them on the f16 matrix pipe (e2eft_conv2d_fwd_f32split) — the normalised fp32 tensor is neither
+    written nor kept.  Backward: the data gradient is the same convolution call on dY (ops.conv2d_dgrad), then e2eft_groupnorm_bwd_add.  split as _GroupNormFn."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, conv, groups, eps, silu, s1, split, gn_stats):
+        dt = x.dtype
+        B, H, W, c1 = x.shape
+        cout = conv.weight.shape[0]
+        planes, inv, ws = ops.groupnorm_fwd_split_ws(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, s1=s1)
+        out = ops.new_nhwc(B, H, W, cout, dt, x.device)
+        if residual is not None:
+            assert tuple(residual.shape) == tuple(out.shape) and residual.dtype == dt
+        r = ops._conv2d_f32split(None, packed_conv_weight(conv, dt), _vec(conv.bias, dt), cout, residual, 1.0, out, gn_stats and ops.GN_STATS_ENABLED and cout % 8 == 0,
+                                 "conv3x3s1n B%d %dx%d %d->%d" % (B, H, W, c1, cout), planes=planes, inv_scale=inv)
+        assert r is not None, "norm_conv_split: the library declined a shape ops.f32split_shape_ok accepted"
+        _stash_stats(out)
+        ctx.save_for_backward(x, gamma, beta, ws)
+        ctx.conv, ctx.meta, ctx.has_res = conv, (groups, eps, silu), residual is not None
+        ctx.psrc = (gamma, beta)
+        if split:
+            return out, x.view_as(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy, dskip=None):
+        x, gamma, beta, ws = ctx.saved_tensors
+        groups, eps, silu = ctx.meta
+        conv = ctx.conv
+        dt = x.dtype
+        need = ctx.needs_input_grad
+        B, H, W, c1 = x.shape
+        if dy is None:
+            return dskip, None, None, None, None, None, None, None, None, None, None
+        Co = conv.weight.shape[0]
+        cop = ops.round_up(Co, ops.epc(dt))
+        dyp = _dense_nhwc(dy, cop)
+        dres = dy if (ctx.has_res and need[3]) else None
+        dx = dgam = dbet = None
+        if need[0] or need[1] or need[2]:
+            dhn = ops.conv2d_dgrad(dyp, packed_conv_weight_dgrad(conv, dt), (B, H, W, c1), 0, 3, 3, 1, (1, 1, 1, 1), None, 1.0)
+            add = _dense_nhwc(dskip, c1) if (dskip is not None and need[0]) else None
+            want_p = need[1] or need[2]
+            gs = grad_sink(ctx.psrc[0]) if (need[1] and need[2] and gamma.dtype == torch.float32) else None
+            bs = grad_sink(ctx.psrc[1]) if (gs is not None and beta.dtype == torch.float32) else None
+            dx, dg, db = ops.groupnorm_bwd(x, None, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu, dhn, ws, need_dx=need[0], need_dparams=want_p,
+                                           dx_add=add, dg_out=None if gs is None else gs[0], db_out=None if bs is None else bs[0])
+            dgam = None if not need[1] else gs[1][0] if gs is not None else dg.to(gamma.dtype)
+            dbet = None if not need[2] else bs[1][0] if bs is not None else db.to(beta.dtype)
+            if not need[0]:
+                dx = None
+        elif dskip is not None:
+            dx = dskip
+        return dx, dgam, dbet, dres, None, None, None, None, None, None, None
+
+
+def norm_conv_split(conv_mod, norm_mod, x, silu, residual=None, split=False, gn_stats=True):
+    """conv_mod(SiLU?(norm_mod(x))) (+ residual) as _NormConvSplitFn, or None when that route does not apply (the caller then runs the two ops): fp32 on the GPU, a
+    frozen 3x3 / stride-1 / pad-1 convolution the library takes from split planes, and a gradient to carry (without one ops.conv2d(norm=) fuses the same way)."""
+    w = conv_mod.weight
+    if x.dtype != torch.float32 or w.dtype != torch.float32 or not x.is_cuda or w.requires_grad or (conv_mod.bias is not None and conv_mod.bias.requires_grad):
+        return None
+    if not needs_grad(x, norm_mod.weight, norm_mod.bias, residual):
+        return None
+    stride = conv_mod.stride[0] if isinstance(conv_mod.stride, tuple) else conv_mod.stride
+    pad = conv_mod.padding[0] if isinstance(conv_mod.padding, tuple) else conv_mod.padding
+    B, H, W, c1 = x.shape
+    if tuple(w.shape[2:]) != (3, 3) or stride != 1 or pad != 1 or w.shape[1] != c1 or not ops.f32split_shape_ok(B, H, W, c1, w.shape[0]):
+        return None
+    try:
+        if ops._nhwc_ld(x) % 4 != 0 or x.data_ptr() % 16 != 0:
+            return None
+    except ValueError:
+        return None
+    sp = split and x.requires_grad
+    out = _NormConvSplitFn.apply(x, norm_mod.weight, norm_mod.bias, residual, conv_mod, norm_mod.num_groups, norm_mod.eps, silu, getattr(x, "_e2eft_gn", None), sp, gn_stats)
+    if split:
+        return (_attach_stats(out[0]), out[1]) if sp else (_attach_stats(out), x)
+    return _attach_stats(out)
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):

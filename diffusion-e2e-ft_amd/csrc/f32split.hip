@@ -22,15 +22,29 @@ __global__ __launch_bounds__(256) void absmax_f32_kernel(long pixels, int c, int
     const int c4 = c >> 2;
     const long total = pixels * c4;
     float m = 0.f;
-    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+    const long stride = (long)gridDim.x * 256;
+    auto at = [&](const long it) -> floatx4 {
         const long pix = it / c4;
         const int ch = (int)(it - pix * c4) * 4;
-        const floatx4 v = *reinterpret_cast<const floatx4*>(x + pix * ldx + ch);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));      // (fmaxf drops NaNs: a NaN input shows in the output through x0 anyway)
+        return *reinterpret_cast<const floatx4*>(x + pix * ldx + ch);
+    };
+    auto fold = [&](const floatx4& v) { m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3]))); };   // (fmaxf drops NaNs: a NaN input shows in the output through x0 anyway)
+    long it = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; it + 3 * stride < total; it += 4 * stride) {      // four independent 16-byte loads in flight per thread (1024 workgroups have to cover the HBM latency)
+        const floatx4 v0 = at(it), v1 = at(it + stride), v2 = at(it + 2 * stride), v3 = at(it + 3 * stride);
+        fold(v0); fold(v1); fold(v2); fold(v3);
     }
+    for (; it < total; it += stride) fold(at(it));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));
+    // ONE atomic per workgroup, at most 1024 workgroups: 16 k same-address atomics (one per wave of 4096 workgroups) cost 0.25 ms — more than the pass itself on a 100 MB tensor
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > 0.f) atomicMax(amax_bits, __float_as_uint(m));
+    }
 }
 
 // power-of-two scale that brings amax into [2^14, 2^15): (s, 1 / s); 1 for an all-zero or non-finite tensor
@@ -72,17 +86,23 @@ __global__ __launch_bounds__(256) void split2_f16_kernel(long pixels, int c, int
 
 bool igemm_patch_eligible(int dtype, int mode, IgemmParams& p, int nz);              // igemm6.hip
 int launch_igemm_patch(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
+bool igemm_persistent_eligible(int dtype, int mode, IgemmParams& p, int nz);        // igemm5.hip
+int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s);
 
+// the implicit-GEMM parameter block of an fp32 convolution whose input arrives as split planes: any filter / stride / padding of e2eft_conv2d_fwd without a second
+// source and without a fused upsample; K = taps * 3 * c1
 static bool f32split_params(const E2eftConvDesc* d, IgemmParams& p) {
     if (!d || d->dtype != E2EFT_F32 || d->c2 != 0 || !option(E2EFT_OPT_F32_SPLIT)) return false;
-    if (d->batch <= 0 || d->hin <= 0 || d->win <= 0 || d->cout <= 0 || d->c1 <= 0) return false;
-    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->hl != d->hin || d->wl != d->win || d->hout != d->hin || d->wout != d->win) return false;
-    if (d->c1 % 64 != 0 || d->ldx1 < 2 * d->c1 || d->ldw < 27 * d->c1 || (long)d->batch * d->hout * d->wout >= 2147483647L) return false;
+    if (d->batch <= 0 || d->hin <= 0 || d->win <= 0 || d->cout <= 0 || d->c1 <= 0 || d->hout <= 0 || d->wout <= 0) return false;
+    if (d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->hl != d->hin || d->wl != d->win) return false;
+    if ((d->hout - 1) * d->stride - d->pad_t >= d->hl || (d->wout - 1) * d->stride - d->pad_l >= d->wl) return false;
+    const int taps = d->kh * d->kw;
+    if (d->c1 % 64 != 0 || d->ldx1 < 2 * d->c1 || d->ldx1 % 8 != 0 || d->ldw < taps * 3 * d->c1 || d->ldw % 8 != 0 || (long)d->batch * d->hout * d->wout >= 2147483647L) return false;
     p = IgemmParams{};
-    p.M = d->batch * d->hout * d->wout; p.N = d->cout; p.K = 27 * d->c1;
+    p.M = d->batch * d->hout * d->wout; p.N = d->cout; p.K = taps * 3 * d->c1;
     p.ldx1 = d->ldx1; p.c1 = 3 * d->c1; p.cin = 3 * d->c1; p.split_c = d->c1;
     p.hin = d->hin; p.win = d->win; p.hl = d->hl; p.wl = d->wl;
-    p.kh = 3; p.kw = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
     p.hout = d->hout; p.wout = d->wout;
     p.up_sh = p.up_sw = 1.f;
     p.ldw = d->ldw; p.ldr = d->ldr > 0 ? d->ldr : d->ldo; p.ldo = d->ldo;
@@ -104,7 +124,7 @@ extern "C" int e2eft_f32_split2(const float* x, int64_t pixels, int32_t c, int32
     if (hipMemsetAsync(scale, 0, sizeof(float), s) != hipSuccess) return fail(E2EFT_ERR_LAUNCH, "f32_split2: memset failed");
     const long units = pixels * (c / 8);
     long nb = (units + 255) / 256;
-    const long nbm = nb > 4096 ? 4096 : nb;          // the reduction: few atomics
+    const long nbm = nb > 1024 ? 1024 : nb;          // the reduction: few atomics
     hipLaunchKernelGGL(absmax_f32_kernel, dim3((unsigned)nbm), dim3(256), 0, s, (long)pixels, c, ldx, x, reinterpret_cast<unsigned*>(scale));
     if (nb > 65536) nb = 65536;
     hipLaunchKernelGGL(split2_f16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (long)pixels, c, ldx, ldp, x, (f16*)planes, reinterpret_cast<const unsigned*>(scale), scale);
@@ -113,30 +133,149 @@ extern "C" int e2eft_f32_split2(const float* x, int64_t pixels, int32_t c, int32
 }
 
 // pure host arithmetic: would e2eft_conv2d_fwd_f32split take this launch (with 16-byte aligned pointers)?  desc: dtype E2EFT_F32, c1 = channels of the fp32
-// tensor, ldx1 = pixel stride of the PLANES in f16 elements (>= 2 c1), ldw = weight row length in f16 elements (>= 27 c1), ldo / ldr in fp32 elements
+// tensor, ldx1 = pixel stride of the PLANES in f16 elements (>= 2 c1), ldw = weight row length in f16 elements (>= kh kw 3 c1), ldo / ldr in fp32 elements
 extern "C" int e2eft_conv2d_fwd_f32split_supported(const E2eftConvDesc* d) {
     IgemmParams p;
     if (!f32split_params(d, p)) return 0;
     void* const al = (void*)(uintptr_t)256;
     p.x1 = al; p.w = al; p.out = al;
-    return igemm_patch_eligible(E2EFT_F16, 1, p, 1) ? 1 : 0;
+    IgemmParams q = p;
+    if (igemm_patch_eligible(E2EFT_F16, 1, q, 1)) return 1;
+    q = p;
+    return igemm_persistent_eligible(E2EFT_F16, 1, q, 1) ? 1 : 0;
 }
 
-extern "C" int e2eft_conv2d_fwd_f32split(const E2eftConvDesc* d, const void* planes, const float* scale, const void* w_split, const float* bias,
+extern "C" int e2eft_conv2d_fwd_f32split(const E2eftConvDesc* d, const void* planes, const float* scale, const void* w_split, const float* w_inv_scale, const float* bias,
                                          const float* residual, float* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* stream) {
     if (slab_rows) *slab_rows = 0;
-    E2EFT_REQUIRE(d && planes && scale && w_split && out, "conv2d_fwd_f32split: null pointer");
+    E2EFT_REQUIRE(d && planes && w_split && out, "conv2d_fwd_f32split: null pointer");
     IgemmParams p;
-    if (!f32split_params(d, p)) return fail(E2EFT_ERR_UNSUPPORTED, "conv2d_fwd_f32split: not a 3x3 / stride-1 / pad-1 fp32 convolution of 64-channel multiples (ask e2eft_conv2d_fwd_f32split_supported)");
+    if (!f32split_params(d, p)) return fail(E2EFT_ERR_UNSUPPORTED, "conv2d_fwd_f32split: not an fp32 convolution of 64-channel multiples from split planes (ask e2eft_conv2d_fwd_f32split_supported)");
+    E2EFT_REQUIRE(((uintptr_t)planes & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)out & 15) == 0, "conv2d_fwd_f32split: pointers must be 16-byte aligned");
     p.x1 = planes; p.w = w_split; p.bias = bias; p.residual = residual; p.out = out;
-    p.alpha_dev = scale + 2;
+    p.alpha_dev = scale ? scale + 2 : nullptr;
+    p.alpha_dev2 = w_inv_scale;
     if (gn_partial && slab_rows) {
         const size_t need = (size_t)d->batch * (size_t)cdiv(p.rows_per_img, 128) * (size_t)d->cout * 3 * sizeof(float);
         if (gn_partial_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "conv2d_fwd_f32split: gn_partial %zu < %zu bytes", gn_partial_bytes, need);
         p.gn_partial = gn_partial;
     }
-    const int rc = launch_igemm_patch(E2EFT_F16, 1, p, 1, (hipStream_t)stream);
-    if (rc < 0) return fail(E2EFT_ERR_UNSUPPORTED, "conv2d_fwd_f32split: this launch is not eligible for the halo-patch kernel");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_igemm_patch(E2EFT_F16, 1, p, 1, s);                         // 3x3 / stride 1 / pad 1 on a 32 x 8 grid: the halo-patch kernel
+    if (rc < 0) rc = launch_igemm_persistent(E2EFT_F16, 1, p, 1, s);            // everything else in whole 256-row tiles: igemm5
+    if (rc < 0 && p.gn_partial) {                                               // statistics need whole tiles inside one image: without them (the consumer runs its own pass)
+        p.gn_partial = nullptr;
+        rc = launch_igemm_persistent(E2EFT_F16, 1, p, 1, s);
+    }
+    if (rc < 0) return fail(E2EFT_ERR_UNSUPPORTED, "conv2d_fwd_f32split: this launch is not eligible for the persistent kernels");
     if (rc == 0 && slab_rows && p.gn_partial) *slab_rows = p.rows_per_img / p.gn_nslabs;
     return rc;
+}
+
+// ---- nn.Linear in fp32 from split planes: out[m][n] = alpha / (s s_w) * sum_k a[m][k] w[n][k] + bias[n] + residual[m][n] on igemm5's GEMM mode.  `d`: dtype E2EFT_F32, k = the
+// fp32 operand's columns (% 64 == 0), lda = row stride of the PLANES in f16 elements (>= 2 k), ldw = row length of w_split [n][w0 (k) | w1 (k) | w0 (k)] (>= 3 k), ldo / ldr
+// in fp32 elements, one problem (nzo = nzi = 1), bias along n.  Whole 256-row tiles only (m % 256 == 0): ask e2eft_gemm_f32split_supported first.
+static bool f32split_gemm_params(const E2eftGemmDesc* d, IgemmParams& p) {
+    if (!d || d->dtype != E2EFT_F32 || !option(E2EFT_OPT_F32_SPLIT) || d->nzo != 1 || d->nzi != 1 || d->bias_along_m) return false;
+    if (d->m <= 0 || d->n <= 0 || d->k <= 0 || d->k % 64 != 0 || d->lda < 2 * d->k || d->lda % 8 != 0 || d->ldw < 3 * d->k || d->ldw % 8 != 0 || d->ldo < d->n) return false;
+    p = IgemmParams{};
+    p.M = d->m; p.N = d->n; p.K = 3 * d->k;
+    p.ldx1 = d->lda; p.c1 = 3 * d->k; p.cin = 3 * d->k; p.split_c = d->k;
+    p.ldw = d->ldw; p.ldr = d->ldr > 0 ? d->ldr : d->ldo; p.ldo = d->ldo;
+    p.rows_per_img = 1;
+    p.alpha = d->alpha;
+    p.nzi = 1;
+    return true;
+}
+
+extern "C" int e2eft_gemm_f32split_supported(const E2eftGemmDesc* d) {
+    IgemmParams p;
+    if (!f32split_gemm_params(d, p)) return 0;
+    void* const al = (void*)(uintptr_t)256;
+    p.x1 = al; p.w = al; p.out = al;
+    return igemm_persistent_eligible(E2EFT_F16, 0, p, 1) ? 1 : 0;
+}
+
+extern "C" int e2eft_gemm_f32split(const E2eftGemmDesc* d, const void* planes, const float* scale, const void* w_split, const float* w_inv_scale, const float* bias,
+                                   const float* residual, float* out, void* stream) {
+    E2EFT_REQUIRE(d && planes && w_split && out, "gemm_f32split: null pointer");
+    IgemmParams p;
+    if (!f32split_gemm_params(d, p)) return fail(E2EFT_ERR_UNSUPPORTED, "gemm_f32split: not an fp32 GEMM of 64-column multiples from split planes (ask e2eft_gemm_f32split_supported)");
+    E2EFT_REQUIRE(((uintptr_t)planes & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)out & 15) == 0, "gemm_f32split: pointers must be 16-byte aligned");
+    p.x1 = planes; p.w = w_split; p.bias = bias; p.residual = residual; p.out = out;
+    p.alpha_dev = scale ? scale + 2 : nullptr;
+    p.alpha_dev2 = w_inv_scale;
+    const int rc = launch_igemm_persistent(E2EFT_F16, 0, p, 1, (hipStream_t)stream);
+    if (rc < 0) return fail(E2EFT_ERR_UNSUPPORTED, "gemm_f32split: this launch is not eligible for the persistent kernel");
+    return rc;
+}
+
+// ---- nearest-2x upsample + 3x3 / stride-1 / pad-1 convolution in fp32 as four 2x2 phase convolutions of the split planes (e2eft_upconv2x_fwd's algebra, igemm.hip).
+// `d` as e2eft_upconv2x_fwd's (dtype E2EFT_F32, hl = 2 hin, ...) with ldx1 = the planes' pixel stride in f16 elements; w_phase_split: f16 [4][cout][2][2][w0 | w1 | w0]
+// (the fp32 phase weights of autograd.phase_conv_weight split as ONE tensor: one scale).  The halo-patch kernel's 2x2-tap variant where the grid allows, else igemm5.
+static bool f32split_upconv_params(const E2eftConvDesc* d, int ph, IgemmParams& p) {
+    if (!d || d->dtype != E2EFT_F32 || d->c2 != 0 || !option(E2EFT_OPT_F32_SPLIT) || !option(E2EFT_OPT_UPCONV_PHASES)) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->hl != 2 * d->hin || d->wl != 2 * d->win || d->hout != d->hl || d->wout != d->wl) return false;
+    if (d->batch <= 0 || d->hin <= 0 || d->win <= 0 || d->c1 <= 0 || d->c1 % 64 != 0 || d->cout % 8 != 0 || d->ldo % 8 != 0 || d->alpha != 1.0f) return false;
+    if (d->ldx1 < 2 * d->c1 || d->ldx1 % 8 != 0 || d->win % 16 != 0 || ((long)d->hin * d->win) % 256 != 0 || (long)d->batch * d->hin * d->win >= 2147483647L) return false;
+    const int py = ph >> 1, px = ph & 1;
+    const int rows_img = d->hin * d->win;
+    p = IgemmParams{};
+    p.M = d->batch * rows_img; p.N = d->cout; p.K = 4 * 3 * d->c1;
+    p.ldx1 = d->ldx1; p.c1 = 3 * d->c1; p.cin = 3 * d->c1; p.split_c = d->c1;
+    p.hin = d->hin; p.win = d->win; p.hl = d->hin; p.wl = d->win;
+    p.kh = 2; p.kw = 2; p.stride = 1; p.pad_t = 1 - py; p.pad_l = 1 - px;
+    p.hout = d->hin; p.wout = d->win;
+    p.up_sh = p.up_sw = 1.f;
+    p.ldw = 12 * d->c1; p.ldo = 2 * d->ldo; p.ldr = p.ldo;
+    p.out_seg = d->win;
+    p.rows_per_img = rows_img;
+    p.alpha = 1.f;
+    p.nzi = 1;
+    return true;
+}
+
+extern "C" int e2eft_upconv2x_fwd_f32split_supported(const E2eftConvDesc* d) {
+    IgemmParams p;
+    if (!f32split_upconv_params(d, 0, p)) return 0;
+    void* const al = (void*)(uintptr_t)256;
+    p.x1 = al; p.w = al; p.out = al;
+    IgemmParams q = p;
+    if (igemm_patch_eligible(E2EFT_F16, 1, q, 1)) return 1;
+    q = p;
+    return igemm_persistent_eligible(E2EFT_F16, 1, q, 1) ? 1 : 0;
+}
+
+extern "C" int e2eft_upconv2x_fwd_f32split(const E2eftConvDesc* d, const void* planes, const float* scale, const void* w_phase_split, const float* w_inv_scale,
+                                           const float* bias, float* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* stream) {
+    if (slab_rows) *slab_rows = 0;
+    E2EFT_REQUIRE(d && planes && w_phase_split && out, "upconv2x_f32split: null pointer");
+    if (!e2eft_upconv2x_fwd_f32split_supported(d)) return fail(E2EFT_ERR_UNSUPPORTED, "upconv2x_f32split: this launch is not eligible (ask e2eft_upconv2x_fwd_f32split_supported)");
+    E2EFT_REQUIRE(((uintptr_t)planes & 15) == 0 && ((uintptr_t)w_phase_split & 15) == 0 && ((uintptr_t)out & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0), "upconv2x_f32split: pointers must be 16-byte aligned");
+    const int rows_img = d->hin * d->win, slabs = rows_img / 256;
+    const bool stats = gn_partial && slab_rows;
+    if (stats) {
+        const size_t need = (size_t)d->batch * (size_t)cdiv(4 * rows_img, 128) * (size_t)d->cout * 3 * sizeof(float);
+        if (gn_partial_bytes < need) return fail(E2EFT_ERR_WORKSPACE, "upconv2x_f32split: gn_partial %zu < %zu bytes", gn_partial_bytes, need);
+    }
+    for (int ph = 0; ph < 4; ++ph) {
+        IgemmParams p;
+        f32split_upconv_params(d, ph, p);
+        const int py = ph >> 1, px = ph & 1;
+        p.x1 = planes; p.w = (const char*)w_phase_split + (size_t)ph * d->cout * 12 * d->c1 * 2; p.bias = bias;
+        p.out = (char*)out + ((size_t)py * d->wl + px) * d->ldo * 4;
+        p.alpha_dev = scale ? scale + 2 : nullptr;
+        p.alpha_dev2 = w_inv_scale;
+        if (stats) {
+            p.gn_partial = gn_partial + (size_t)ph * slabs * d->cout * 3;
+            p.gn_islabs = 4 * slabs;
+        }
+        p.mtiles = p.M / 256; p.ntiles = cdiv(p.N, 128);
+        int rc = launch_igemm_patch(E2EFT_F16, 1, p, 1, (hipStream_t)stream);
+        if (rc < 0) rc = launch_igemm_persistent(E2EFT_F16, 1, p, 1, (hipStream_t)stream);
+        if (rc < 0) return fail(E2EFT_ERR_UNSUPPORTED, "upconv2x_f32split: the persistent kernels declined phase %d", ph);
+        if (rc) return rc;
+    }
+    if (stats) *slab_rows = 256;
+    return E2EFT_OK;
 }

@@ -56,6 +56,7 @@ struct IgemmParams {
     // out = acc * (alpha * *alpha_dev) + bias + residual   (alpha_dev: device scalar 1 / s of the activation split; alpha carries 1 / s_w and the caller's factor)
     int split_c;         // > 0: channels of one plane (cin = 3 * split_c)
     const float* alpha_dev;
+    const float* alpha_dev2;   // a second optional device factor (1 / s_w of weights that were split on the device)
     int debug_flags;     // instrumented build (-DE2EFT_STAMPS) only: bit 0 / 1 / 2 = the persistent kernel issues its A-operand LDS-DMA never / on the
                          // first tap of a filter row only / on the first tap of a 64-channel chunk only (WRONG results; the price of operand
                          // delivery: profiles/r03d_a_operand_delivery_probe.txt, "what an A-reuse scheme could buy at most")

@@ -86,9 +86,13 @@ __device__ __forceinline__ int fast_div5(int n, int d) {   // as igemm2.hip: flo
 }
 
 // RES: the launch has a residual operand (fp32 sliced epilogue); otherwise the packed epilogue — one of the two per instantiation, for the register budget
-template <typename T, int MODE, bool RES>
+// F32O (round 6, csrc/f32split.hip): an fp32 convolution / GEMM whose products are formed on the f16 matrix pipe.  A holds the two f16 planes [x0 | x1] of an fp32 operand
+// side by side (split_c columns each), the weights arrive as [w0 | w1 | w0] per tap, K runs over the three blocks (x0, w0), (x0, w1), (x1, w0): the A offset walks
+// split_c columns, starts over, then walks on into the second plane.  Bias / residual / output are fp32 (epilogue_f32 of the .inc).
+template <typename T, int MODE, bool RES, bool F32O = false>
 __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const int total_tiles) {
     using namespace pers;
+    static_assert(!F32O || (RES && std::is_same<T, f16>::value), "fp32 output: the fp32-window epilogue, f16 split operands");
     __shared__ __attribute__((aligned(16))) char smem[LDS];
     constexpr int EPC = 8;                 // elements per 16 bytes
     constexpr int BK = 64;
@@ -248,10 +252,20 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         fire_a = !(p.debug_flags & 1) && !((p.debug_flags & 2) && kx != 0) && !((p.debug_flags & 4) && (kx != 0 || ky != 0));
 #endif
         if (MODE == 0) {
+            if constexpr (F32O) {   // block (x0, w1) reads the first plane again; (x1, w0) simply walks on
+                const unsigned back = tile_c == p.split_c ? (unsigned)p.split_c * 2u : 0u;
+                tile_c += BK;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cur_a[i] += 128u;
+                for (int i = 0; i < 4; ++i) cur_a[i] += 128u - back;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur_a[i] += 128u;
+            }
         } else {
-            if (tile_c == 0) {
+            if (F32O && tile_c == p.split_c) {   // block (x0, w1): the first plane again; (x1, w0) then walks on into the second plane
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur_a[i] = off1[i];
+            } else if (tile_c == 0) {
                 retap();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) cur_a[i] = off1[i];
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     const int er = lane >> 3, ec = lane & 7;          // row inside an 8-row slice, 8-column chunk inside the wave's 64 columns
     const T* __restrict__ bias = (const T*)p.bias;
     const T* __restrict__ rowadd = (const T*)p.rowadd;
-    constexpr bool has_res = RES;
+    constexpr bool has_res = RES && !F32O;            // (F32O requests its fp32 bias / residual inside epilogue_f32)
     const bool has_ra = rowadd != nullptr, stats = p.gn_partial != nullptr;
     Vec16<T> pre_res[4], pre_bias, pre_ra;            // residual rows of slices 0-3, bias and rowadd chunk of this lane
     T col_bias[2], col_ra[2];                          // packed epilogue (no residual): bias / rowadd of the two COLUMNS this lane owns in the accumulator layout
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     // every LDS read of k-tile g has been requested by then, and the barrier skew of the eight waves disappears under 8 MFMAs (igemm2's
     // unrolled loop gets the same placement from the compiler's scheduler; a rolled loop has to spell it out).  nextwait: 0 none,
     // 2 vmcnt(6), 3 vmcnt(6 + NPRE) with NPRE = the operand requests issued at the top of a KIND-1 k-tile.
-    const int npre = has_res ? 4 + (bias ? 1 : 0) + (has_ra ? 1 : 0) : 2 * ((bias ? 1 : 0) + (has_ra ? 1 : 0));
+    const int npre = F32O ? 0 : has_res ? 4 + (bias ? 1 : 0) + (has_ra ? 1 : 0) : 2 * ((bias ? 1 : 0) + (has_ra ? 1 : 0));
     bool nxt = false;                                  // the workgroup has a tile after the current one (set at the top of a tile)
     long zoff_o = 0;
     auto enter_tile = [&]() {   // the MFMA side enters the tile the loader is (still) on; then the loader's coordinates move to the workgroup's next tile
@@ -381,7 +395,8 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         if constexpr (KIND == 3) enter_tile();   // index arithmetic of this tile's epilogue and of the next tile: under the first MFMAs
         if constexpr (KIND == 1) {
             // every lane requests (columns beyond N read the tile's first chunk instead: the count of VMEM instructions must not depend on exec)
-            if (has_res) {
+            if constexpr (F32O) {
+            } else if (has_res) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) pre_res[s] = ld16((const T*)p.residual + c_rrow + (long)(s * 8) * p.ldr);
                 if (bias) pre_bias = ld16(bias + c_ncl);
@@ -445,6 +460,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
 #define EPI_STAMP(i) STAMP5(tseq, i)
 #include "igemm_persistent_epilogue.inc"
 #undef EPI_STAMP
+    const float al_f32 = F32O ? p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.f) * (p.alpha_dev2 ? *p.alpha_dev2 : 1.f) : 0.f;
     // ================================ main ==========================================================================
     tile_coords(u_dma);
     fill_rowtab();
@@ -467,7 +483,8 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         ktile(IC5<2>{}, 0);    // opens the epilogue: barrier only
         STAMP5(tseq, 2);
         // after the rotation of the last k-tile its stage is s_dst (the next DMA destination): scratch until the next barrier
-        if constexpr (RES) epilogue(s_dst, zoff_o);
+        if constexpr (F32O) epilogue_f32(s_dst, al_f32);
+        else if constexpr (RES) epilogue(s_dst, zoff_o);
         else epilogue_packed(s_dst, zoff_o);
         STAMP5(tseq, 3);
         ++tseq;
@@ -489,17 +506,27 @@ extern int g_debug_flags5;
 #endif
 
 template <typename T, int MODE> static int launch5(IgemmParams& p, int nz, int total, int grid, hipStream_t s) {
+    if constexpr (std::is_same<T, f16>::value) {
+        if (p.split_c > 0) {   // fp32 operands as f16 split planes (launch_igemm_persistent checked the shape)
+            hipLaunchKernelGGL((igemm5_kernel<f16, MODE, true, true>), dim3(grid), dim3(512), 0, s, p, total);
+            tag_kernel("igemm5_kernel<_Float16, %d, true, f32split>", MODE);
+            return check_launch("igemm5");
+        }
+    }
     if (p.residual) hipLaunchKernelGGL((igemm5_kernel<T, MODE, true>), dim3(grid), dim3(512), 0, s, p, total);
     else hipLaunchKernelGGL((igemm5_kernel<T, MODE, false>), dim3(grid), dim3(512), 0, s, p, total);
     tag_kernel("igemm5_kernel<%s, %d, %s>", std::is_same<T, f16>::value ? "_Float16" : "__bf16", MODE, p.residual ? "true" : "false");
     return check_launch("igemm5");
 }
 
-int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s) {
+// the checks and the tile plan of launch_igemm_persistent (fills p.mtiles / p.ntiles / p.gn_nslabs): 0, or -1 = not this kernel's launch
+static int persistent_plan(int dtype, int mode, IgemmParams& p, int nz, long& total_out, int& cus_out) {
     using namespace pers;
     if (!option(E2EFT_OPT_PERSISTENT)) return -1;
     if (dtype != E2EFT_F16 && dtype != E2EFT_BF16) return -1;
     if (p.ksplit_taps > 0 || p.bias_along_m) return -1;
+    if (p.split_c > 0 && (dtype != E2EFT_F16 || nz != 1 || p.x2 || p.rowadd || p.split_c % 64 != 0 || p.cin != 3 * p.split_c || p.c1 != p.cin ||
+                          (mode == 0 && p.K != 3 * p.split_c))) return -1;
     if (p.M % BM != 0 || p.K % 64 != 0 || p.K / 64 < 3) return -1;
     if (p.N % 8 != 0 || p.ldo % 8 != 0 || (((uintptr_t)p.out) & 15) != 0) return -1;
     if (p.residual && (p.ldr % 8 != 0 || (((uintptr_t)p.residual) & 15) != 0)) return -1;
@@ -527,6 +554,21 @@ int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStre
         if (!(nz == 1 && p.rows_per_img % BM == 0 && p.M % p.rows_per_img == 0)) return -1;
         p.gn_nslabs = p.rows_per_img / BM;
     }
+    total_out = total;
+    cus_out = g_pers_cus;
+    return 0;
+}
+
+bool igemm_persistent_eligible(int dtype, int mode, IgemmParams& p, int nz) {   // pure host arithmetic (csrc/f32split.hip asks before it splits anything)
+    long total;
+    int cus;
+    return persistent_plan(dtype, mode, p, nz, total, cus) == 0;
+}
+
+int launch_igemm_persistent(int dtype, int mode, IgemmParams& p, int nz, hipStream_t s) {
+    long total;
+    int g_pers_cus;
+    if (persistent_plan(dtype, mode, p, nz, total, g_pers_cus) != 0) return -1;
     g_pers_launches.fetch_add(1, std::memory_order_relaxed);
 #ifdef E2EFT_STAMPS
     p.debug_flags = g_debug_flags5;

@@ -470,114 +470,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
 #define EPI_STAMP(i) do { } while (0)
 #include "igemm_persistent_epilogue.inc"
 #undef EPI_STAMP
-    // ---- F32O: the fp32-window epilogue of the .inc with fp32 bias / residual / output: out = acc * al + bias + residual, al = alpha / (activation split scale).
-    // A lane's 8-column chunk of a row is two 16-byte units; bias and the residual rows of slices 0-3 are requested on entry (the staging of slice 0 covers
-    // their latency), slices 4-7 at slice 0.  Statistics as the 16-bit epilogue (of the fp32 values that are stored).
-    const float al_f32 = F32O ? p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.f) : 0.f;
-    auto epilogue_f32 = [&](const int sfree) {
-        float* win = reinterpret_cast<float*>(smem + sfree + wave * 4096);
-        const int wofs = ((l31 >> 2) & 1) * 256 + h * 128 + (l31 >> 3) * 4 + (l31 & 3);
-        float* __restrict__ out = (float*)p.out;
-        const float* __restrict__ res = (const float*)p.residual;
-        const float* __restrict__ bias32 = (const float*)p.bias;
-        const bool hres = res != nullptr;
-        const f2 al2 = {al_f32, al_f32};
-        f2 bv2[4], pv2[4], sm2[4], sq2[4];
-        {
-            floatx4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-            if (bias32) { b0 = *reinterpret_cast<const floatx4*>(bias32 + c_ncl); b1 = *reinterpret_cast<const floatx4*>(bias32 + c_ncl + 4); }
-            bv2[0] = f2{b0[0], b0[1]}; bv2[1] = f2{b0[2], b0[3]}; bv2[2] = f2{b1[0], b1[1]}; bv2[3] = f2{b1[2], b1[3]};
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { pv2[q] = f2{0.f, 0.f}; sm2[q] = f2{0.f, 0.f}; sq2[q] = f2{0.f, 0.f}; }
-        floatx4 rr[4][2];
-        auto req = [&](const int s0) {
-            if (hres) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float* r = res + c_rrow + epi_rofs((s0 + t) * 8) * p.ldr;
-                    rr[t][0] = *reinterpret_cast<const floatx4*>(r);
-                    rr[t][1] = *reinterpret_cast<const floatx4*>(r + 4);
-                }
-            }
-        };
-        auto wr = [&](auto sc_) {
-            constexpr int s = decltype(sc_)::value, i = s >> 2, q = s & 3;
-            float* wb = win + (s & 1) * 512 + wofs;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) wb[e * 32 + j * 16] = acc[i][j][4 * q + e];
-        };
-        auto slice = [&](auto sc_) {
-            constexpr int s = decltype(sc_)::value;
-            if constexpr (s < 7) wr(IConst<s + 1>{});
-            if constexpr (s == 4) __builtin_amdgcn_s_waitcnt(0x0F70);   // (as the 16-bit epilogue: the next tile's first pieces have landed; also the residual rows)
-            const float* rb = win + (s & 1) * 512 + lane * 4;
-            const floatx4 t0 = *reinterpret_cast<const floatx4*>(rb);
-            const floatx4 t1 = *reinterpret_cast<const floatx4*>(rb + 256);
-            f2 x2[4] = {f2{t0[0], t0[1]}, f2{t0[2], t0[3]}, f2{t1[0], t1[1]}, f2{t1[2], t1[3]}};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x2[q] = __builtin_elementwise_fma(x2[q], al2, bv2[q]);
-            if (hres) {
-                const floatx4 r0 = rr[s & 3][0], r1 = rr[s & 3][1];
-                x2[0] += f2{r0[0], r0[1]}; x2[1] += f2{r0[2], r0[3]}; x2[2] += f2{r1[0], r1[1]}; x2[3] += f2{r1[2], r1[3]};
-            }
-            if (c_colok) {
-                float* o = out + c_orow + epi_rofs(s * 8) * p.ldo;
-                *reinterpret_cast<floatx4*>(o) = floatx4{x2[0][0], x2[0][1], x2[1][0], x2[1][1]};
-                *reinterpret_cast<floatx4*>(o + 4) = floatx4{x2[2][0], x2[2][1], x2[3][0], x2[3][1]};
-            }
-            if constexpr (s == 3) req(4);      // (rr is free: slice 3 was its last reader)
-            if (stats) {
-                if constexpr (s == 0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) pv2[q] = f2{__shfl(x2[q][0], ec, 64), __shfl(x2[q][1], ec, 64)};
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f2 d = x2[q] - pv2[q];
-                    sm2[q] += d;
-                    sq2[q] = __builtin_elementwise_fma(d, d, sq2[q]);
-                }
-            }
-        };
-        req(0);
-        wr(IConst<0>{});
-        slice(IConst<0>{}); slice(IConst<1>{}); slice(IConst<2>{}); slice(IConst<3>{});
-        slice(IConst<4>{}); slice(IConst<5>{}); slice(IConst<6>{}); slice(IConst<7>{});
-        if (stats) {   // the reduce-scatter butterfly and the deposits of the 16-bit fp32-window epilogue (igemm_persistent_epilogue.inc)
-            float v[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { v[2 * q] = sm2[q][0]; v[2 * q + 1] = sm2[q][1]; v[8 + 2 * q] = sq2[q][0]; v[8 + 2 * q + 1] = sq2[q][1]; }
-            const bool b0 = (er & 1) != 0, b1 = (er & 2) != 0, b2 = (er & 4) != 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float keep = b0 ? v[k + 8] : v[k], send = b0 ? v[k] : v[k + 8];
-                v[k] = keep + __shfl_xor(send, 8, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float keep = b1 ? v[k + 4] : v[k], send = b1 ? v[k] : v[k + 4];
-                v[k] = keep + __shfl_xor(send, 16, 64);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float keep = b2 ? v[k + 2] : v[k], send = b2 ? v[k] : v[k + 2];
-                v[k] = keep + __shfl_xor(send, 32, 64);
-            }
-            const int e0 = ((er >> 1) & 1) * 4 + (er >> 2) * 2;
-            float pva[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pva[e] = pv2[e >> 1][e & 1];
-            const float pe0 = b1 ? (b2 ? pva[6] : pva[4]) : (b2 ? pva[2] : pva[0]);
-            const float pe1 = b1 ? (b2 ? pva[7] : pva[5]) : (b2 ? pva[3] : pva[1]);
-            float* d3 = reinterpret_cast<float*>(smem + EPI_DEP) + (wave * 64 + ec * 8 + e0) * 3;
-            d3[(int)b0] = v[0];
-            d3[3 + (int)b0] = v[1];
-            if (!b0) { d3[2] = pe0; d3[5] = pe1; }
-        }
-    };
+    const float al_f32 = F32O ? p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.f) * (p.alpha_dev2 ? *p.alpha_dev2 : 1.f) : 0.f;      // (epilogue_f32 of the .inc)
     // ================================ main ==========================================================================
     tile_coords(u_dma);
     set_a(true);
@@ -602,7 +495,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         for (int c = 1; c < nch - 1; ++c) chunk(IC6<0>{}, c);
         chunk(IC6<2>{}, nch - 1);
         // the patch buffer of the last chunk (pnext after the swap) is scratch until the next tile's second patch is requested
-        if constexpr (F32O) epilogue_f32(pnext);
+        if constexpr (F32O) epilogue_f32(pnext, al_f32);
         else if constexpr (RES) epilogue(pnext, 0L);
         else epilogue_packed(pnext, 0L);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // statistics deposits written; every slice window read
@@ -619,9 +512,10 @@ int device_cus();   // api.hip
 
 template <typename T> static int launch6(IgemmParams& p, int total, int grid, hipStream_t s) {
     if constexpr (std::is_same<T, f16>::value) {
-        if (p.split_c > 0) {   // an fp32 convolution from f16 split planes (patch_eligible)
-            hipLaunchKernelGGL((igemm6_kernel<f16, true, false, 3, true>), dim3(grid), dim3(512), 0, s, p, total);
-            tag_kernel("igemm6_kernel<_Float16, true, false, 3, f32split>");
+        if (p.split_c > 0) {   // an fp32 convolution from f16 split planes (patch_eligible): 3x3, or a 2x2 parity phase of an upsampler convolution
+            if (p.kh == 2) hipLaunchKernelGGL((igemm6_kernel<f16, true, false, 2, true>), dim3(grid), dim3(512), 0, s, p, total);
+            else hipLaunchKernelGGL((igemm6_kernel<f16, true, false, 3, true>), dim3(grid), dim3(512), 0, s, p, total);
+            tag_kernel("igemm6_kernel<_Float16, true, false, %d, f32split>", p.kh);
             return check_launch("igemm6");
         }
     }
@@ -648,7 +542,7 @@ static bool patch_eligible(int dtype, int mode, IgemmParams& p, int nz, int& gri
     if (p.ksplit_taps > 0 || p.bias_along_m) return false;
     if (p.stride != 1 || p.zins > 1) return false;
     const bool taps3 = p.kh == 3 && p.kw == 3 && p.pad_t == 1 && p.pad_l == 1;
-    if (p.split_c > 0 && (dtype != E2EFT_F16 || !taps3 || p.x2 || p.nrm_ad || p.rowadd || p.cin != 3 * p.split_c || p.split_c % 64 != 0 || p.hl != p.hin || p.out_seg != 0)) return false;
+    if (p.split_c > 0 && (dtype != E2EFT_F16 || p.x2 || p.nrm_ad || p.rowadd || p.cin != 3 * p.split_c || p.split_c % 64 != 0 || p.hl != p.hin)) return false;
     // round 6: a 2x2 convolution with top / left pads of 0 or 1 — one parity phase of a 2x-upsampler convolution (e2eft_upconv2x_fwd); its rows may be written as
     // segments of a full-resolution image (out_seg = the row length)
     const bool taps2 = p.kh == 2 && p.kw == 2 && (unsigned)p.pad_t <= 1u && (unsigned)p.pad_l <= 1u && !p.residual && !p.nrm_ad && !p.x2 && (p.out_seg == 0 || p.out_seg == p.wl);

@@ -221,6 +221,57 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnGeom g, int silu, int l
     }
 }
 
+// fp32 GroupNorm(+SiLU) whose output leaves as the two-term f16 split of csrc/f32split.hip: planes [pixel][y0 (C) | y1 (C)] with y * s = y0 + y1, s a power of two the
+// HOST chose from a bound of the output (|SiLU(t)| <= |t| <= max|gamma| * sqrt(elements per group) + max|beta|: the normalised value of one element of n is at most
+// sqrt(n - 1)) — no maximum pass, and the consumer (e2eft_conv2d_fwd_f32split) never sees the fp32 tensor: 4 + 4 bytes per element like the plain apply pass.
+// The conversions saturate (a bound that generous costs nothing: values 2^17 below it still carry 22 bits).  grid as gn_apply_kernel, one source.
+__global__ __launch_bounds__(256) void gn_apply_split_kernel(GnGeom g, int silu, int ldp, float s, const float* __restrict__ x1, const float* __restrict__ ad,
+                                                             const float* __restrict__ beta, f16* __restrict__ planes) {
+    const int tid = threadIdx.x;
+    const int chl = tid % g.cpb, pl = tid / g.cpb;
+    if (pl >= g.pl) return;
+    const int ch = blockIdx.z * g.cpb + chl;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * g.slab;
+    const int p1 = min(p0 + g.slab, g.hw);
+    const int c = ch * 4;
+    const float* src = x1 + c;
+    float a[4], mu[4], be[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        a[e] = ad[((long)b * g.C + c + e) * 2];
+        mu[e] = ad[((long)b * g.C + c + e) * 2 + 1];
+        be[e] = beta ? beta[c + e] : 0.f;
+    }
+    auto one = [&](long row, const floatx4& v) {
+        half4 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = fmaf(v[e] - mu[e], a[e], be[e]);      // gn_apply_kernel<float>'s arithmetic
+            if (silu) t = silu_f(t);
+            t = fminf(fmaxf(t * s, -65504.f), 65504.f);
+            const f16 q0 = (f16)t;
+            h0[e] = q0;
+            h1[e] = (f16)(t - (float)q0);
+        }
+        *reinterpret_cast<half4*>(planes + row * ldp + c) = h0;
+        *reinterpret_cast<half4*>(planes + row * ldp + g.C + c) = h1;
+    };
+    int pix = p0 + pl;
+    for (; pix + 3 * g.pl < p1; pix += 4 * g.pl) {
+        const long row = (long)b * g.hw + pix;
+        floatx4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const floatx4*>(src + (row + (long)u * g.pl) * g.ldx1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(row + (long)u * g.pl, v[u]);
+    }
+    for (; pix < p1; pix += g.pl) {
+        const long row = (long)b * g.hw + pix;
+        one(row, *reinterpret_cast<const floatx4*>(src + row * g.ldx1));
+    }
+}
+
 static int gn_geom(const E2eftGroupNormDesc* d, GnGeom& g) {
     const int epc = 16 / (int)dtype_size(d->dtype);
     g.batch = d->batch; g.hw = d->hw; g.c1 = d->c1; g.ldx1 = d->ldx1; g.c2 = d->c2; g.ldx2 = d->ldx2;
@@ -839,6 +890,26 @@ extern "C" int e2eft_groupnorm_fwd_stats(const E2eftGroupNormDesc* d, const void
     E2EFT_DISPATCH_DTYPE(d->dtype, T, return gn_run<T>(d, g, x1, x2, gamma, nullptr, nullptr, partial1, nslabs1, d->c2 > 0 ? partial2 : nullptr, nslabs2,
                                                       workspace, (hipStream_t)stream));
     return 0;
+}
+
+// fp32 GroupNorm(+SiLU) -> f16 split planes (csrc/f32split.hip): the statistics exactly as e2eft_groupnorm_fwd_stats (the workspace afterwards is what
+// e2eft_groupnorm_bwd expects), then gn_apply_split_kernel
+extern "C" int e2eft_groupnorm_fwd_split(const E2eftGroupNormDesc* d, const float* x, const float* gamma, const float* beta, void* planes, int32_t ldp, float scale,
+                                         const float* partial1, int32_t nslabs1, void* workspace, size_t ws_bytes, void* stream) {
+    E2EFT_REQUIRE(d && d->dtype == E2EFT_F32 && d->c2 == 0, "groupnorm_fwd_split: one fp32 source");
+    E2EFT_REQUIRE(planes && ldp >= 2 * d->c1 && ldp % 4 == 0 && ((uintptr_t)planes & 7) == 0 && d->c1 % 4 == 0, "groupnorm_fwd_split: planes ldp=%d", (int)ldp);
+    E2EFT_REQUIRE(scale > 0.f && scale < 3.0e38f, "groupnorm_fwd_split: scale");
+    const int rc = e2eft_groupnorm_fwd_stats(d, x, nullptr, gamma, partial1, nslabs1, nullptr, 0, workspace, ws_bytes, stream);
+    if (rc) return rc;
+    GnGeom g;
+    gn_geom(d, g);
+    const float* ad = (const float*)((const char*)workspace + e2eft_groupnorm_coeff_offset(d));
+    const long tensor_bytes = (long)d->batch * d->hw * g.C * 4L;
+    const int it = option(E2EFT_OPT_GN_APPLY_ITERS);
+    g.slab = g.pl * 4 * (it > 0 ? it : (tensor_bytes <= (128L << 20) ? 4 : 2));
+    g.nslabs = (d->hw + g.slab - 1) / g.slab;
+    hipLaunchKernelGGL(gn_apply_split_kernel, dim3(g.nslabs, g.batch, g.nchb), dim3(256), 0, (hipStream_t)stream, g, d->silu, (int)ldp, scale, x, ad, beta, (f16*)planes);
+    return check_launch("groupnorm_fwd_split");
 }
 
 extern "C" int e2eft_groupnorm_fwd(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma,

@@ -156,17 +156,25 @@ class ResnetBlock2D(nn.Module):
             h = conv_nhwc(self.conv1, x, rowadd=rowadd, norm=(self.norm1, True))
             sc = conv_nhwc(self.conv_shortcut, x) if self.conv_shortcut is not None else x
             return conv_nhwc(self.conv2, h, residual=sc, norm=(self.norm2, True))
-        if x2 is None:
-            h, x = self.norm1.nhwc(x, silu=True, split=True)     # x: the same tensor, routed through the norm for its gradient
+        # fp32 with a frozen convolution (the VAE under the fp32 recipe): norm + conv as one differentiable op on f16 split planes (autograd._NormConvSplitFn)
+        fused = F.norm_conv_split(self.conv1, self.norm1, x, True, split=True) if (x2 is None and rowadd is None) else None
+        if fused is not None:
+            h, x = fused
         else:
-            h = self.norm1.nhwc(x, x2=x2, silu=True)
-        h = conv_nhwc(self.conv1, h, rowadd=rowadd)
-        h = self.norm2.nhwc(h, silu=True)
+            if x2 is None:
+                h, x = self.norm1.nhwc(x, silu=True, split=True)     # x: the same tensor, routed through the norm for its gradient
+            else:
+                h = self.norm1.nhwc(x, x2=x2, silu=True)
+            h = conv_nhwc(self.conv1, h, rowadd=rowadd)
         if self.conv_shortcut is not None:
             sc = conv_nhwc(self.conv_shortcut, x, x2=x2)
         else:
             assert x2 is None
             sc = x
+        fused = F.norm_conv_split(self.conv2, self.norm2, h, True, residual=sc)
+        if fused is not None:
+            return fused
+        h = self.norm2.nhwc(h, silu=True)
         return conv_nhwc(self.conv2, h, residual=sc)
 
     def forward(self, x, temb=None):

@@ -246,7 +246,8 @@ def _attach_stats(out, buf, slab_rows, images, rows_per_image, cout):
     return out
 
 
-F32_SPLIT_ENABLED = True      # tests / A-B: False keeps fp32 3x3 convolutions on the fp32 matrix instruction (igemm2)
+F32_SPLIT_ENABLED = True      # tests / A-B: False keeps fp32 convolutions / GEMMs on the fp32 matrix instruction (igemm2)
+WGRAD_F32_SPLIT = True        # tests / A-B: False keeps fp32 weight gradients on wgrad32_kernel (v_mfma_f32_32x32x2_f32)
 
 
 def f32_split2(x):
@@ -263,49 +264,120 @@ def f32_split2(x):
 
 
 def f32_split_weight(w_packed, taps, c):
-    """fp32 packed weight [cout, taps*c] (rows (tap, c)) -> (f16 [cout, taps*3c] rows (tap, [w0 | w1 | w0]) with w * s_w = w0 + w1, 1 / s_w).  Cached on the packed tensor
-    (autograd.packed_conv_weight hands out one object per parameter version); one host read of the maximum per weight version."""
+    """fp32 packed weight [cout, taps*c] (rows (tap, c)) -> (f16 [cout, taps*3c] rows (tap, [w0 | w1 | w0]) with w * s_w = w0 + w1, device scalar 1 / s_w).  s_w is the
+    power of two that brings the weight's maximum into [2^14, 2^15), computed on the device (trainable weights change every optimizer step: no host read).  Cached on
+    the packed tensor object per version (autograd.packed_conv_weight hands out one object per parameter version)."""
     ent = getattr(w_packed, "_e2eft_split", None)
     if ent is not None and ent[0] == w_packed._version:
         return ent[1], ent[2]
-    cout = w_packed.shape[0]
-    assert w_packed.dtype == torch.float32 and w_packed.shape[1] == taps * c
+    cout = w_packed.numel() // (taps * c)          # (a [4, cout, taps * c] stack of phase weights splits as one tensor: one scale)
+    assert w_packed.dtype == torch.float32 and w_packed.shape[-1] == taps * c and w_packed.is_contiguous()
+    with torch.no_grad():
+        wv = w_packed.detach().view(cout, taps, c)
+        ex = torch.frexp(wv.abs().max())[1]                  # max = m * 2^ex, m in [0.5, 1)  (0 -> ex = 0: any scale serves a zero weight)
+        k = (15 - ex).clamp(-100, 100)
+        one = torch.ones((), dtype=torch.float32, device=w_packed.device)
+        ws = wv * torch.ldexp(one, k)
+        w0 = ws.to(torch.float16)
+        w1 = (ws - w0.float()).to(torch.float16)
+        wsp = torch.cat([w0, w1, w0], dim=2).reshape(cout, taps * 3 * c).contiguous()
+        inv = torch.ldexp(one, -k).reshape(1).contiguous()
+    w_packed._e2eft_split = (w_packed._version, wsp, inv)
+    return wsp, inv
+
+
+def _pow2_scale(bound):
+    """power of two s with bound * s in [2^14, 2^15) (1.0 for 0 / non-finite bounds), and 1 / s"""
     import math
-    amax = float(w_packed.detach().abs().max())
-    k = 0 if (amax == 0.0 or not math.isfinite(amax)) else 14 - math.frexp(amax)[1] + 1      # amax * 2^k in [2^14, 2^15)
-    k = max(-100, min(100, k))
-    ws = w_packed.detach().view(cout, taps, c) * (2.0 ** k)
-    w0 = ws.to(torch.float16)
-    w1 = (ws - w0.float()).to(torch.float16)
-    wsp = torch.cat([w0, w1, w0], dim=2).reshape(cout, taps * 3 * c).contiguous()
-    w_packed._e2eft_split = (w_packed._version, wsp, 2.0 ** (-k))
-    return wsp, 2.0 ** (-k)
+    if bound == 0.0 or not math.isfinite(bound):
+        return 1.0, 1.0
+    k = max(-100, min(100, 15 - math.frexp(bound)[1]))
+    return 2.0 ** k, 2.0 ** (-k)
 
 
-def _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label):
-    """The fp32 3x3 / stride-1 / pad-1 convolution through e2eft_conv2d_fwd_f32split, or None when the library declines the shape."""
-    B, H, W, c1 = x.shape
+def _absmax_cached(t):
+    """max |t| of a parameter-like tensor as a host float, cached on the tensor object per version (one host read per parameter version)"""
+    if t is None:
+        return 0.0
+    ent = getattr(t, "_e2eft_absmax", None)
+    if ent is None or ent[0] != t._version:
+        ent = (t._version, float(t.detach().abs().max()))
+        t._e2eft_absmax = ent
+    return ent[1]
+
+
+def _f32split_desc(B, H, W, c1, cout, kh, kw, stride, pad, ldo, ldr):
+    pt, pb, pl, pr = pad
     d = ConvDesc()
     d.dtype = _lib.F32
     d.batch, d.hin, d.win, d.hl, d.wl = B, H, W, H, W
     d.c1, d.ldx1, d.c2, d.ldx2 = c1, 2 * c1, 0, 0
-    d.kh, d.kw, d.stride, d.pad_t, d.pad_l = 3, 3, 1, 1, 1
-    d.hout, d.wout, d.cout, d.ldo = H, W, cout, _nhwc_ld(out)
-    d.ldr = _nhwc_ld(residual) if residual is not None else 0
-    d.ldw = 27 * c1
+    d.kh, d.kw, d.stride, d.pad_t, d.pad_l = kh, kw, stride, pt, pl
+    d.hout = (H + pt + pb - kh) // stride + 1
+    d.wout = (W + pl + pr - kw) // stride + 1
+    d.cout, d.ldo, d.ldr, d.ldw = cout, ldo, ldr, kh * kw * 3 * c1
+    d.alpha = 1.0
+    return d
+
+
+def f32split_shape_ok(B, H, W, c1, cout, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1)):
+    """pure host arithmetic: would the library run this fp32 convolution [B,H,W,c1] -> cout from f16 split planes (e2eft_conv2d_fwd_f32split_supported)?"""
+    if not F32_SPLIT_ENABLED or c1 % 64 != 0 or cout % 8 != 0:
+        return False
+    d = _f32split_desc(B, H, W, c1, cout, kh, kw, stride, pad, cout, cout)
+    return _lib.load().e2eft_conv2d_fwd_f32split_supported(C.byref(d)) == 1
+
+
+def groupnorm_fwd_split_ws(x, gamma, beta, groups, eps, silu=False, s1=None):
+    """fp32 GroupNorm(+SiLU) of x [B,H,W,C] whose output leaves as f16 split planes (e2eft_groupnorm_fwd_split) -> (planes [B,H,W,2C], 1 / scale, workspace for
+    groupnorm_bwd).  The scale is a host constant from a bound of the output: |y| <= max|gamma| * sqrt(H W C / groups) + max|beta|."""
+    _check_cuda(x, gamma, beta)
+    B, H, W, c1 = x.shape
+    assert x.dtype == torch.float32
+    import math
+    bound = _absmax_cached(gamma) * math.sqrt(float(H * W * (c1 // groups))) + _absmax_cached(beta) if gamma is not None else math.sqrt(float(H * W * (c1 // groups)))
+    sc, inv = _pow2_scale(bound)
+    planes = torch.empty((B, H, W, 2 * c1), dtype=torch.float16, device=x.device)
+    d = _gn_desc(x, None, groups, eps, silu, c1)
+    lib = _lib.load()
+    nbytes = lib.e2eft_groupnorm_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError("groupnorm: %s" % lib.e2eft_last_error().decode())
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    if not GN_STATS_ENABLED:
+        s1 = None
+    with _timed("groupnorm", 0.0, 2.0 * B * H * W * c1 * 4, label="gn->split B%d %dx%d C%d" % (B, H, W, c1)):
+        check(lib.e2eft_groupnorm_fwd_split(C.byref(d), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(planes), 2 * c1, sc, _ptr(s1.partial) if s1 else C.c_void_p(0),
+                                            s1.nslabs if s1 else 0, _ptr(ws), nbytes, _stream()))
+    return planes, inv, ws
+
+
+def _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label, planes=None, inv_scale=None, geom=(3, 3, 1, (1, 1, 1, 1))):
+    """An fp32 convolution (geom = kh, kw, stride, pads; one source, no fused upsample) through e2eft_conv2d_fwd_f32split, or None when the library declines the
+    shape.  planes / inv_scale: the input already split (groupnorm_fwd_split_ws) — x is then ignored."""
+    B, H, W, c1 = x.shape if planes is None else (planes.shape[0], planes.shape[1], planes.shape[2], planes.shape[3] // 2)
+    kh, kw, stride, pad = geom
+    d = _f32split_desc(B, H, W, c1, cout, kh, kw, stride, pad, _nhwc_ld(out), _nhwc_ld(residual) if residual is not None else 0)
+    assert (d.hout, d.wout) == (out.shape[1], out.shape[2])
+    H, W = d.hout, d.wout          # (below: the OUTPUT grid)
     d.alpha = alpha
     lib = _lib.load()
     if (lib.e2eft_conv2d_fwd_f32split_supported(C.byref(d)) != 1 or out.data_ptr() % 16 or (residual is not None and residual.data_ptr() % 16)
-            or (bias is not None and bias.data_ptr() % 16) or x.data_ptr() % 16 or _nhwc_ld(x) % 4 or not w_packed.is_contiguous()):
+            or (bias is not None and bias.data_ptr() % 16) or not w_packed.is_contiguous() or (planes is None and (x.data_ptr() % 16 or _nhwc_ld(x) % 4))):
         return None
-    wsp, inv_sw = f32_split_weight(w_packed, 9, c1)
-    d.alpha = alpha * inv_sw
-    planes, scale = f32_split2(x)
-    nb = (B * H * W * 2 * c1 * 2 + B * H * W * cout * 4 * (2 if residual is not None else 1) + cout * 27 * c1 * 2)
-    with _timed("igemm", 2.0 * B * H * W * cout * 9 * c1, nb, label=label + " f32split"):
-        buf, nbytes = _gn_buffer(B, H * W, cout, x.device) if want else (None, 0)
+    wsp, inv_sw = f32_split_weight(w_packed, kh * kw, c1)
+    d.alpha = alpha
+    scale = None
+    if planes is None:
+        planes, scale = f32_split2(x)
+    else:
+        d.alpha = d.alpha * inv_scale
+    nb = (planes.numel() * 2 + B * H * W * cout * 4 * (2 if residual is not None else 1) + cout * kh * kw * 3 * c1 * 2)
+    # (flops: what the f16 pipe multiplies — three products per fp32 product; flops_nominal: the fp32 convolution)
+    with _timed("igemm", 6.0 * B * H * W * cout * kh * kw * c1, nb, label=label + " f32split", flops_nominal=2.0 * B * H * W * cout * kh * kw * c1):
+        buf, nbytes = _gn_buffer(B, H * W, cout, out.device) if want else (None, 0)
         slab = C.c_int32(0)
-        check(lib.e2eft_conv2d_fwd_f32split(C.byref(d), _ptr(planes), _ptr(scale), _ptr(wsp), _ptr(bias), _ptr(residual), _ptr(out), _ptr(buf), nbytes,
+        check(lib.e2eft_conv2d_fwd_f32split(C.byref(d), _ptr(planes), _ptr(scale), _ptr(wsp), _ptr(inv_sw), _ptr(bias), _ptr(residual), _ptr(out), _ptr(buf), nbytes,
                                             C.byref(slab), _stream()))
         if want:
             _attach_stats(out, buf, slab.value, B, H * W, cout)
@@ -352,6 +424,30 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
     if rowadd is not None:
         assert rowadd.dtype == x.dtype and tuple(rowadd.shape) == (B, cout) and rowadd.is_contiguous()
     want = gn_stats and GN_STATS_ENABLED and cout % 8 == 0
+    if (w_phase is not None and UPCONV_PHASES_ENABLED and F32_SPLIT_ENABLED and x.dtype == torch.float32 and up_to is not None and x2 is None and rowadd is None
+            and residual is None and norm is None and alpha == 1.0 and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1) and (hl, wl) == (2 * H, 2 * W)
+            and c1 % 64 == 0 and x.data_ptr() % 16 == 0 and d.ldx1 % 4 == 0 and out.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0)):
+        # fp32: the four 2x2 phases on the f16 matrix pipe from split planes (csrc/f32split.hip)
+        lib = _lib.load()
+        ldx_keep = d.ldx1
+        d.ldx1 = 2 * c1
+        ok = lib.e2eft_upconv2x_fwd_f32split_supported(C.byref(d)) == 1
+        if ok:
+            wp = w_phase()
+            assert tuple(wp.shape) == (4, cout, 4 * c1) and wp.dtype == torch.float32
+            wsp, inv_sw = f32_split_weight(wp, 4, c1)
+            planes, scale = f32_split2(x)
+            nbp = planes.numel() * 2 + B * hout * wout * cout * 4 + wsp.numel() * 2
+            with _timed("igemm", 6.0 * B * H * W * 4 * cout * 4 * c1, nbp, label="upconv2x(4 phases) B%d %dx%d %d->%d f32split" % (B, hout, wout, c1, cout), launches=4,
+                        flops_nominal=2.0 * B * hout * wout * cout * 9 * c1):
+                buf, nbytes = _gn_buffer(B, hout * wout, cout, x.device) if want else (None, 0)
+                slab = C.c_int32(0)
+                check(lib.e2eft_upconv2x_fwd_f32split(C.byref(d), _ptr(planes), _ptr(scale), _ptr(wsp), _ptr(inv_sw), _ptr(bias), _ptr(out), _ptr(buf), nbytes,
+                                                      C.byref(slab), _stream()))
+                if want:
+                    _attach_stats(out, buf, slab.value, B, hout * wout, cout)
+            return out
+        d.ldx1 = ldx_keep
     if (w_phase is not None and UPCONV_PHASES_ENABLED and up_to is not None and x2 is None and rowadd is None and residual is None and norm is None and alpha == 1.0
             and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1) and (hl, wl) == (2 * H, 2 * W)
             and _lib.load().e2eft_upconv2x_fwd_supported(C.byref(d)) == 1):
@@ -379,14 +475,25 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
         narrow_ok = cout > 4 or (rowadd is None and residual is None and not want)
         if NORM_FUSION_ENABLED and x2 is None and not sk and narrow_ok and lib.e2eft_conv2d_fwd_normed_supported(C.byref(d)) == 1:
             ws, coeff = groupnorm_stats(x, gamma, groups, eps)     # (a, mean) pairs; the apply pass is the convolution's operand fetch
+        elif (x.dtype == torch.float32 and x2 is None and not sk and up_to is None and rowadd is None and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1)
+              and (alpha == 1.0 or bias is None)
+              and w_packed.shape[1] == 9 * c1 and f32split_shape_ok(B, H, W, c1, cout)):
+            # fp32: the norm's apply pass writes the f16 split planes the convolution reads (csrc/f32split.hip) — no fp32 intermediate, no maximum pass
+            planes, inv, _ = groupnorm_fwd_split_ws(x, gamma, beta, groups, eps, silu=silu, s1=getattr(x, "_e2eft_gn", None))
+            r = _conv2d_f32split(None, w_packed, bias, cout, residual, alpha, out, want,
+                                 "conv3x3s1n B%d %dx%d %d->%d" % (B, hout, wout, c1, cout), planes=planes, inv_scale=inv)
+            if r is not None:
+                return r
+            x = groupnorm(x, gamma, beta, groups, eps, silu=silu)
         else:
             x = groupnorm(x, gamma, beta, groups, eps, silu=silu, x2=x2)      # the norm of the CONCATENATED input; its output is one tensor
             x2 = None
             d.c1, d.ldx1, d.c2, d.ldx2 = x.shape[3], _nhwc_ld(x), 0, 0
     label = _label or "conv%dx%ds%d%s%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", "n" if coeff is not None else "", B, hout, wout, d.c1 + d.c2, cout)
-    if (F32_SPLIT_ENABLED and x.dtype == torch.float32 and coeff is None and not sk and x2 is None and up_to is None and rowadd is None and (kh, kw, stride) == (3, 3, 1)
-            and tuple(pad) == (1, 1, 1, 1) and x.shape[3] % 64 == 0 and w_packed.shape[1] == 9 * x.shape[3]):
-        r = _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label)
+    if (F32_SPLIT_ENABLED and x.dtype == torch.float32 and coeff is None and not sk and x2 is None and up_to is None and rowadd is None and kh * kw > 1
+            and (alpha == 1.0 or bias is None)
+            and x.shape[3] % 64 == 0 and w_packed.shape[1] == kh * kw * x.shape[3]):
+        r = _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label, geom=(kh, kw, stride, tuple(pad)))
         if r is not None:
             return r
     with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2), nb, label=label):
@@ -437,6 +544,28 @@ def gemm(a, w, bias=None, residual=None, out=None, alpha=1.0, bias_along_m=False
     if residual is not None:
         assert tuple(residual.shape) == (M, N) and residual.dtype == a.dtype
     want = gn_rows_per_image > 0 and GN_STATS_ENABLED and N % 8 == 0 and M % gn_rows_per_image == 0 and not bias_along_m
+    if (F32_SPLIT_ENABLED and a.dtype == torch.float32 and not want and not bias_along_m and (alpha == 1.0 or bias is None) and K % 64 == 0 and M % 256 == 0 and N % 8 == 0 and w.is_contiguous()
+            and a.data_ptr() % 16 == 0 and d.lda % 4 == 0 and out.data_ptr() % 16 == 0 and (residual is None or residual.data_ptr() % 16 == 0)
+            and (bias is None or bias.data_ptr() % 16 == 0)):
+        # fp32 nn.Linear of whole 256-row tiles: two-term f16 split planes on the f16 matrix pipe (csrc/f32split.hip; igemm5's GEMM mode)
+        ds = GemmDesc()
+        ds.dtype = _lib.F32
+        ds.m, ds.n, ds.k = M, N, K
+        ds.lda, ds.ldw, ds.ldo, ds.ldr = 2 * K, 3 * K, d.ldo, d.ldr
+        ds.nzo = ds.nzi = 1
+        ds.bias_along_m = 0
+        ds.alpha = alpha
+        lib = _lib.load()
+        if lib.e2eft_gemm_f32split_supported(C.byref(ds)) == 1:
+            wsp, inv_sw = f32_split_weight(w, 1, K)
+            planes = torch.empty((M, 2 * K), dtype=torch.float16, device=a.device)
+            scale = torch.empty(4, dtype=torch.float32, device=a.device)
+            with _timed("f32split", 0.0, 12.0 * M * K, label="split2 rows M%d K%d" % (M, K), launches=2):
+                check(lib.e2eft_f32_split2(_ptr(a), M, K, d.lda, _ptr(planes), 2 * K, _ptr(scale), _stream()))
+            with _timed("igemm", 6.0 * M * N * K, (M * 2 * K * 2 + N * 3 * K * 2 + M * N * 4 * (2 if residual is not None else 1)), label="gemm M%d N%d K%d f32split" % (M, N, K),
+                        flops_nominal=2.0 * M * N * K):
+                check(lib.e2eft_gemm_f32split(C.byref(ds), _ptr(planes), _ptr(scale), _ptr(wsp), _ptr(inv_sw), _ptr(bias), _ptr(residual), _ptr(out), _stream()))
+            return out
     with _timed("igemm", 2.0 * M * N * K, (M * K + N * K + M * N * (2 if residual is not None else 1)) * a.element_size(), label="gemm M%d N%d K%d" % (M, N, K)):
         if want:
             buf, nbytes = _gn_buffer(M // gn_rows_per_image, gn_rows_per_image, N, a.device)
@@ -929,6 +1058,26 @@ def conv2d_wgrad(dy, x, x2, cout, kh, kw, stride, pad, alpha, out=None):
     if not WGRAD_DIRECT or (dy.dtype == torch.float32 and not WGRAD_DIRECT_FP32):
         return None
     _check_cuda(dy, x, x2)
+    if (dy.dtype == torch.float32 and F32_SPLIT_ENABLED and WGRAD_F32_SPLIT and x2 is None and x.shape[3] % 64 == 0 and cout % 64 == 0 and dy.shape[3] % 8 == 0
+            and _lib.load().e2eft_get_option(_lib.OPT_F32_SPLIT) == 1 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
+        # fp32 on the f16 matrix pipe (csrc/f32split.hip): dy s_dy = d0 + d1, x s_x = x0 + x1 (two-term f16 splits, exact to 2^-22); the gradient is the sum of the
+        # 16-bit kernel's results for (d0, x0), (d0, x1), (d1, x0), scaled back by the two device scalars — three launches at the f16 rate instead of one at the fp32 rate
+        dyp, sdy = f32_split2(dy)
+        xp, sx = f32_split2(x)
+        c0, c1 = dy.shape[3], x.shape[3]
+        r = None
+        for (a_, b_) in ((dyp[..., :c0], xp[..., :c1]), (dyp[..., :c0], xp[..., c1:]), (dyp[..., c0:], xp[..., :c1])):
+            t = conv2d_wgrad(a_, b_, None, cout, kh, kw, stride, pad, alpha)
+            if t is None:
+                r = None
+                break
+            r = t if r is None else r.add_(t)
+        if r is not None:
+            r = r.mul_(sdy[2] * sx[2])
+            if out is not None:
+                out.view(r.shape).copy_(r)
+                return out.view(r.shape)
+            return r
     B = x.shape[0]
     lddy = _nhwc_ld(dy)
     es = dy.element_size()

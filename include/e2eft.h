@@ -171,16 +171,28 @@ int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const void* w_phas
  * product, below the fp32 accumulation error of the reduction itself (tests/test_f32split_gpu.py measures both routes against float64).
  *   e2eft_f32_split2: x fp32 [pixels][ldx] (c channels, c % 8 == 0, 16-byte aligned) -> planes f16 [pixels][ldp], channels [0, c) = x0, [c, 2c) = x1 (ldp >= 2c, % 8);
  *     scale: three device floats of workspace, on return (stream-ordered) scale[1] = s, scale[2] = 1 / s.  No host synchronisation.
- *   e2eft_conv2d_fwd_f32split: out = alpha / s * (conv3x3(planes, w_split)) + bias + residual in fp32.  `d`: dtype E2EFT_F32, 3x3 / stride 1 / pads 1, c2 = 0,
- *     c1 = c (% 64 == 0, >= 64), ldx1 = ldp (f16 elements), ldw = row length of w_split in f16 elements (>= 27 c), ldo / ldr in fp32 elements, width % 32 == 0,
- *     height % 8 == 0; alpha = (the caller's factor) / s_w.  w_split: f16 [cout][3][3][w0 (c) | w1 (c) | w0 (c)] with w s_w = w0 + w1 built once per weight by the
- *     caller (power-of-two s_w).  scale: the workspace e2eft_f32_split2 filled for these planes.  gn_partial / slab_rows as e2eft_conv2d_fwd_gnstats (statistics of
+ *   e2eft_conv2d_fwd_f32split: out = alpha / (s s_w) * conv(planes, w_split) + bias + residual in fp32.  `d`: dtype E2EFT_F32, any filter / stride / pads of
+ *     e2eft_conv2d_fwd with one source and no fused upsample (c2 = 0, hl = hin, wl = win), c1 = c (% 64 == 0), ldx1 = ldp (f16 elements), ldw = row length of w_split in
+ *     f16 elements (>= kh kw 3 c), ldo / ldr in fp32 elements.  3x3 / stride 1 / pads 1 on a width % 32 == 0, height % 8 == 0 grid runs on the halo-patch kernel
+ *     (igemm6), everything else in whole 256-row tiles on igemm5.  w_split: f16 [cout][kh][kw][w0 (c) | w1 (c) | w0 (c)] with w s_w = w0 + w1 built once per weight
+ *     version by the caller (power-of-two s_w); w_inv_scale: device scalar 1 / s_w, or null when alpha already carries it.  scale: the workspace e2eft_f32_split2 filled for these planes, or null when the planes' scale is already folded into alpha (e2eft_groupnorm_fwd_split).  gn_partial / slab_rows as e2eft_conv2d_fwd_gnstats (statistics of
  *     the fp32 output).  Ask e2eft_conv2d_fwd_f32split_supported first (pure host arithmetic; E2EFT_OPT_F32_SPLIT = 0 makes it answer 0); E2EFT_ERR_UNSUPPORTED otherwise.
  *     The data gradient of such a convolution is the same call on dY with the flipped, transposed weights (e2eft_conv2d_dgrad's w_dgrad) split the same way. */
 int e2eft_f32_split2(const float* x, int64_t pixels, int32_t c, int32_t ldx, void* planes, int32_t ldp, float* scale, void* stream);
 int e2eft_conv2d_fwd_f32split_supported(const E2eftConvDesc* d);
-int e2eft_conv2d_fwd_f32split(const E2eftConvDesc* d, const void* planes, const float* scale, const void* w_split, const float* bias, const float* residual,
-                              float* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
+int e2eft_conv2d_fwd_f32split(const E2eftConvDesc* d, const void* planes, const float* scale, const void* w_split, const float* w_inv_scale, const float* bias,
+                              const float* residual, float* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
+/* nn.Linear in fp32 the same way (igemm5's GEMM mode): out[m][n] = alpha / (s s_w) * sum_k a[m][k] w[n][k] + bias[n] + residual[m][n].  `d`: dtype E2EFT_F32, k = columns of the
+ * fp32 operand (% 64 == 0), lda = row stride of its planes [a0 (k) | a1 (k)] in f16 elements (e2eft_f32_split2 with pixels = m, c = k), ldw = row length of
+ * w_split [n][w0 (k) | w1 (k) | w0 (k)], ldo / ldr in fp32 elements, one problem (nzo = nzi = 1), m % 256 == 0.  Ask e2eft_gemm_f32split_supported first. */
+/* e2eft_upconv2x_fwd in fp32 the same way: `d` as that call's (dtype E2EFT_F32) with ldx1 = the planes' pixel stride in f16 elements; w_phase_split: f16
+ * [4][cout][2][2][w0 (c1) | w1 (c1) | w0 (c1)] — the fp32 phase weights split as ONE tensor (one s_w).  c1 % 64 == 0, win % 16 == 0, hin * win % 256 == 0, alpha 1. */
+int e2eft_upconv2x_fwd_f32split_supported(const E2eftConvDesc* d);
+int e2eft_upconv2x_fwd_f32split(const E2eftConvDesc* d, const void* planes, const float* scale, const void* w_phase_split, const float* w_inv_scale,
+                                const float* bias, float* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
+int e2eft_gemm_f32split_supported(const E2eftGemmDesc* d);
+int e2eft_gemm_f32split(const E2eftGemmDesc* d, const void* planes, const float* scale, const void* w_split, const float* w_inv_scale, const float* bias,
+                        const float* residual, float* out, void* stream);
 int e2eft_conv2d_fwd_normed(const E2eftConvDesc* d, const void* x1, const float* coeff, const void* beta, int32_t silu, const void* w,
                             const void* bias, const void* rowadd, const void* residual, void* out, float* gn_partial,
                             size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
@@ -214,6 +226,14 @@ typedef struct E2eftGroupNormDesc {
 size_t e2eft_groupnorm_workspace_bytes(const E2eftGroupNormDesc* d);
 int e2eft_groupnorm_fwd(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma,
                         const void* beta, void* y, void* workspace, size_t ws_bytes, void* stream);
+
+/* fp32 GroupNorm(+SiLU) whose result leaves as split planes for e2eft_conv2d_fwd_f32split (one source, d->dtype E2EFT_F32): y * scale = y0 + y1.  `scale` is a power of
+ * two chosen by the HOST so that scale * (max|gamma| * sqrt(hw * channels per group) + max|beta|) < 2^15 — a bound of |y| that needs no pass over the data (a normalised
+ * value among n is at most sqrt(n - 1), |SiLU(t)| <= |t|); conversions saturate.  The consumer passes 1 / scale inside its alpha and a null `scale` workspace.
+ * partial1 / nslabs1 / workspace as e2eft_groupnorm_fwd_pre; afterwards the workspace serves e2eft_groupnorm_bwd like the plain forward's. */
+int e2eft_groupnorm_fwd_split(const E2eftGroupNormDesc* d, const float* x, const float* gamma, const float* beta, void* planes, int32_t ldp, float scale,
+                              const float* partial1, int32_t nslabs1, void* workspace, size_t ws_bytes, void* stream);
+
 /* GroupNorm whose statistics pass was (partly) done by the producer (e2eft_*_gnstats): partialK / nslabsK describe source K
  * ([batch][nslabsK][cK][3]); a NULL partial is computed here.  Same workspace size as e2eft_groupnorm_fwd. */
 int e2eft_groupnorm_fwd_pre(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma,

@@ -51,34 +51,39 @@ assert torch.isfinite(hp.float()).all() and 2.0 ** 14 <= 3.0e30 * hs[1].item() <
 
 # ---- the convolution against float64, beside the fp32 matrix instruction on the same inputs
 worst = 0.0
-# B, H, W, C, Co, bias, residual, wide-range input
+# B, H, W, C, Co, bias, residual, wide-range input, (kh, kw, stride, pad), kernel
 cases = [
-    (2, 32, 64, 128, 128, True, True, False),
-    (1, 16, 64, 64, 128, True, False, False),       # one plane = one 64-channel chunk: every chunk changes block
-    (3, 8, 32, 192, 64, False, True, True),         # three chunks per plane, cout 64, input over 6 decades
-    (2, 16, 32, 256, 256, True, False, True),       # two N tiles
+    (2, 32, 64, 128, 128, True, True, False, (3, 3, 1, 1), "igemm6"),
+    (1, 16, 64, 64, 128, True, False, False, (3, 3, 1, 1), "igemm6"),      # one plane = one 64-channel chunk: every chunk changes block
+    (5, 8, 32, 192, 64, False, True, True, (3, 3, 1, 1), "igemm6"),        # three chunks per plane, cout 64, input over 6 decades
+    (2, 16, 32, 192, 256, True, False, True, (3, 3, 1, 1), "igemm6"),      # two N tiles (K = 1728: below the split-K plan of small problems)
+    (2, 16, 48, 128, 128, True, True, False, (3, 3, 1, 1), "igemm5"),      # width 48: not the halo-patch kernel's grid -> igemm5 (tap-major K, 256-row tiles)
+    (8, 8, 24, 128, 64, True, False, True, (3, 3, 1, 1), "igemm5"),        # 192 pixels per image: tiles straddle images, no statistics from the epilogue
+    (2, 32, 64, 128, 128, True, False, False, (4, 4, 2, 1), "igemm5"),     # 4x4 / stride 2 / pad 1: the data gradient of an upsampler convolution (autograd.upconv_dgrad_weight)
+    (2, 32, 64, 64, 192, False, False, False, (3, 3, 2, 1), "igemm5"),     # a stride-2 downsampler, ragged N tile
 ]
-for (B, H, W, Cc, Co, hb, rs, wide) in cases:
-    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cc + Co + W)
+for (B, H, W, Cc, Co, hb, rs, wide, (kh, kw, st, pd), kern) in cases:
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cc + Co + W + kh)
     x = torch.randn(B, Cc, H, W, generator=g) * 1.5 + 0.3
     if wide:
         x = x * torch.exp(torch.randn(B, Cc, H, W, generator=g) * 2.0)
-    w = torch.randn(Co, Cc, 3, 3, generator=g) / (Cc * 9) ** 0.5
+    w = torch.randn(Co, Cc, kh, kw, generator=g) / (Cc * kh * kw) ** 0.5
     b = torch.randn(Co, generator=g) if hb else None
-    r = torch.randn(B, Co, H, W, generator=g) if rs else None
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), stride=st, padding=pd)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    r = torch.randn(B, Co, Ho, Wo, generator=g) if rs else None
     xd, wd = nhwc(x, torch.float32, dev), pack_conv_weight(w, torch.float32, dev)
     bd = None if b is None else b.to(dev)
     rd = None if r is None else nhwc(r, torch.float32, dev)
-    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
     if r is not None:
         ref = ref + r.double()
     ops.F32_SPLIT_ENABLED = True
-    y1 = ops.conv2d(xd, wd, bd, Co, 3, 3, 1, (1, 1, 1, 1), residual=rd, gn_stats=True)
+    y1 = ops.conv2d(xd, wd, bd, Co, kh, kw, st, (pd, pd, pd, pd), residual=rd, gn_stats=True)
     torch.cuda.synchronize()
     k1 = lib.e2eft_debug_last_kernel().decode()
-    assert "f32split" in k1, k1
+    assert "f32split" in k1 and kern in k1, k1
     ops.F32_SPLIT_ENABLED = False
-    y2 = ops.conv2d(xd, wd, bd, Co, 3, 3, 1, (1, 1, 1, 1), residual=rd, gn_stats=True)
+    y2 = ops.conv2d(xd, wd, bd, Co, kh, kw, st, (pd, pd, pd, pd), residual=rd, gn_stats=True)
     torch.cuda.synchronize()
     k2 = lib.e2eft_debug_last_kernel().decode()
     assert "float" in k2 and "f32split" not in k2, k2
@@ -86,23 +91,109 @@ for (B, H, W, Cc, Co, hb, rs, wide) in cases:
     e1, e2 = rel_err(to_nchw(y1).double(), ref), rel_err(to_nchw(y2).double(), ref)
     rms1 = ((to_nchw(y1).double() - ref) ** 2).mean().sqrt().item() / ref.abs().max().item()
     rms2 = ((to_nchw(y2).double() - ref) ** 2).mean().sqrt().item() / ref.abs().max().item()
-    # GroupNorm statistics of the output (n, mean, M2 per slab and channel): both routes describe the same tensor
-    st1, st2 = y1._e2eft_gn, y2._e2eft_gn
-    def moments(st, y):
-        p = st.partial.view(B, st.nslabs, Co, 3).double().cpu()
-        n = p[..., 0].sum(1)
-        mean = (p[..., 0] * p[..., 1]).sum(1) / n
-        m2 = (p[..., 2] + p[..., 0] * (p[..., 1] - mean[:, None]) ** 2).sum(1)
-        return n, mean, m2
-    n1, m1, v1 = moments(st1, y1)
-    yy = to_nchw(y1).double()
-    assert (n1 == H * W).all()
-    assert (m1 - yy.mean((2, 3))).abs().max() <= 1e-5 * yy.abs().max(), "statistics: mean"
-    assert ((v1 / (H * W)) - yy.var((2, 3), unbiased=False)).abs().max() <= 1e-4 * yy.var((2, 3), unbiased=False).max(), "statistics: variance"
-    print("f32split conv %%s: max err %%.3e (fp32 MFMA %%.3e), rms %%.3e (%%.3e)  [%%s]" %% ((B, H, W, Cc, Co, hb, rs, wide), e1, e2, rms1, rms2, k1), flush=True)
+    # GroupNorm statistics of the output (n, mean, M2 per slab and channel) where the epilogue emits them: they describe the tensor that was written
+    st1 = getattr(y1, "_e2eft_gn", None)
+    assert st1 is not None or (Ho * Wo) %% 256 != 0, "statistics missing"
+    if st1 is not None:
+        p = st1.partial.view(B, st1.nslabs, Co, 3).double().cpu()
+        n1 = p[..., 0].sum(1)
+        m1 = (p[..., 0] * p[..., 1]).sum(1) / n1
+        v1 = (p[..., 2] + p[..., 0] * (p[..., 1] - m1[:, None]) ** 2).sum(1)
+        yy = to_nchw(y1).double()
+        assert (n1 == Ho * Wo).all()
+        assert (m1 - yy.mean((2, 3))).abs().max() <= 1e-5 * yy.abs().max(), "statistics: mean"
+        assert ((v1 / (Ho * Wo)) - yy.var((2, 3), unbiased=False)).abs().max() <= 1e-4 * yy.var((2, 3), unbiased=False).max(), "statistics: variance"
+    print("f32split conv %%s: max err %%.3e (fp32 MFMA %%.3e), rms %%.3e (%%.3e)  [%%s]" %% ((B, H, W, Cc, Co, hb, rs, wide, kh, st), e1, e2, rms1, rms2, k1), flush=True)
     assert e1 <= max(1.5 * e2, 4e-7), (e1, e2)
     assert rms1 <= max(1.5 * rms2, 5e-8), (rms1, rms2)
     worst = max(worst, e1 / max(e2, 1e-12))
+
+# ---- nn.Linear (e2eft_gemm_f32split, igemm5's GEMM mode): x W^T + b + residual against float64, beside the fp32 matrix instruction
+for (Mr, N, K, hb, rs) in [(1024, 320, 320, True, True), (2048, 1280, 64, False, False), (512, 640, 2560, True, False)]:
+    g = torch.Generator().manual_seed(Mr + N + K)
+    a = torch.randn(Mr, K, generator=g) * torch.exp(torch.randn(Mr, K, generator=g))
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) if hb else None
+    r = torch.randn(Mr, N, generator=g) if rs else None
+    ref = a.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    if r is not None:
+        ref = ref + r.double()
+    ad, wd = a.to(dev), w.to(dev)
+    ys = {}
+    for on in (True, False):
+        ops.F32_SPLIT_ENABLED = on
+        ys[on] = ops.gemm(ad, wd, None if b is None else b.to(dev), None if r is None else r.to(dev))
+        torch.cuda.synchronize()
+        assert ("f32split" in lib.e2eft_debug_last_kernel().decode()) == on, lib.e2eft_debug_last_kernel()
+    ops.F32_SPLIT_ENABLED = True
+    e1, e2 = rel_err(ys[True].double().cpu(), ref), rel_err(ys[False].double().cpu(), ref)
+    print("f32split gemm M%%d N%%d K%%d: max err %%.3e (fp32 MFMA %%.3e)" %% (Mr, N, K, e1, e2), flush=True)
+    assert e1 <= max(1.5 * e2, 4e-7), (e1, e2)
+
+# ---- nearest-2x upsample + conv3x3 as four 2x2 phases of the split planes (e2eft_upconv2x_fwd_f32split): both kernels
+for (B, H, W, Cc, Co, kern) in [(2, 16, 32, 128, 128, "igemm6"), (2, 16, 16, 128, 64, "igemm5")]:
+    g = torch.Generator().manual_seed(B + H + W + Cc + Co)
+    x = torch.randn(B, Cc, H, W, generator=g) * 1.3
+    w = torch.randn(Co, Cc, 3, 3, generator=g) / (Cc * 9) ** 0.5
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    up = torch.nn.Conv2d(Cc, Co, 3, padding=1).to(dev)
+    with torch.no_grad():
+        up.weight.copy_(w); up.bias.copy_(b)
+    ys = {}
+    for on in (True, False):
+        ops.F32_SPLIT_ENABLED = on
+        with torch.no_grad():
+            ys[on] = ag.conv(up, nhwc(x, torch.float32, dev), up_to=(2 * H, 2 * W))
+        torch.cuda.synchronize()
+        kk = lib.e2eft_debug_last_kernel().decode()
+        assert ("f32split" in kk) == on and (not on or kern in kk), kk
+    ops.F32_SPLIT_ENABLED = True
+    e1, e2 = rel_err(to_nchw(ys[True]).double(), ref), rel_err(to_nchw(ys[False]).double(), ref)
+    print("f32split upconv2x %%s: max err %%.3e (fp32 MFMA %%.3e)" %% ((B, H, W, Cc, Co), e1, e2), flush=True)
+    assert e1 <= max(1.5 * e2, 4e-7), (e1, e2)
+
+# ---- weight gradients: three launches of the 16-bit kernel on the split planes of dY and X against float64, beside wgrad32_kernel
+for (B, H, W, Cc, Co, k) in [(2, 24, 24, 320, 320, 3), (4, 16, 32, 64, 128, 1), (2, 18, 18, 640, 640, 3)]:
+    g = torch.Generator().manual_seed(B + H + Cc + Co + k)
+    x = torch.randn(B, Cc, H, W, generator=g) * torch.exp(torch.randn(B, Cc, H, W, generator=g))
+    gy = torch.randn(B, Co, H, W, generator=g) * 1e-3 * torch.exp(torch.randn(B, Co, H, W, generator=g))
+    w64 = torch.zeros(Co, Cc, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w64, None, padding=k // 2).backward(gy.double())
+    ref = w64.grad.permute(0, 2, 3, 1).reshape(Co, -1)
+    xd, gd = nhwc(x, torch.float32, dev), nhwc(gy, torch.float32, dev)
+    rs = {}
+    for on in (True, False):
+        ops.WGRAD_F32_SPLIT = on
+        rs[on] = ops.conv2d_wgrad(gd, xd, None, Co, k, k, 1, (k // 2,) * 4, 1.0)
+        torch.cuda.synchronize()
+        assert rs[on] is not None
+    ops.WGRAD_F32_SPLIT = True
+    e1, e2 = rel_err(rs[True].double().cpu(), ref), rel_err(rs[False].double().cpu(), ref)
+    print("f32split wgrad %%s: max err %%.3e (fp32 MFMA %%.3e)" %% ((B, H, W, Cc, Co, k), e1, e2), flush=True)
+    assert e1 <= max(1.5 * e2, 4e-7), (e1, e2)
+
+# ---- GroupNorm + SiLU whose apply pass writes the planes (e2eft_groupnorm_fwd_split), without a gradient: ops.conv2d(norm=) against float64
+g = torch.Generator().manual_seed(11)
+B, H, W, Cc, Co = 2, 32, 64, 128, 128
+x = torch.randn(B, Cc, H, W, generator=g) * 3.0 - 1.0
+gamma, beta = torch.randn(Cc, generator=g) * 0.3 + 1.0, torch.randn(Cc, generator=g) * 0.5
+w = torch.randn(Co, Cc, 3, 3, generator=g) / (Cc * 9) ** 0.5
+b = torch.randn(Co, generator=g)
+ref = F.conv2d(F.silu(F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)), w.double(), b.double(), padding=1)
+xd, wd = nhwc(x, torch.float32, dev), pack_conv_weight(w, torch.float32, dev)
+yn = {}
+for on in (True, False):
+    ops.F32_SPLIT_ENABLED = on
+    yn[on] = ops.conv2d(xd, wd, b.to(dev), Co, 3, 3, 1, (1, 1, 1, 1), norm=(gamma.to(dev), beta.to(dev), 32, 1e-5, True))
+    torch.cuda.synchronize()
+    assert ("f32split" in lib.e2eft_debug_last_kernel().decode()) == on
+ops.F32_SPLIT_ENABLED = True
+en1, en2 = rel_err(to_nchw(yn[True]).double(), ref), rel_err(to_nchw(yn[False]).double(), ref)
+print("norm -> planes -> conv: max err %%.3e (fp32 GroupNorm pass + fp32 MFMA %%.3e)" %% (en1, en2), flush=True)
+assert en1 <= max(1.5 * en2, 6e-7), (en1, en2)
 
 # ---- autograd: forward + data gradient through the split route against float64 autograd
 from types import SimpleNamespace
@@ -133,6 +224,36 @@ ef1, ef2 = rel_err(res[True][0], y64.detach()), rel_err(res[False][0], y64.detac
 eg1, eg2 = rel_err(res[True][1], x64.grad), rel_err(res[False][1], x64.grad)
 print("autograd: forward %%.3e (fp32 MFMA %%.3e), data gradient %%.3e (%%.3e)" %% (ef1, ef2, eg1, eg2), flush=True)
 assert ef1 <= max(1.5 * ef2, 4e-7) and eg1 <= max(1.5 * eg2, 4e-7)
+
+# ---- a frozen fp32 ResnetBlock2D under autograd (the VAE decoder of the fp32 recipe): _NormConvSplitFn twice, the skip gradient folded into the first norm's backward
+from diffusion_e2e_ft_amd import modules as M
+blk = M.ResnetBlock2D(128, 128, None).to(dev)
+with torch.no_grad():
+    for prm in blk.parameters():
+        prm.copy_(torch.randn(prm.shape, generator=g) * (0.05 if prm.dim() > 1 else 0.3) + (1.0 if prm.dim() == 1 else 0.0))
+blk.requires_grad_(False)
+x = torch.randn(2, 128, 16, 64, generator=g) * 2.0
+gy = torch.randn(2, 128, 16, 64, generator=g)
+out = {}
+for on in (True, False):
+    ops.F32_SPLIT_ENABLED = on
+    xd = nhwc(x, torch.float32, dev).requires_grad_(True)
+    y = blk.nhwc(xd)
+    y.backward(nhwc(gy, torch.float32, dev))
+    torch.cuda.synchronize()
+    out[on] = (to_nchw(y.detach()).double(), to_nchw(xd.grad).double())
+ops.F32_SPLIT_ENABLED = True
+b64 = torch.nn.Module()
+x64 = x.double().requires_grad_(True)
+sd = {k: v.detach().double().cpu() for k, v in blk.state_dict().items()}
+h = F.conv2d(F.silu(F.group_norm(x64, 32, sd["norm1.weight"], sd["norm1.bias"], 1e-5)), sd["conv1.weight"], sd["conv1.bias"], padding=1)
+h = F.conv2d(F.silu(F.group_norm(h, 32, sd["norm2.weight"], sd["norm2.bias"], 1e-5)), sd["conv2.weight"], sd["conv2.bias"], padding=1)
+y64 = x64 + h
+y64.backward(gy.double())
+eb1, eb2 = rel_err(out[True][0], y64.detach()), rel_err(out[False][0], y64.detach())
+egb1, egb2 = rel_err(out[True][1], x64.grad), rel_err(out[False][1], x64.grad)
+print("frozen ResnetBlock2D under autograd: forward %%.3e (unfused fp32 %%.3e), input gradient %%.3e (%%.3e)" %% (eb1, eb2, egb1, egb2), flush=True)
+assert eb1 <= max(1.5 * eb2, 6e-7) and egb1 <= max(1.5 * egb2, 6e-7)
 
 # ---- the option switches the route off; shapes the kernel does not take fall back (width not a multiple of 32)
 _lib.set_option(_lib.OPT_F32_SPLIT, 0)

@@ -396,11 +396,14 @@ def test_wgrad_pixel_split_fills_whole_rounds_of_the_machine():
         too_small = (-(-pix // 64) // 8) * tiles < 256          # even at 8 k-tiles per workgroup the problem does not fill one round
         assert w / (rounds * 256) >= 0.85 or too_small, ((b, hw, cin, cout, k), ns, tiles, rounds)
     assert splits(32, 72, 320, 320, 3)[:2] == (7, 36)          # 252 workgroups: one round, 98 % full
-    # fp32 and channel counts that are not multiples of 64 are not this kernel's: 0 bytes, the caller keeps the transpose + GEMM route
+    # channel counts that are not multiples of 64 are not this kernel's: 0 bytes, the caller keeps the transpose + GEMM route; fp32 has its own form of the kernel since
+    # round 6 (wgrad32_kernel): a workspace like the 16-bit one
     d = _lib.ConvDesc()
-    d.dtype, d.batch, d.hin, d.win, d.hl, d.wl, d.hout, d.wout = 0, 1, 8, 8, 8, 8, 8, 8
-    d.c1, d.ldx1, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.cout, d.ldo, d.ldw, d.alpha = 64, 64, 3, 3, 1, 1, 1, 64, 64, 576, 1.0
+    d.dtype, d.batch, d.hin, d.win, d.hl, d.wl, d.hout, d.wout = 1, 1, 8, 8, 8, 8, 8, 8
+    d.c1, d.ldx1, d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.cout, d.ldo, d.ldw, d.alpha = 48, 48, 3, 3, 1, 1, 1, 64, 64, 432, 1.0
     assert lib.e2eft_conv2d_wgrad_workspace_bytes(C.byref(d), 64) == 0
+    d.dtype, d.c1, d.ldx1, d.ldw = 0, 64, 64, 576
+    assert lib.e2eft_conv2d_wgrad_workspace_bytes(C.byref(d), 64) > 0
 
 
 def _apply_tables(x, xt, yt):
