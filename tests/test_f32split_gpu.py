@@ -133,7 +133,7 @@ for (Mr, N, K, hb, rs) in [(1024, 320, 320, True, True), (2048, 1280, 64, False,
     assert e1 <= max(1.5 * e2, 4e-7), (e1, e2)
 
 # ---- nearest-2x upsample + conv3x3 as four 2x2 phases of the split planes (e2eft_upconv2x_fwd_f32split): both kernels
-for (B, H, W, Cc, Co, kern) in [(2, 16, 32, 128, 128, "igemm6"), (2, 16, 16, 128, 64, "igemm5")]:
+for (B, H, W, Cc, Co, kern) in [(2, 16, 32, 128, 128, "igemm6"), (4, 16, 16, 128, 64, "igemm5")]:
     g = torch.Generator().manual_seed(B + H + W + Cc + Co)
     x = torch.randn(B, Cc, H, W, generator=g) * 1.3
     w = torch.randn(Co, Cc, 3, 3, generator=g) / (Cc * 9) ** 0.5
