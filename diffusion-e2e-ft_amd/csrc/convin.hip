@@ -125,6 +125,7 @@ __global__ __launch_bounds__(512) void conv_thin_in_kernel(const IgemmParams p, 
 
     floatx16 acc[2][2];
     auto epi_rofs = [&](const int r) -> long { return (long)(r & 31) + (long)(r >> 5) * W; };
+    auto epi_rows_left = [&]() -> int { return 0x40000000; };
     constexpr int EPI_DEP = WIN;
 #define EPI_STAMP(i) do { } while (0)
 #include "igemm_persistent_epilogue.inc"

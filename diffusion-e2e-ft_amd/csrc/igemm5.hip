@@ -157,7 +157,8 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
             const int b = fast_div5(m, hw);
             const int rem = m - b * hw;
             const int oy = fast_div5(rem, p.wout), ox = rem - oy * p.wout;
-            const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+            int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+            if (F32O && m >= p.M) iy0 = -0x4000;      // a row beyond the problem (ragged last tile, F32O only): every tap is padding
             const u32x4 v = {(unsigned)(b - d_b0), (unsigned)iy0, (unsigned)ix0, (unsigned)(((b - d_b0) * p.hin + iy0) * p.win + ix0)};
             const unsigned addr = (unsigned)(RING + DEP) + (unsigned)tid * 16u;
             asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory");
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
         if (MODE == 0) {
             b1 = X1 + (long)d_m0 * p.ldx1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cur_a[i] = (unsigned)((lrow + RSTEP * i) * p.ldx1 + jc * EPC) * (unsigned)sizeof(T) - 128u;
+            for (int i = 0; i < 4; ++i) cur_a[i] = ((F32O && d_m0 + lrow + RSTEP * i >= p.M) ? OOB : (unsigned)((lrow + RSTEP * i) * p.ldx1 + jc * EPC) * (unsigned)sizeof(T)) - 128u;
         } else {
             b1 = X1 + (long)d_b0 * p.hin * p.win * p.ldx1;
             if (b2) b2 += (long)d_b0 * p.hin * p.win * p.ldx2;
@@ -452,6 +453,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(const IgemmParams p, const 
     // ---- epilogues and statistics merge: shared with igemm6.hip (rows of a wave's block are consecutive GEMM rows here)
     // p.out_seg > 0 (e2eft_upconv2x_fwd): row r (a multiple of 8; of 16 in the packed epilogue, out_seg is a multiple of 16) of the block may lie in a later output
     // segment than row 0 — every segment passed adds out_seg pixel rows (wave-uniform: one float-reciprocal division per slice)
+    auto epi_rows_left = [&]() -> int { return F32O ? p.M - (c_m0 + wm * 64 + er) : 0x40000000; };   // (epilogue_f32: rows of this lane's column of slices that exist)
     auto epi_rofs = [&](const int r) -> long {
         if (p.out_seg <= 0) return (long)r;
         return (long)r + (long)(fast_div5(c_mb + r, p.out_seg) - c_seg0) * p.out_seg;
@@ -527,7 +529,9 @@ static int persistent_plan(int dtype, int mode, IgemmParams& p, int nz, long& to
     if (p.ksplit_taps > 0 || p.bias_along_m) return -1;
     if (p.split_c > 0 && (dtype != E2EFT_F16 || nz != 1 || p.x2 || p.rowadd || p.split_c % 64 != 0 || p.cin != 3 * p.split_c || p.c1 != p.cin ||
                           (mode == 0 && p.K != 3 * p.split_c))) return -1;
-    if (p.M % BM != 0 || p.K % 64 != 0 || p.K / 64 < 3) return -1;
+    // whole 256-row tiles — except the fp32-split launches (F32O): their row table / A offsets zero the rows beyond M and epilogue_f32 masks them (the 18^2 UNet level
+    // of the 576^2 recipe is 20.25 tiles per launch)
+    if ((p.M % BM != 0 && !(p.split_c > 0 && p.out_seg == 0 && p.M > BM)) || p.K % 64 != 0 || p.K / 64 < 3) return -1;
     if (p.N % 8 != 0 || p.ldo % 8 != 0 || (((uintptr_t)p.out) & 15) != 0) return -1;
     if (p.residual && (p.ldr % 8 != 0 || (((uintptr_t)p.residual) & 15) != 0)) return -1;
     if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return -1;
@@ -545,7 +549,7 @@ static int persistent_plan(int dtype, int mode, IgemmParams& p, int nz, long& to
     if (g_pers_cus == 0) return -1;
     const int gopt = option(E2EFT_OPT_PERSISTENT_GRID);   // tests: a small grid sends small problems through the persistent kernel
     if (gopt >= 8 && gopt < g_pers_cus) g_pers_cus = gopt;
-    const int mtiles = p.M / BM, ntiles = cdiv(p.N, BN);
+    const int mtiles = cdiv(p.M, BM), ntiles = cdiv(p.N, BN);
     const long total = (long)mtiles * ntiles * nz;
     if (4 * total < (long)option(E2EFT_OPT_PERSISTENT_MIN_QROUNDS) * g_pers_cus || total > 2000000000L || mtiles >= (1 << 22)) return -1;   // (tile / row splits use a float reciprocal: quotients below 2^22)
     p.mtiles = mtiles;

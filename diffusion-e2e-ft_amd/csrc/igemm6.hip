@@ -466,6 +466,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
     // ---- epilogues and statistics merge: shared with igemm5.hip; rows of a wave's 64-row block are two image rows of 32 pixels here.
     // Packed (no residual): rounds of 16 rows = half an image row; fp32 (residual): slices 4-7 = the wave's second image row.
     auto epi_rofs = [&](const int r) -> long { return (long)(r & 31) + (long)(r >> 5) * Wo; };
+    auto epi_rows_left = [&]() -> int { return 0x40000000; };      // (tiles are whole 8 x 32 blocks of one image)
     constexpr int EPI_DEP = OFF_DEP;
 #define EPI_STAMP(i) do { } while (0)
 #include "igemm_persistent_epilogue.inc"

@@ -552,7 +552,7 @@ def gemm(a, w, bias=None, residual=None, out=None, alpha=1.0, bias_along_m=False
     if residual is not None:
         assert tuple(residual.shape) == (M, N) and residual.dtype == a.dtype
     want = gn_rows_per_image > 0 and GN_STATS_ENABLED and N % 8 == 0 and M % gn_rows_per_image == 0 and not bias_along_m
-    if (F32_SPLIT_ENABLED and a.dtype == torch.float32 and not want and not bias_along_m and (alpha == 1.0 or bias is None) and K % 64 == 0 and M % 256 == 0 and N % 8 == 0 and w.is_contiguous()
+    if (F32_SPLIT_ENABLED and a.dtype == torch.float32 and not want and not bias_along_m and (alpha == 1.0 or bias is None) and K % 64 == 0 and M > 256 and N % 8 == 0 and w.is_contiguous()
             and a.data_ptr() % 16 == 0 and d.lda % 4 == 0 and out.data_ptr() % 16 == 0 and (residual is None or residual.data_ptr() % 16 == 0)
             and (bias is None or bias.data_ptr() % 16 == 0)):
         # fp32 nn.Linear of whole 256-row tiles: two-term f16 split planes on the f16 matrix pipe (csrc/f32split.hip; igemm5's GEMM mode)
@@ -1157,7 +1157,7 @@ def conv2d_dgrad(dy, w_dgrad, x_shape, c2, kh, kw, stride, pad, up_to, alpha):
     cin = c1 + c2
     assert w_dgrad.shape == (cin, kh * kw * cop) and w_dgrad.is_contiguous() and w_dgrad.dtype == dy.dtype
     label = "dgrad%dx%ds%d B%d %dx%d %d->%d" % (kh, kw, stride, B, hl, wl, cop, cin)
-    if (F32_SPLIT_ENABLED and dy.dtype == torch.float32 and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1) and up_to is None and c2 == 0 and cop % 64 == 0
+    if (F32_SPLIT_ENABLED and dy.dtype == torch.float32 and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1) and up_to is None and cop % 64 == 0
             and cin % 8 == 0):
         # the data gradient of a 3x3 / stride-1 / pad-1 convolution IS such a convolution of dY with the flipped, transposed weights: the f16-split route of conv2d
         dx = new_nhwc(B, hl, wl, cin, dy.dtype, dy.device)

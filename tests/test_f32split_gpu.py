@@ -61,6 +61,8 @@ cases = [
     (8, 8, 24, 128, 64, True, False, True, (3, 3, 1, 1), "igemm5"),        # 192 pixels per image: tiles straddle images, no statistics from the epilogue
     (2, 32, 64, 128, 128, True, False, False, (4, 4, 2, 1), "igemm5"),     # 4x4 / stride 2 / pad 1: the data gradient of an upsampler convolution (autograd.upconv_dgrad_weight)
     (2, 32, 64, 64, 192, False, False, False, (3, 3, 2, 1), "igemm5"),     # a stride-2 downsampler, ragged N tile
+    (5, 18, 18, 128, 128, True, True, False, (3, 3, 1, 1), "igemm5"),      # 1620 output pixels = 6.33 tiles: the ragged last tile's rows beyond M are zeroed on the way in and masked on the way out
+    (10, 9, 9, 192, 64, False, False, True, (3, 3, 1, 1), "igemm5"),       # 810 pixels: 3.16 tiles, 81 pixels per image
 ]
 for (B, H, W, Cc, Co, hb, rs, wide, (kh, kw, st, pd), kern) in cases:
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cc + Co + W + kh)
@@ -109,7 +111,7 @@ for (B, H, W, Cc, Co, hb, rs, wide, (kh, kw, st, pd), kern) in cases:
     worst = max(worst, e1 / max(e2, 1e-12))
 
 # ---- nn.Linear (e2eft_gemm_f32split, igemm5's GEMM mode): x W^T + b + residual against float64, beside the fp32 matrix instruction
-for (Mr, N, K, hb, rs) in [(1024, 320, 320, True, True), (2048, 1280, 64, False, False), (512, 640, 2560, True, False)]:
+for (Mr, N, K, hb, rs) in [(1024, 320, 320, True, True), (2048, 1280, 64, False, False), (512, 640, 2560, True, False), (1100, 320, 320, True, True), (1296, 1280, 1280, False, True)]:
     g = torch.Generator().manual_seed(Mr + N + K)
     a = torch.randn(Mr, K, generator=g) * torch.exp(torch.randn(Mr, K, generator=g))
     w = torch.randn(N, K, generator=g) / K ** 0.5
