@@ -380,7 +380,9 @@ def run_train(args, rank, world, dev):
             "median_ms_per_step": per_step[len(per_step) // 2], "min_ms_per_step": per_step[0], "max_ms_per_step": per_step[-1],
             "images_per_s": n_img / sec, "final_loss": float(loss), "peak_mem_gib": peak_mem,
             "config": {"workload": "E2E-FT training step (%s loss, UNet bwd) batch=%d/GPU (%d micro-steps x %d) at %dx%d, %s compute, fp32 master "
-                                   "weights + flat AdamW, %s%s" % (args.modality, mb * acc, acc, mb, R, R, args.dtype,
+                                   "weights + flat AdamW, %s%s" % (args.modality, mb * acc, acc, mb, R, R,
+                                                                                         args.dtype if args.dtype != "fp32" else "fp32 (fp32 tensors and accumulation; matrix products as exact two-term f16 splits on the f16 pipe "
+                                                                                         "where the shape allows — error <= the fp32 instruction's against float64, tests/test_f32split_gpu.py — else v_mfma_f32_32x32x2_f32)",
                                                                                          "per-block activation recompute (UNet + decoder)" if getattr(args, "grad_ckpt", False) else "no activation recompute",
                                                                                          " [TINY CONFIG - NOT A VALID BENCHMARK]" if args.tiny else ""),
                        "images_per_step": n_img, "resolution": R, "parallelism": "dp%d (RCCL all-reduce of the flat fp32 gradient, overlapped)" % world},
@@ -801,7 +803,7 @@ def main():
                     t = run_train(targs, 0, 1, dev)
                     line[key] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "median_ms_per_step", "min_ms_per_step", "max_ms_per_step", "images_per_s", "dtype", "steps", "warmup", "peak_mem_gib")}
                     line[key]["workload"] = t["config"]["workload"]
-                    line[key]["roofline"] = {k: t["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac")}
+                    line[key]["roofline"] = {k: t["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "pipes") if k in t["roofline"]}
                 except Exception as e:
                     line[key] = {"value": None, "error": repr(e)}
             _mark(timeline, "train legs end")
