@@ -58,7 +58,8 @@ __device__ __forceinline__ void split_scale(const unsigned amax_bits, float& s, 
 }
 
 // one thread: eight channels of one pixel -> one 16-byte unit of each plane
-__global__ __launch_bounds__(256) void split2_f16_kernel(long pixels, int c, int ldx, int ldp, const float* __restrict__ x, f16* __restrict__ planes,
+// (coff, ctot: this source's first column inside a plane and the plane's width — two sources side by side are the split of their channel concatenation)
+__global__ __launch_bounds__(256) void split2_f16_kernel(long pixels, int c, int ldx, int ldp, int coff, int ctot, const float* __restrict__ x, f16* __restrict__ planes,
                                                          const unsigned* __restrict__ amax_bits, float* __restrict__ scale_out) {
     float s, inv;
     split_scale(*amax_bits, s, inv);
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(256) void split2_f16_kernel(long pixels, int c, int
             p0.e[e] = h0;
             p1.e[e] = (f16)(t - (float)h0);             // exact difference, rounded once
         }
-        st16(planes + pix * ldp + ch, p0);
-        st16(planes + pix * ldp + c + ch, p1);
+        st16(planes + pix * ldp + coff + ch, p0);
+        st16(planes + pix * ldp + ctot + coff + ch, p1);
     }
 }
 
@@ -127,9 +128,36 @@ extern "C" int e2eft_f32_split2(const float* x, int64_t pixels, int32_t c, int32
     const long nbm = nb > 1024 ? 1024 : nb;          // the reduction: few atomics
     hipLaunchKernelGGL(absmax_f32_kernel, dim3((unsigned)nbm), dim3(256), 0, s, (long)pixels, c, ldx, x, reinterpret_cast<unsigned*>(scale));
     if (nb > 65536) nb = 65536;
-    hipLaunchKernelGGL(split2_f16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (long)pixels, c, ldx, ldp, x, (f16*)planes, reinterpret_cast<const unsigned*>(scale), scale);
+    hipLaunchKernelGGL(split2_f16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (long)pixels, c, ldx, ldp, 0, c, x, (f16*)planes, reinterpret_cast<const unsigned*>(scale), scale);
     tag_kernel("split2_f16_kernel");
     return check_launch("f32_split2");
+}
+
+// the channel concatenation [x1 (c1) | x2 (c2)] of two fp32 tensors as ONE pair of planes under ONE scale (the two-source convolutions of the UNet's up blocks:
+// unet_2d_blocks.py:2328,2456 `torch.cat([hidden_states, res_hidden_states], dim=1)`): planes [pixels][x1_0 | x2_0 | x1_1 | x2_1], ldp >= 2 (c1 + c2)
+extern "C" int e2eft_f32_split2_cat(const float* x1, int32_t c1, int32_t ldx1, const float* x2, int32_t c2, int32_t ldx2, int64_t pixels, void* planes, int32_t ldp,
+                                    float* scale, void* stream) {
+    E2EFT_REQUIRE(x1 && x2 && planes && scale && pixels > 0, "f32_split2_cat: null pointer / empty tensor");
+    E2EFT_REQUIRE(c1 > 0 && c1 % 8 == 0 && c2 > 0 && c2 % 8 == 0 && ldx1 >= c1 && ldx1 % 4 == 0 && ldx2 >= c2 && ldx2 % 4 == 0 && ldp >= 2 * (c1 + c2) && ldp % 8 == 0,
+                  "f32_split2_cat: c1=%d c2=%d ldx1=%d ldx2=%d ldp=%d", c1, c2, ldx1, ldx2, ldp);
+    E2EFT_REQUIRE(((uintptr_t)x1 & 15) == 0 && ((uintptr_t)x2 & 15) == 0 && ((uintptr_t)planes & 15) == 0 && ((uintptr_t)scale & 3) == 0, "f32_split2_cat: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(scale, 0, sizeof(float), s) != hipSuccess) return fail(E2EFT_ERR_LAUNCH, "f32_split2_cat: memset failed");
+    const float* xs[2] = {x1, x2};
+    const int cs[2] = {c1, c2}, lds[2] = {ldx1, ldx2};
+    for (int i = 0; i < 2; ++i) {      // one maximum over both sources
+        long nb = (pixels * (cs[i] / 8) + 255) / 256;
+        if (nb > 1024) nb = 1024;
+        hipLaunchKernelGGL(absmax_f32_kernel, dim3((unsigned)nb), dim3(256), 0, s, (long)pixels, cs[i], lds[i], xs[i], reinterpret_cast<unsigned*>(scale));
+    }
+    for (int i = 0; i < 2; ++i) {
+        long nb = (pixels * (cs[i] / 8) + 255) / 256;
+        if (nb > 65536) nb = 65536;
+        hipLaunchKernelGGL(split2_f16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (long)pixels, cs[i], lds[i], ldp, i ? c1 : 0, c1 + c2, xs[i], (f16*)planes,
+                           reinterpret_cast<const unsigned*>(scale), scale);
+    }
+    tag_kernel("split2_f16_kernel");
+    return check_launch("f32_split2_cat");
 }
 
 // pure host arithmetic: would e2eft_conv2d_fwd_f32split take this launch (with 16-byte aligned pointers)?  desc: dtype E2EFT_F32, c1 = channels of the fp32

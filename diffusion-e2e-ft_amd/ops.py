@@ -250,14 +250,22 @@ F32_SPLIT_ENABLED = True      # tests / A-B: False keeps fp32 convolutions / GEM
 WGRAD_F32_SPLIT = True        # tests / A-B: False keeps fp32 weight gradients on wgrad32_kernel (v_mfma_f32_32x32x2_f32)
 
 
-def f32_split2(x, keep=False):
+def f32_split2(x, keep=False, x2=None):
     """fp32 NHWC [B,H,W,C] (C % 8 == 0) -> (planes f16 [B,H,W,2C] = [x0 | x1] with x * s = x0 + x1 to 2^-22, scale workspace fp32 [4]: [1] = s, [2] = 1 / s).
     s is the power of two that brings the tensor's maximum into [2^14, 2^15), found on the device (csrc/f32split.hip).
     keep: park the result on the tensor object (per version) — a gradient dY is split once for its data-gradient convolution AND its weight-gradient launches; only for
-    short-lived tensors (the planes live as long as x does)."""
-    _check_cuda(x)
+    short-lived tensors (the planes live as long as x does).  x2: a second source — the planes are then those of cat(x, x2) along the channels, under one scale."""
+    _check_cuda(x, x2)
     B, H, W, Cc = x.shape
     assert x.dtype == torch.float32 and Cc % 8 == 0
+    if x2 is not None:
+        c2 = x2.shape[3]
+        assert tuple(x2.shape[:3]) == (B, H, W) and x2.dtype == torch.float32 and c2 % 8 == 0 and not keep
+        planes = torch.empty((B, H, W, 2 * (Cc + c2)), dtype=torch.float16, device=x.device)
+        scale = torch.empty(4, dtype=torch.float32, device=x.device)
+        with _timed("f32split", 0.0, 12.0 * B * H * W * (Cc + c2), label="split2 B%d %dx%d C%d+%d" % (B, H, W, Cc, c2), launches=4):
+            check(_lib.load().e2eft_f32_split2_cat(_ptr(x), Cc, _nhwc_ld(x), _ptr(x2), c2, _nhwc_ld(x2), B * H * W, _ptr(planes), 2 * (Cc + c2), _ptr(scale), _stream()))
+        return planes, scale
     if keep:
         ent = getattr(x, "_e2eft_planes", None)
         if ent is not None and ent[0] == x._version:
@@ -360,10 +368,12 @@ def groupnorm_fwd_split_ws(x, gamma, beta, groups, eps, silu=False, s1=None):
     return planes, inv, ws
 
 
-def _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label, planes=None, inv_scale=None, geom=(3, 3, 1, (1, 1, 1, 1)), keep_planes=False):
+def _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label, planes=None, inv_scale=None, geom=(3, 3, 1, (1, 1, 1, 1)), keep_planes=False, x2=None):
     """An fp32 convolution (geom = kh, kw, stride, pads; one source, no fused upsample) through e2eft_conv2d_fwd_f32split, or None when the library declines the
     shape.  planes / inv_scale: the input already split (groupnorm_fwd_split_ws) — x is then ignored."""
     B, H, W, c1 = x.shape if planes is None else (planes.shape[0], planes.shape[1], planes.shape[2], planes.shape[3] // 2)
+    if x2 is not None:          # two sources: the convolution of their channel concatenation (one pair of planes, one scale)
+        c1 = c1 + x2.shape[3]
     kh, kw, stride, pad = geom
     d = _f32split_desc(B, H, W, c1, cout, kh, kw, stride, pad, _nhwc_ld(out), _nhwc_ld(residual) if residual is not None else 0)
     assert (d.hout, d.wout) == (out.shape[1], out.shape[2])
@@ -371,13 +381,14 @@ def _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label,
     d.alpha = alpha
     lib = _lib.load()
     if (lib.e2eft_conv2d_fwd_f32split_supported(C.byref(d)) != 1 or out.data_ptr() % 16 or (residual is not None and residual.data_ptr() % 16)
-            or (bias is not None and bias.data_ptr() % 16) or not w_packed.is_contiguous() or (planes is None and (x.data_ptr() % 16 or _nhwc_ld(x) % 4))):
+            or (bias is not None and bias.data_ptr() % 16) or not w_packed.is_contiguous() or (planes is None and (x.data_ptr() % 16 or _nhwc_ld(x) % 4))
+            or (x2 is not None and (x2.data_ptr() % 16 or _nhwc_ld(x2) % 4 or x2.shape[3] % 8 or x.shape[3] % 8))):
         return None
     wsp, inv_sw = f32_split_weight(w_packed, kh * kw, c1)
     d.alpha = alpha
     scale = None
     if planes is None:
-        planes, scale = f32_split2(x, keep=keep_planes)
+        planes, scale = f32_split2(x, keep=keep_planes, x2=x2)
     else:
         d.alpha = d.alpha * inv_scale
     nb = (planes.numel() * 2 + B * H * W * cout * 4 * (2 if residual is not None else 1) + cout * kh * kw * 3 * c1 * 2)
@@ -498,10 +509,10 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
             x2 = None
             d.c1, d.ldx1, d.c2, d.ldx2 = x.shape[3], _nhwc_ld(x), 0, 0
     label = _label or "conv%dx%ds%d%s%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", "n" if coeff is not None else "", B, hout, wout, d.c1 + d.c2, cout)
-    if (F32_SPLIT_ENABLED and x.dtype == torch.float32 and coeff is None and not sk and x2 is None and up_to is None and rowadd is None and kh * kw > 1
+    if (F32_SPLIT_ENABLED and x.dtype == torch.float32 and coeff is None and not sk and up_to is None and rowadd is None
             and (alpha == 1.0 or bias is None)
-            and x.shape[3] % 64 == 0 and w_packed.shape[1] == kh * kw * x.shape[3]):
-        r = _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label, geom=(kh, kw, stride, tuple(pad)))
+            and (d.c1 + d.c2) % 64 == 0 and w_packed.shape[1] == kh * kw * (d.c1 + d.c2)):
+        r = _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label, geom=(kh, kw, stride, tuple(pad)), x2=x2)
         if r is not None:
             return r
     with _timed("igemm", 2.0 * B * hout * wout * cout * kh * kw * (d.c1 + d.c2), nb, label=label):
@@ -1066,13 +1077,15 @@ def conv2d_wgrad(dy, x, x2, cout, kh, kw, stride, pad, alpha, out=None):
     if not WGRAD_DIRECT or (dy.dtype == torch.float32 and not WGRAD_DIRECT_FP32):
         return None
     _check_cuda(dy, x, x2)
-    if (dy.dtype == torch.float32 and F32_SPLIT_ENABLED and WGRAD_F32_SPLIT and x2 is None and x.shape[3] % 64 == 0 and cout % 64 == 0 and dy.shape[3] % 8 == 0
-            and _lib.load().e2eft_get_option(_lib.OPT_F32_SPLIT) == 1 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
+    cin_all = x.shape[3] + (x2.shape[3] if x2 is not None else 0)
+    if (dy.dtype == torch.float32 and F32_SPLIT_ENABLED and WGRAD_F32_SPLIT and cin_all % 64 == 0 and x.shape[3] % 8 == 0 and cout % 64 == 0 and dy.shape[3] % 8 == 0
+            and _lib.load().e2eft_get_option(_lib.OPT_F32_SPLIT) == 1 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+            and (x2 is None or (x2.shape[3] % 8 == 0 and x2.data_ptr() % 16 == 0))):
         # fp32 on the f16 matrix pipe (csrc/f32split.hip): dy s_dy = d0 + d1, x s_x = x0 + x1 (two-term f16 splits, exact to 2^-22); the gradient is the sum of the
         # 16-bit kernel's results for (d0, x0), (d0, x1), (d1, x0), scaled back by the two device scalars — three launches at the f16 rate instead of one at the fp32 rate
         dyp, sdy = f32_split2(dy, keep=True)          # (the data-gradient convolution of the same dY has usually split it already: autograd._Conv2dFn.backward)
-        xp, sx = f32_split2(x)
-        c0, c1 = dy.shape[3], x.shape[3]
+        xp, sx = f32_split2(x, x2=x2)                 # (two sources: the planes of their concatenation — the 16-bit kernel then sees ONE source of c1 + c2 channels)
+        c0, c1 = dy.shape[3], cin_all
         r = None
         for (a_, b_) in ((dyp[..., :c0], xp[..., :c1]), (dyp[..., :c0], xp[..., c1:]), (dyp[..., c0:], xp[..., :c1])):
             t = conv2d_wgrad(a_, b_, None, cout, kh, kw, stride, pad, alpha)
@@ -1157,11 +1170,11 @@ def conv2d_dgrad(dy, w_dgrad, x_shape, c2, kh, kw, stride, pad, up_to, alpha):
     cin = c1 + c2
     assert w_dgrad.shape == (cin, kh * kw * cop) and w_dgrad.is_contiguous() and w_dgrad.dtype == dy.dtype
     label = "dgrad%dx%ds%d B%d %dx%d %d->%d" % (kh, kw, stride, B, hl, wl, cop, cin)
-    if (F32_SPLIT_ENABLED and dy.dtype == torch.float32 and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1) and up_to is None and cop % 64 == 0
-            and cin % 8 == 0):
-        # the data gradient of a 3x3 / stride-1 / pad-1 convolution IS such a convolution of dY with the flipped, transposed weights: the f16-split route of conv2d
+    if (F32_SPLIT_ENABLED and dy.dtype == torch.float32 and ((kh, kw, stride, tuple(pad)) == (3, 3, 1, (1, 1, 1, 1)) or (kh, kw, stride, tuple(pad)) == (1, 1, 1, (0, 0, 0, 0)))
+            and up_to is None and cop % 64 == 0 and cin % 8 == 0):
+        # the data gradient of a 3x3 / stride-1 / pad-1 (or 1x1) convolution IS such a convolution of dY with the flipped, transposed weights: the f16-split route of conv2d
         dx = new_nhwc(B, hl, wl, cin, dy.dtype, dy.device)
-        if _conv2d_f32split(dy, w_dgrad, None, cin, None, alpha, dx, False, label, keep_planes=True) is not None:
+        if _conv2d_f32split(dy, w_dgrad, None, cin, None, alpha, dx, False, label, keep_planes=True, geom=(kh, kw, 1, tuple(pad))) is not None:
             return dx
     else:
         dx = new_nhwc(B, hl, wl, cin, dy.dtype, dy.device)

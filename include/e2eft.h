@@ -179,6 +179,9 @@ int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const void* w_phas
  *     the fp32 output).  Ask e2eft_conv2d_fwd_f32split_supported first (pure host arithmetic; E2EFT_OPT_F32_SPLIT = 0 makes it answer 0); E2EFT_ERR_UNSUPPORTED otherwise.
  *     The data gradient of such a convolution is the same call on dY with the flipped, transposed weights (e2eft_conv2d_dgrad's w_dgrad) split the same way. */
 int e2eft_f32_split2(const float* x, int64_t pixels, int32_t c, int32_t ldx, void* planes, int32_t ldp, float* scale, void* stream);
+/* the channel concatenation [x1 (c1) | x2 (c2)] as one pair of planes under one scale: planes [pixels][x1_0 | x2_0 | x1_1 | x2_1] (the UNet's two-source convolutions) */
+int e2eft_f32_split2_cat(const float* x1, int32_t c1, int32_t ldx1, const float* x2, int32_t c2, int32_t ldx2, int64_t pixels, void* planes, int32_t ldp,
+                         float* scale, void* stream);
 int e2eft_conv2d_fwd_f32split_supported(const E2eftConvDesc* d);
 int e2eft_conv2d_fwd_f32split(const E2eftConvDesc* d, const void* planes, const float* scale, const void* w_split, const float* w_inv_scale, const float* bias,
                               const float* residual, float* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* stream);

@@ -61,6 +61,7 @@ cases = [
     (8, 8, 24, 128, 64, True, False, True, (3, 3, 1, 1), "igemm5"),        # 192 pixels per image: tiles straddle images, no statistics from the epilogue
     (2, 32, 64, 128, 128, True, False, False, (4, 4, 2, 1), "igemm5"),     # 4x4 / stride 2 / pad 1: the data gradient of an upsampler convolution (autograd.upconv_dgrad_weight)
     (2, 32, 64, 64, 192, False, False, False, (3, 3, 2, 1), "igemm5"),     # a stride-2 downsampler, ragged N tile
+    (2, 32, 32, 256, 128, True, False, False, (1, 1, 1, 0), "igemm5"),     # a 1x1 shortcut convolution (K = 3 C: three k-tiles per 64 channels)
     (5, 18, 18, 128, 128, True, True, False, (3, 3, 1, 1), "igemm5"),      # 1620 output pixels = 6.33 tiles: the ragged last tile's rows beyond M are zeroed on the way in and masked on the way out
     (10, 9, 9, 192, 64, False, False, True, (3, 3, 1, 1), "igemm5"),       # 810 pixels: 3.16 tiles, 81 pixels per image
 ]
@@ -109,6 +110,36 @@ for (B, H, W, Cc, Co, hb, rs, wide, (kh, kw, st, pd), kern) in cases:
     assert e1 <= max(1.5 * e2, 4e-7), (e1, e2)
     assert rms1 <= max(1.5 * rms2, 5e-8), (rms1, rms2)
     worst = max(worst, e1 / max(e2, 1e-12))
+
+# ---- two sources (the UNet's up blocks: conv(cat(h, skip))): one pair of planes under one scale (e2eft_f32_split2_cat); forward and weight gradient
+g = torch.Generator().manual_seed(23)
+B, H, W, C1, C2, Co = 2, 16, 32, 128, 64, 128
+xa = torch.randn(B, C1, H, W, generator=g) * 2.0
+xb = torch.randn(B, C2, H, W, generator=g) * 0.01           # a skip tensor three decades below its partner: the common scale must not cost it its bits
+w = torch.randn(Co, C1 + C2, 3, 3, generator=g) / ((C1 + C2) * 9) ** 0.5
+gy = torch.randn(B, Co, H, W, generator=g)
+xcat = torch.cat([xa, xb], 1).double()
+w64 = w.double().requires_grad_(True)
+y64 = F.conv2d(xcat, w64, None, padding=1)
+y64.backward(gy.double())
+refw = w64.grad.permute(0, 2, 3, 1).reshape(Co, -1)
+xad, xbd, wd, gd = nhwc(xa, torch.float32, dev), nhwc(xb, torch.float32, dev), pack_conv_weight(w, torch.float32, dev), nhwc(gy, torch.float32, dev)
+res2 = {}
+for on in (True, False):
+    ops.F32_SPLIT_ENABLED = on
+    y = ops.conv2d(xad, wd, None, Co, 3, 3, 1, (1, 1, 1, 1), x2=xbd)
+    torch.cuda.synchronize()
+    assert ("f32split" in lib.e2eft_debug_last_kernel().decode()) == on, lib.e2eft_debug_last_kernel()
+    dw = ops.conv2d_wgrad(gd, xad, xbd, Co, 3, 3, 1, (1, 1, 1, 1), 1.0)
+    torch.cuda.synchronize()
+    res2[on] = (to_nchw(y).double(), dw.double().cpu())
+ops.F32_SPLIT_ENABLED = True
+e1, e2 = rel_err(res2[True][0], y64.detach()), rel_err(res2[False][0], y64.detach())
+w1, w2 = rel_err(res2[True][1], refw), rel_err(res2[False][1], refw)
+# the small source's own contribution: the columns of dW that multiply xb
+s1, s2 = rel_err(res2[True][1].view(Co, 9, C1 + C2)[..., C1:], refw.view(Co, 9, C1 + C2)[..., C1:]), rel_err(res2[False][1].view(Co, 9, C1 + C2)[..., C1:], refw.view(Co, 9, C1 + C2)[..., C1:])
+print("two sources: forward %%.3e (fp32 MFMA %%.3e), weight gradient %%.3e (%%.3e), its columns of the small source %%.3e (%%.3e)" %% (e1, e2, w1, w2, s1, s2), flush=True)
+assert e1 <= max(1.5 * e2, 4e-7) and w1 <= max(1.5 * w2, 4e-7) and s1 <= max(1.5 * s2, 6e-7), (e1, e2, w1, w2, s1, s2)
 
 # ---- nn.Linear (e2eft_gemm_f32split, igemm5's GEMM mode): x W^T + b + residual against float64, beside the fp32 matrix instruction
 for (Mr, N, K, hb, rs) in [(1024, 320, 320, True, True), (2048, 1280, 64, False, False), (512, 640, 2560, True, False), (1100, 320, 320, True, True), (1296, 1280, 1280, False, True)]:
