@@ -582,12 +582,12 @@ class _NormConvSplitFn(torch.autograd.Function):
         dt = x.dtype
         B, H, W, c1 = x.shape
         cout = conv.weight.shape[0]
-        planes, inv, ws = ops.groupnorm_fwd_split_ws(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, s1=s1)
+        planes, pscale, ws = ops.groupnorm_fwd_split_ws(x, _vec(gamma, dt), _vec(beta, dt), groups, eps, silu=silu, s1=s1)
         out = ops.new_nhwc(B, H, W, cout, dt, x.device)
         if residual is not None:
             assert tuple(residual.shape) == tuple(out.shape) and residual.dtype == dt
         r = ops._conv2d_f32split(None, packed_conv_weight(conv, dt), _vec(conv.bias, dt), cout, residual, 1.0, out, gn_stats and ops.GN_STATS_ENABLED and cout % 8 == 0,
-                                 "conv3x3s1n B%d %dx%d %d->%d" % (B, H, W, c1, cout), planes=planes, inv_scale=inv)
+                                 "conv3x3s1n B%d %dx%d %d->%d" % (B, H, W, c1, cout), planes=planes, scale=pscale)
         assert r is not None, "norm_conv_split: the library declined a shape ops.f32split_shape_ok accepted"
         _stash_stats(out)
         ctx.save_for_backward(x, gamma, beta, ws)

@@ -221,12 +221,41 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnGeom g, int silu, int l
     }
 }
 
-// fp32 GroupNorm(+SiLU) whose output leaves as the two-term f16 split of csrc/f32split.hip: planes [pixel][y0 (C) | y1 (C)] with y * s = y0 + y1, s a power of two the
-// HOST chose from a bound of the output (|SiLU(t)| <= |t| <= max|gamma| * sqrt(elements per group) + max|beta|: the normalised value of one element of n is at most
+// fp32 GroupNorm(+SiLU) whose output leaves as the two-term f16 split of csrc/f32split.hip: planes [pixel][y0 (C) | y1 (C)] with y * s = y0 + y1, s a power of two
+// derived (gn_split_scale_kernel below) from a bound of the output (|SiLU(t)| <= |t| <= max|gamma| * sqrt(elements per group) + max|beta|: the normalised value of one element of n is at most
 // sqrt(n - 1)) — no maximum pass, and the consumer (e2eft_conv2d_fwd_f32split) never sees the fp32 tensor: 4 + 4 bytes per element like the plain apply pass.
 // The conversions saturate (a bound that generous costs nothing: values 2^17 below it still carry 22 bits).  grid as gn_apply_kernel, one source.
-__global__ __launch_bounds__(256) void gn_apply_split_kernel(GnGeom g, int silu, int ldp, float s, const float* __restrict__ x1, const float* __restrict__ ad,
+// the scale of the planes from a bound of the output, on the device (one workgroup; no host read of the parameters — they may be training, and a captured graph
+// cannot wait for the host): bound = max|gamma| * sqrt(n) + max|beta| -> s = 2^k with bound * s in [2^14, 2^15); scale[1] = s, scale[2] = 1 / s
+__global__ __launch_bounds__(256) void gn_split_scale_kernel(int C, float sqrt_n, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale) {
+    float mg = gamma ? 0.f : 1.f, mb = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        if (gamma) mg = fmaxf(mg, fabsf(gamma[c]));
+        if (beta) mb = fmaxf(mb, fabsf(beta[c]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mg = fmaxf(mg, __shfl_xor(mg, o, 64)); mb = fmaxf(mb, __shfl_xor(mb, o, 64)); }
+    __shared__ float sg[4], sb[4];
+    if ((threadIdx.x & 63) == 0) { sg[threadIdx.x >> 6] = mg; sb[threadIdx.x >> 6] = mb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mg = fmaxf(fmaxf(sg[0], sg[1]), fmaxf(sg[2], sg[3]));
+        mb = fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3]));
+        const float bound = mg * sqrt_n + mb;
+        const unsigned bits = __float_as_uint(bound);
+        const int ex = (int)((bits >> 23) & 0xffu);
+        int k = 0;
+        if (bound > 0.f && ex != 0xff) k = 14 - (ex == 0 ? -126 : ex - 127);      // bound in [2^(ex-127), 2^(ex-126)) -> bound * 2^k in [2^14, 2^15)
+        k = k > 100 ? 100 : k < -100 ? -100 : k;
+        scale[0] = bound;
+        scale[1] = __uint_as_float((unsigned)(127 + k) << 23);
+        scale[2] = __uint_as_float((unsigned)(127 - k) << 23);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_split_kernel(GnGeom g, int silu, int ldp, const float* __restrict__ scale, const float* __restrict__ x1, const float* __restrict__ ad,
                                                              const float* __restrict__ beta, f16* __restrict__ planes) {
+    const float s = scale[1];
     const int tid = threadIdx.x;
     const int chl = tid % g.cpb, pl = tid / g.cpb;
     if (pl >= g.pl) return;
@@ -894,13 +923,14 @@ extern "C" int e2eft_groupnorm_fwd_stats(const E2eftGroupNormDesc* d, const void
 
 // fp32 GroupNorm(+SiLU) -> f16 split planes (csrc/f32split.hip): the statistics exactly as e2eft_groupnorm_fwd_stats (the workspace afterwards is what
 // e2eft_groupnorm_bwd expects), then gn_apply_split_kernel
-extern "C" int e2eft_groupnorm_fwd_split(const E2eftGroupNormDesc* d, const float* x, const float* gamma, const float* beta, void* planes, int32_t ldp, float scale,
+extern "C" int e2eft_groupnorm_fwd_split(const E2eftGroupNormDesc* d, const float* x, const float* gamma, const float* beta, void* planes, int32_t ldp, float* scale,
                                          const float* partial1, int32_t nslabs1, void* workspace, size_t ws_bytes, void* stream) {
     E2EFT_REQUIRE(d && d->dtype == E2EFT_F32 && d->c2 == 0, "groupnorm_fwd_split: one fp32 source");
     E2EFT_REQUIRE(planes && ldp >= 2 * d->c1 && ldp % 4 == 0 && ((uintptr_t)planes & 7) == 0 && d->c1 % 4 == 0, "groupnorm_fwd_split: planes ldp=%d", (int)ldp);
-    E2EFT_REQUIRE(scale > 0.f && scale < 3.0e38f, "groupnorm_fwd_split: scale");
+    E2EFT_REQUIRE(scale && ((uintptr_t)scale & 3) == 0, "groupnorm_fwd_split: scale workspace");
     const int rc = e2eft_groupnorm_fwd_stats(d, x, nullptr, gamma, partial1, nslabs1, nullptr, 0, workspace, ws_bytes, stream);
     if (rc) return rc;
+    hipLaunchKernelGGL(gn_split_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d->c1, sqrtf((float)d->hw * (float)(d->c1 / d->groups)), gamma, beta, scale);
     GnGeom g;
     gn_geom(d, g);
     const float* ad = (const float*)((const char*)workspace + e2eft_groupnorm_coeff_offset(d));
@@ -908,7 +938,7 @@ extern "C" int e2eft_groupnorm_fwd_split(const E2eftGroupNormDesc* d, const floa
     const int it = option(E2EFT_OPT_GN_APPLY_ITERS);
     g.slab = g.pl * 4 * (it > 0 ? it : (tensor_bytes <= (128L << 20) ? 4 : 2));
     g.nslabs = (d->hw + g.slab - 1) / g.slab;
-    hipLaunchKernelGGL(gn_apply_split_kernel, dim3(g.nslabs, g.batch, g.nchb), dim3(256), 0, (hipStream_t)stream, g, d->silu, (int)ldp, scale, x, ad, beta, (f16*)planes);
+    hipLaunchKernelGGL(gn_apply_split_kernel, dim3(g.nslabs, g.batch, g.nchb), dim3(256), 0, (hipStream_t)stream, g, d->silu, (int)ldp, (const float*)scale, x, ad, beta, (f16*)planes);
     return check_launch("groupnorm_fwd_split");
 }
 

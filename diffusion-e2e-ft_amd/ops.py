@@ -302,26 +302,6 @@ def f32_split_weight(w_packed, taps, c):
     return wsp, inv
 
 
-def _pow2_scale(bound):
-    """power of two s with bound * s in [2^14, 2^15) (1.0 for 0 / non-finite bounds), and 1 / s"""
-    import math
-    if bound == 0.0 or not math.isfinite(bound):
-        return 1.0, 1.0
-    k = max(-100, min(100, 15 - math.frexp(bound)[1]))
-    return 2.0 ** k, 2.0 ** (-k)
-
-
-def _absmax_cached(t):
-    """max |t| of a parameter-like tensor as a host float, cached on the tensor object per version (one host read per parameter version)"""
-    if t is None:
-        return 0.0
-    ent = getattr(t, "_e2eft_absmax", None)
-    if ent is None or ent[0] != t._version:
-        ent = (t._version, float(t.detach().abs().max()))
-        t._e2eft_absmax = ent
-    return ent[1]
-
-
 def _f32split_desc(B, H, W, c1, cout, kh, kw, stride, pad, ldo, ldr):
     pt, pb, pl, pr = pad
     d = ConvDesc()
@@ -345,15 +325,14 @@ def f32split_shape_ok(B, H, W, c1, cout, kh=3, kw=3, stride=1, pad=(1, 1, 1, 1))
 
 
 def groupnorm_fwd_split_ws(x, gamma, beta, groups, eps, silu=False, s1=None):
-    """fp32 GroupNorm(+SiLU) of x [B,H,W,C] whose output leaves as f16 split planes (e2eft_groupnorm_fwd_split) -> (planes [B,H,W,2C], 1 / scale, workspace for
-    groupnorm_bwd).  The scale is a host constant from a bound of the output: |y| <= max|gamma| * sqrt(H W C / groups) + max|beta|."""
+    """fp32 GroupNorm(+SiLU) of x [B,H,W,C] whose output leaves as f16 split planes (e2eft_groupnorm_fwd_split) -> (planes [B,H,W,2C], scale workspace [4] for the
+    consuming convolution, workspace for groupnorm_bwd).  The scale comes from a bound of the output, |y| <= max|gamma| * sqrt(H W C / groups) + max|beta|, computed
+    on the device: no host read of the parameters, no pass over the data."""
     _check_cuda(x, gamma, beta)
     B, H, W, c1 = x.shape
     assert x.dtype == torch.float32
-    import math
-    bound = _absmax_cached(gamma) * math.sqrt(float(H * W * (c1 // groups))) + _absmax_cached(beta) if gamma is not None else math.sqrt(float(H * W * (c1 // groups)))
-    sc, inv = _pow2_scale(bound)
     planes = torch.empty((B, H, W, 2 * c1), dtype=torch.float16, device=x.device)
+    scale = torch.empty(4, dtype=torch.float32, device=x.device)
     d = _gn_desc(x, None, groups, eps, silu, c1)
     lib = _lib.load()
     nbytes = lib.e2eft_groupnorm_workspace_bytes(C.byref(d))
@@ -363,14 +342,14 @@ def groupnorm_fwd_split_ws(x, gamma, beta, groups, eps, silu=False, s1=None):
     if not GN_STATS_ENABLED:
         s1 = None
     with _timed("groupnorm", 0.0, 2.0 * B * H * W * c1 * 4, label="gn->split B%d %dx%d C%d" % (B, H, W, c1)):
-        check(lib.e2eft_groupnorm_fwd_split(C.byref(d), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(planes), 2 * c1, sc, _ptr(s1.partial) if s1 else C.c_void_p(0),
+        check(lib.e2eft_groupnorm_fwd_split(C.byref(d), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(planes), 2 * c1, _ptr(scale), _ptr(s1.partial) if s1 else C.c_void_p(0),
                                             s1.nslabs if s1 else 0, _ptr(ws), nbytes, _stream()))
-    return planes, inv, ws
+    return planes, scale, ws
 
 
-def _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label, planes=None, inv_scale=None, geom=(3, 3, 1, (1, 1, 1, 1)), keep_planes=False, x2=None):
-    """An fp32 convolution (geom = kh, kw, stride, pads; one source, no fused upsample) through e2eft_conv2d_fwd_f32split, or None when the library declines the
-    shape.  planes / inv_scale: the input already split (groupnorm_fwd_split_ws) — x is then ignored."""
+def _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label, planes=None, scale=None, geom=(3, 3, 1, (1, 1, 1, 1)), keep_planes=False, x2=None):
+    """An fp32 convolution (geom = kh, kw, stride, pads; no fused upsample) through e2eft_conv2d_fwd_f32split, or None when the library declines the
+    shape.  planes / scale: the input already split (groupnorm_fwd_split_ws) — x is then ignored."""
     B, H, W, c1 = x.shape if planes is None else (planes.shape[0], planes.shape[1], planes.shape[2], planes.shape[3] // 2)
     if x2 is not None:          # two sources: the convolution of their channel concatenation (one pair of planes, one scale)
         c1 = c1 + x2.shape[3]
@@ -386,11 +365,9 @@ def _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label,
         return None
     wsp, inv_sw = f32_split_weight(w_packed, kh * kw, c1)
     d.alpha = alpha
-    scale = None
     if planes is None:
         planes, scale = f32_split2(x, keep=keep_planes, x2=x2)
-    else:
-        d.alpha = d.alpha * inv_scale
+    assert scale is not None
     nb = (planes.numel() * 2 + B * H * W * cout * 4 * (2 if residual is not None else 1) + cout * kh * kw * 3 * c1 * 2)
     # (flops: what the f16 pipe multiplies — three products per fp32 product; flops_nominal: the fp32 convolution)
     with _timed("igemm", 6.0 * B * H * W * cout * kh * kw * c1, nb, label=label + " f32split", flops_nominal=2.0 * B * H * W * cout * kh * kw * c1):
@@ -498,9 +475,9 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
               and (alpha == 1.0 or bias is None)
               and w_packed.shape[1] == 9 * c1 and f32split_shape_ok(B, H, W, c1, cout)):
             # fp32: the norm's apply pass writes the f16 split planes the convolution reads (csrc/f32split.hip) — no fp32 intermediate, no maximum pass
-            planes, inv, _ = groupnorm_fwd_split_ws(x, gamma, beta, groups, eps, silu=silu, s1=getattr(x, "_e2eft_gn", None))
+            planes, pscale, _ = groupnorm_fwd_split_ws(x, gamma, beta, groups, eps, silu=silu, s1=getattr(x, "_e2eft_gn", None))
             r = _conv2d_f32split(None, w_packed, bias, cout, residual, alpha, out, want,
-                                 "conv3x3s1n B%d %dx%d %d->%d" % (B, hout, wout, c1, cout), planes=planes, inv_scale=inv)
+                                 "conv3x3s1n B%d %dx%d %d->%d" % (B, hout, wout, c1, cout), planes=planes, scale=pscale)
             if r is not None:
                 return r
             x = groupnorm(x, gamma, beta, groups, eps, silu=silu)

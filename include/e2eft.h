@@ -175,7 +175,7 @@ int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const void* w_phas
  *     e2eft_conv2d_fwd with one source and no fused upsample (c2 = 0, hl = hin, wl = win), c1 = c (% 64 == 0), ldx1 = ldp (f16 elements), ldw = row length of w_split in
  *     f16 elements (>= kh kw 3 c), ldo / ldr in fp32 elements.  3x3 / stride 1 / pads 1 on a width % 32 == 0, height % 8 == 0 grid runs on the halo-patch kernel
  *     (igemm6), everything else in whole 256-row tiles on igemm5.  w_split: f16 [cout][kh][kw][w0 (c) | w1 (c) | w0 (c)] with w s_w = w0 + w1 built once per weight
- *     version by the caller (power-of-two s_w); w_inv_scale: device scalar 1 / s_w, or null when alpha already carries it.  scale: the workspace e2eft_f32_split2 filled for these planes, or null when the planes' scale is already folded into alpha (e2eft_groupnorm_fwd_split).  gn_partial / slab_rows as e2eft_conv2d_fwd_gnstats (statistics of
+ *     version by the caller (power-of-two s_w); w_inv_scale: device scalar 1 / s_w, or null when alpha already carries it.  scale: the workspace e2eft_f32_split2 / e2eft_groupnorm_fwd_split filled for these planes (null: the planes' scale is already folded into alpha).  gn_partial / slab_rows as e2eft_conv2d_fwd_gnstats (statistics of
  *     the fp32 output).  Ask e2eft_conv2d_fwd_f32split_supported first (pure host arithmetic; E2EFT_OPT_F32_SPLIT = 0 makes it answer 0); E2EFT_ERR_UNSUPPORTED otherwise.
  *     The data gradient of such a convolution is the same call on dY with the flipped, transposed weights (e2eft_conv2d_dgrad's w_dgrad) split the same way. */
 int e2eft_f32_split2(const float* x, int64_t pixels, int32_t c, int32_t ldx, void* planes, int32_t ldp, float* scale, void* stream);
@@ -230,11 +230,12 @@ size_t e2eft_groupnorm_workspace_bytes(const E2eftGroupNormDesc* d);
 int e2eft_groupnorm_fwd(const E2eftGroupNormDesc* d, const void* x1, const void* x2, const void* gamma,
                         const void* beta, void* y, void* workspace, size_t ws_bytes, void* stream);
 
-/* fp32 GroupNorm(+SiLU) whose result leaves as split planes for e2eft_conv2d_fwd_f32split (one source, d->dtype E2EFT_F32): y * scale = y0 + y1.  `scale` is a power of
- * two chosen by the HOST so that scale * (max|gamma| * sqrt(hw * channels per group) + max|beta|) < 2^15 — a bound of |y| that needs no pass over the data (a normalised
- * value among n is at most sqrt(n - 1), |SiLU(t)| <= |t|); conversions saturate.  The consumer passes 1 / scale inside its alpha and a null `scale` workspace.
+/* fp32 GroupNorm(+SiLU) whose result leaves as split planes for e2eft_conv2d_fwd_f32split (one source, d->dtype E2EFT_F32): y * s = y0 + y1.  s is the power of two
+ * with s * (max|gamma| * sqrt(hw * channels per group) + max|beta|) in [2^14, 2^15) — a bound of |y| that needs no pass over the data (a normalised value among n is
+ * at most sqrt(n - 1), |SiLU(t)| <= |t|); it is computed ON THE DEVICE from the parameters (they may be training; no host read), conversions saturate.  `scale`: three
+ * device floats of workspace, on return scale[1] = s, scale[2] = 1 / s — the `scale` argument of the consuming e2eft_conv2d_fwd_f32split.
  * partial1 / nslabs1 / workspace as e2eft_groupnorm_fwd_pre; afterwards the workspace serves e2eft_groupnorm_bwd like the plain forward's. */
-int e2eft_groupnorm_fwd_split(const E2eftGroupNormDesc* d, const float* x, const float* gamma, const float* beta, void* planes, int32_t ldp, float scale,
+int e2eft_groupnorm_fwd_split(const E2eftGroupNormDesc* d, const float* x, const float* gamma, const float* beta, void* planes, int32_t ldp, float* scale,
                               const float* partial1, int32_t nslabs1, void* workspace, size_t ws_bytes, void* stream);
 
 /* GroupNorm whose statistics pass was (partly) done by the producer (e2eft_*_gnstats): partialK / nslabsK describe source K
