@@ -242,6 +242,65 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(t1) : "v"(ta), "n"(NORM_CMAX * 4) : "memory");
         n_x = x0; n_a = t0; n_m = t1;
     };
+    // round 6: inside the k-loop a lane's sixteen coefficients (a2, d2 of its channel octet — fixed per launch, only the chunk moves) are loaded ONCE per chunk, in the
+    // chunk's first norm k-tile, and stay in registers for its six pieces: four of the five ds_read_b128 of a norm k-tile were these (DESIGN.md "Measured (round 6)")
+    floatx4 c_a0, c_a1, c_d0, c_d1;
+    auto norm_issue_unit = [&](auto ic, const int pbuf) {
+        constexpr int i = decltype(ic)::value;
+        const int j = wave + 8 * i;
+        n_on = j < PPIECES;
+        n_addr = lds_base + (unsigned)(n_on ? pbuf + j * 1024 : OFF_DUMP + wave * 1024) + (unsigned)lane * 16u;
+        const unsigned ad = n_addr;
+        u32x4 x0;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(x0) : "v"(ad) : "memory");
+        n_x = x0;
+    };
+    auto norm_load_coef = [&]() {
+        const unsigned ta = lds_base + (unsigned)OFF_TAB + (unsigned)n_c0 * 4u;
+        floatx4 t0, t1, t2, t3;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(t0) : "v"(ta) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(t1) : "v"(ta) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(t2) : "v"(ta), "n"(NORM_CMAX * 4) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(t3) : "v"(ta), "n"(NORM_CMAX * 4 + 16) : "memory");
+        c_a0 = t0; c_a1 = t1; c_d0 = t2; c_d1 = t3;
+    };
+    auto norm_ready_k = [&](const bool with_coef) {   // as norm_ready: the unit (and, in a chunk's first norm k-tile, the coefficients) are the oldest LDS reads in flight
+        u32x4 x0 = n_x;
+        if (with_coef) {
+            floatx4 t0 = c_a0, t1 = c_a1, t2 = c_d0, t3 = c_d1;
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x0), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) :: "memory");
+            c_a0 = t0; c_a1 = t1; c_d0 = t2; c_d1 = t3;
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x0) :: "memory");
+        }
+        n_x = x0;
+    };
+    auto norm_pair_k = [&](auto hc, auto qc) {   // norm_pair on the persistent coefficients; the result replaces the unit's dword in place
+        constexpr int hf = decltype(hc)::value, q2 = decltype(qc)::value;
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        Vec16<T> v;
+        v.raw = n_x;
+        constexpr int e = 4 * hf + 2 * q2;
+        const floatx4& ca = hf ? c_a1 : c_a0;
+        const floatx4& cd = hf ? c_d1 : c_d0;
+        const f2 xx = {to_f(v.e[e]), to_f(v.e[e + 1])};
+        const f2 aa = {ca[2 * q2], ca[2 * q2 + 1]}, dd = {cd[2 * q2], cd[2 * q2 + 1]};
+        const f2 u = __builtin_elementwise_fma(xx, aa, dd);
+        f2 t;
+        {
+            float r0 = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-u[0]), GN_L2E, GN_L2E));
+            float r1 = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-u[1]), GN_L2E, GN_L2E));
+            if (!n_silu) { r0 = GN_LN2; r1 = GN_LN2; }
+            t = u * f2{r0, r1};
+        }
+        n_x[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, T2));      // (in place: the pair's own dword — four registers fewer than a separate result)
+    };
+    auto norm_store_k = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const unsigned ad = (n_on && pix[i] >= 0) ? n_addr : lds_base + (unsigned)(OFF_DUMP + wave * 1024) + (unsigned)lane * 16u;
+        const u32x4 ov = n_x;
+        asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(ov) : "memory");
+    };
     auto norm_issue2 = [&]() {   // the coefficients of the unit's last four channels (into the registers the first half is done with)
         const unsigned ta = n_t;
         floatx4 t0, t1;
@@ -388,11 +447,11 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         constexpr bool NRM = NORM && t >= 2 && t <= 7;      // this k-tile normalises piece t - 2 of the next patch (landed since the previous k-tile's wait)
         // the unit and the coefficients of its first four channels are requested FIRST: LDS returns in order, so the wait the compiler puts in front of group 0's
         // first MFMA (for fragments requested after these) covers them
-        if constexpr (NRM) norm_issue(IC6<t - 2>{}, pnext);
+        if constexpr (NRM) { norm_issue_unit(IC6<t - 2>{}, pnext); if constexpr (t == 2) norm_load_coef(); }
         rd(IC6<0>{}, IC6<0>{});
         rd(IC6<1>{}, IC6<1>{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NRM) norm_ready();
+        if constexpr (NRM) norm_ready_k(t == 2);
         rd(IC6<2>{}, IC6<2>{});
         if constexpr (!(CK == 2 && t == NT - 2)) fire_b(bs_dst, kofs);
         __builtin_amdgcn_sched_barrier(0);
@@ -405,7 +464,7 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         } else {
             mma_group(a0[0], a1[0], b0[0], b1[0]);
         }
-        if constexpr (NRM) { norm_pair(IC6<0>{}, IC6<0>{}); interleave4(); }
+        if constexpr (NRM) { norm_pair_k(IC6<0>{}, IC6<0>{}); interleave4(); }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (CK == 1 && t == 0) enter_tile();
         if constexpr (t == 0) {
@@ -437,21 +496,19 @@ __global__ __launch_bounds__(512) void igemm6_kernel(const IgemmParams p, const 
         if constexpr (AN >= 2) fire_a(IC6<AF + 1>{}, pnext);
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[1], a1[1], b0[1], b1[1]);
-        if constexpr (NRM) { norm_pair(IC6<0>{}, IC6<1>{}); interleave4(); }
+        if constexpr (NRM) { norm_pair_k(IC6<0>{}, IC6<1>{}); interleave4(); }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NRM) norm_issue2();                // coefficients of the last four channels: back before the barrier (its lgkmcnt(0))
         // lgkmcnt(0): this wave's reads of the current stage have RETURNED before the barrier lets others overwrite it
         if constexpr (CK == 2 && t == NT - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else if constexpr (CK == 2 && t == NT - 2) wait_vm(2 + AN + npre);   // younger than the previous k-tile's pieces: this k-tile's operand requests + its weight / patch pieces
         else wait_vm(2 + AN);                                               // all but this k-tile's own pieces have landed
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (NRM) norm_mark();
         __builtin_amdgcn_sched_barrier(0);
         mma_group(a0[2], a1[2], b0[2], b1[2]);
-        if constexpr (NRM) { norm_pair(IC6<1>{}, IC6<0>{}); interleave4(); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (NRM) { norm_pair_k(IC6<1>{}, IC6<0>{}); interleave4(); __builtin_amdgcn_sched_barrier(0); }
         mma_group(a0[0], a1[0], b0[0], b1[0]);
-        if constexpr (NRM) { norm_pair(IC6<1>{}, IC6<1>{}); interleave4(); __builtin_amdgcn_sched_barrier(0); norm_store(IC6<t - 2>{}); }
+        if constexpr (NRM) { norm_pair_k(IC6<1>{}, IC6<1>{}); interleave4(); __builtin_amdgcn_sched_barrier(0); norm_store_k(IC6<t - 2>{}); }
         asm volatile("" ::: "memory");
         { const int x = bs_cur; bs_cur = bs_nxt; bs_nxt = bs_dst; bs_dst = x; }
         if constexpr (t == NT - 1) { const int x = pcur; pcur = pnext; pnext = x; }
