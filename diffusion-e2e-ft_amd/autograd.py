@@ -573,7 +573,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, split=False):
 
 class _NormConvSplitFn(torch.autograd.Function):
     """fp32, FROZEN 3x3 / stride-1 / pad-1 convolution of GroupNorm(+SiLU)(x) (+ residual) — the VAE decoder's ResnetBlock2D halves under the fp32 recipe
-    (training/scripts/train_marigold_e2e_ft_depth.sh:15; the VAE carries no gradient: training/train.py:321-323).  Forward: the norm's apply pass writes the f16 split
+    (training/scripts/train_marigold_e2e_ft_depth.sh:15; the VAE carries no gradient: training/train.py:304).  Forward: the norm's apply pass writes the f16 split
     planes (e2eft_groupnorm_fwd_split), the convolution multiplies them on the f16 matrix pipe (e2eft_conv2d_fwd_f32split) — the normalised fp32 tensor is neither
     written nor kept.  Backward: the data gradient is the same convolution call on dY (ops.conv2d_dgrad), then e2eft_groupnorm_bwd_add.  split as _GroupNormFn."""
 

@@ -480,7 +480,8 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
                                  "conv3x3s1n B%d %dx%d %d->%d" % (B, hout, wout, c1, cout), planes=planes, scale=pscale)
             if r is not None:
                 return r
-            x = groupnorm(x, gamma, beta, groups, eps, silu=silu)
+            x = groupnorm(x, gamma, beta, groups, eps, silu=silu)      # (the library declined after all: the two-pass route)
+            d.ldx1 = _nhwc_ld(x)
         else:
             x = groupnorm(x, gamma, beta, groups, eps, silu=silu, x2=x2)      # the norm of the CONCATENATED input; its output is one tensor
             x2 = None
