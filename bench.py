@@ -792,7 +792,8 @@ def main():
             del pipe, out, rgb, img
             # 10 timed steps after 2 warm-up steps each, mean (`value`) and median: VERDICT r4 (3 steps after 1 were too few).  `train_step_fp32_ckpt` is the
             # reference recipe as its script runs it: fp32, `--gradient_checkpointing`, micro-batches of 2 x 16 (train_marigold_e2e_ft_depth.sh:9-11,15)
-            for key, tdt, tsteps, twarm, ckpt in (("train_step", "bf16", 10, 2, False), ("train_step_fp32", "fp32", 10, 2, False), ("train_step_fp32_ckpt", "fp32", 10, 2, True)):
+            # order: the legs at the reference's precision first (fp32: `--mixed_precision "no"`), the bf16-compute extra last
+            for key, tdt, tsteps, twarm, ckpt in (("train_step_fp32", "fp32", 10, 2, False), ("train_step_fp32_ckpt", "fp32", 10, 2, True), ("train_step", "bf16", 10, 2, False)):
                 try:
                     torch.cuda.empty_cache()
                     torch.cuda.reset_peak_memory_stats()
