@@ -288,6 +288,34 @@ egb1, egb2 = rel_err(out[True][1], x64.grad), rel_err(out[False][1], x64.grad)
 print("frozen ResnetBlock2D under autograd: forward %%.3e (unfused fp32 %%.3e), input gradient %%.3e (%%.3e)" %% (eb1, eb2, egb1, egb2), flush=True)
 assert eb1 <= max(1.5 * eb2, 6e-7) and egb1 <= max(1.5 * egb2, 6e-7)
 
+# ---- nothing on the route reads the device back: a ResnetBlock2D forward (norm -> planes -> conv twice: maximum / bound, scales, weight splits all on the
+#      device) is captured in a hipGraph and replayed on new input — any host synchronisation inside would fail the capture
+blk2 = M.ResnetBlock2D(128, 128, None).to(dev)
+with torch.no_grad():
+    for prm in blk2.parameters():
+        prm.copy_(torch.randn(prm.shape, generator=g) * (0.05 if prm.dim() > 1 else 0.3) + (1.0 if prm.dim() == 1 else 0.0))
+xs = nhwc(torch.randn(2, 128, 16, 64, generator=g), torch.float32, dev)
+with torch.no_grad():
+    for _ in range(2):                      # warm-up on a side stream, as torch asks before a capture
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            blk2.nhwc(xs)
+        torch.cuda.current_stream().wait_stream(s_)
+    for prm in blk2.parameters():           # fresh weight versions: the capture has to contain the weight splits as well
+        prm.mul_(1.0)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        yg = blk2.nhwc(xs)
+    assert "f32split" in lib.e2eft_debug_last_kernel().decode()
+    xs.copy_(nhwc(torch.randn(2, 128, 16, 64, generator=g) * 3.0, torch.float32, dev))
+    gr.replay()
+    torch.cuda.synchronize()
+    ye = blk2.nhwc(xs)
+    torch.cuda.synchronize()
+assert torch.equal(yg, ye), (yg - ye).abs().max().item()
+print("hipGraph capture + replay of the split route: bit-equal to the eager launches", flush=True)
+
 # ---- the option switches the route off; shapes the kernel does not take fall back (width not a multiple of 32)
 _lib.set_option(_lib.OPT_F32_SPLIT, 0)
 xd, wd = nhwc(x, torch.float32, dev), pack_conv_weight(w, torch.float32, dev)
