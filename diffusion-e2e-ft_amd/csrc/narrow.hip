@@ -72,17 +72,25 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const NarrowParams 
     for (int c0 = 0; c0 < p.cin; c0 += CH) {
         const int nch = min(CH, p.cin - c0);          // multiple of EPC
         const int ngr = nch / EPC;                    // 16-byte groups per pixel in this chunk
-        __syncthreads();                              // the previous chunk is consumed
-        // ---- stage the halo: 324 pixels x ngr 16-byte groups, zeros outside the image (the convolution's zero padding)
-        for (int i = tid; i < NR_H * NR_H * 8; i += 256) {
-            const int g = i & 7, pix = i >> 3;
-            if (g >= ngr) continue;
+        // ---- stage the halo: 324 pixels x ngr 16-byte groups, zeros outside the image (the convolution's zero padding).  Two passes (round 6, as the MFMA form
+        // below): all eleven loads of a thread in flight, then the stores — the one-pass loop waited out one memory latency per unit
+        constexpr int NIT = (NR_H * NR_H * 8 + 255) / 256;
+        u32x4 raw[NIT];
+        const int g = tid & 7;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pix = (tid + it * 256) >> 3;
             const int hy = pix / NR_H, hx = pix - hy * NR_H;
             const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                v = *reinterpret_cast<const u32x4*>(xb + ((long)iy * p.W + ix) * p.ldx + c0 + g * EPC);
-            *reinterpret_cast<u32x4*>(halo + pix * NR_PIX + g * 16) = v;
+            raw[it] = u32x4{0u, 0u, 0u, 0u};
+            if (pix < NR_H * NR_H && g < ngr && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                raw[it] = *reinterpret_cast<const u32x4*>(xb + ((long)iy * p.W + ix) * p.ldx + c0 + g * EPC);
+        }
+        __syncthreads();                              // the previous chunk is consumed
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pix = (tid + it * 256) >> 3;
+            if (pix < NR_H * NR_H && g < ngr) *reinterpret_cast<u32x4*>(halo + pix * NR_PIX + g * 16) = raw[it];
         }
         __syncthreads();
         // ---- 9 taps x ngr groups x CO outputs, 4 dot2 per (group, output)
@@ -154,37 +162,55 @@ __global__ __launch_bounds__(256, 2) void conv3x3_narrow_mfma_kernel(const Narro
                 const bool ok = wrow && sl * 32 < nch;
                 bf[tap][sl] = ok ? *reinterpret_cast<const u32x4*>(wg + (long)m * p.ldw + (long)tap * p.cin + c0 + sl * 32 + kq * 8) : u32x4{0u, 0u, 0u, 0u};
             }
+        // staging in two passes (round 6): first ALL of this thread's 16-byte units of the chunk are requested (eleven independent loads in flight — the one-pass loop
+        // waited out one HBM latency per unit: 11 x 2 chunks x ~1.5 us was the kernel's 0.8 ms), then they are normalised and stored
+        constexpr int NIT = (NR_H * NR_H * 8 + 255) / 256;      // 11 (the unit's channel group g = tid & 7 is the same in every iteration: 256 % 8 == 0)
+        u32x4 raw[NIT];
+        const int g = tid & 7;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pix = (tid + it * 256) >> 3;
+            const int hy = pix / NR_H, hx = pix - hy * NR_H;
+            const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+            const bool inb = pix < NR_H * NR_H && g < ngr && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            raw[it] = u32x4{0u, 0u, 0u, 0u};
+            if (inb) raw[it] = *reinterpret_cast<const u32x4*>(xb + ((long)iy * p.W + ix) * p.ldx + c0 + g * 8);
+        }
         // fused GroupNorm(+SiLU) of the input: a thread stages the same 8-channel group (tid & 7) of every pixel it handles, so its 24 coefficients
         // are loaded once per chunk; the staged value is what e2eft_groupnorm_fwd would have written (padding stays zero)
         float na[8], nm[8], nb[8];
         const bool nrm = p.nrm_ad != nullptr && (tid & 7) < ngr;
         if (nrm) {
             const int c = c0 + (tid & 7) * 8;
+            // the sixteen (a, mean) floats of channels c .. c + 7 are consecutive, beta's eight values one 16-byte unit: five vector loads in flight instead of 24 scalar ones
+            const floatx4* ad4 = reinterpret_cast<const floatx4*>(p.nrm_ad + ((long)blockIdx.y * p.cin + c) * 2);
+            const floatx4 q0 = ad4[0], q1 = ad4[1], q2 = ad4[2], q3 = ad4[3];
+            Vec16<T> bq;
+            bq.raw = u32x4{0u, 0u, 0u, 0u};
+            if (p.nrm_beta) bq = ld16((const T*)p.nrm_beta + c);
+            const float av[8] = {q0[0], q0[2], q1[0], q1[2], q2[0], q2[2], q3[0], q3[2]};
+            const float mv[8] = {q0[1], q0[3], q1[1], q1[3], q2[1], q2[3], q3[1], q3[3]};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                na[e] = p.nrm_ad[((long)blockIdx.y * p.cin + c + e) * 2];
-                nm[e] = p.nrm_ad[((long)blockIdx.y * p.cin + c + e) * 2 + 1];
-                nb[e] = p.nrm_beta ? to_f(((const T*)p.nrm_beta)[c + e]) : 0.f;
-                gn_fold(na[e], nm[e], nb[e], na[e], nb[e]);      // (a2, d2): gn_apply_kernel's exp2-domain arithmetic (common.h)
+                nm[e] = mv[e];
+                gn_fold(av[e], mv[e], p.nrm_beta ? to_f(bq.e[e]) : 0.f, na[e], nb[e]);      // (a2, d2): gn_apply_kernel's exp2-domain arithmetic (common.h)
             }
         }
         __syncthreads();                              // the previous chunk is consumed
-        for (int i = tid; i < NR_H * NR_H * 8; i += 256) {
-            const int g = i & 7, pix = i >> 3;
-            if (g >= ngr) continue;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pix = (tid + it * 256) >> 3;
+            if (pix >= NR_H * NR_H || g >= ngr) continue;
             const int hy = pix / NR_H, hx = pix - hy * NR_H;
             const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
             Vec16<T> v;
-            v.raw = u32x4{0u, 0u, 0u, 0u};
-            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-                v.raw = *reinterpret_cast<const u32x4*>(xb + ((long)iy * p.W + ix) * p.ldx + c0 + g * 8);
-                if (nrm) {
+            v.raw = raw[it];
+            if (nrm && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float t = gn_act_u(__builtin_fmaf(to_f(v.e[e]), na[e], nb[e]), p.nrm_silu != 0);
-                        asm("" : "+v"(t));      // the fp32 product exists before it is rounded to T, as in gn_apply_kernel (mul, then cvt_pk): without this the
-                        v.e[e] = from_f<T>(t);  // compiler emits v_fma_mixlo_f16 (u * r rounded ONCE to fp16) and the two routes differ in the last bit
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    float t = gn_act_u(__builtin_fmaf(to_f(v.e[e]), na[e], nb[e]), p.nrm_silu != 0);
+                    asm("" : "+v"(t));      // the fp32 product exists before it is rounded to T, as in gn_apply_kernel (mul, then cvt_pk): without this the
+                    v.e[e] = from_f<T>(t);  // compiler emits v_fma_mixlo_f16 (u * r rounded ONCE to fp16) and the two routes differ in the last bit
                 }
             }
             *reinterpret_cast<u32x4*>(halo + pix * NR_PIX + g * 16) = v.raw;
