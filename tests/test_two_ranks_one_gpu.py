@@ -54,7 +54,13 @@ def _worker(rank, world, port, q, backend="gloo", ckpt=False):
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
-        from diffusion_e2e_ft_amd import training
+        from diffusion_e2e_ft_amd import training, _lib
+        # the suite's A/B variants (conftest.dev) are process-wide options of the PARENT: a rank must route its launches the same way, or the comparison below mixes
+        # kernel routes (under E2EFT_TEST_PERSISTENT_GRID=8 the parent's small fp32 launches take the persistent / f16-split kernels: 3.6e-5 against the 1e-5 bar)
+        if "E2EFT_TEST_PERSISTENT_GRID" in os.environ:
+            _lib.set_option(_lib.OPT_PERSISTENT_GRID, int(os.environ["E2EFT_TEST_PERSISTENT_GRID"]))
+        if os.environ.get("E2EFT_TEST_PERSISTENT") == "0":
+            _lib.set_option(_lib.OPT_PERSISTENT, 0)
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         dist.init_process_group(backend, rank=rank, world_size=world)
