@@ -202,7 +202,7 @@ extern "C" int e2eft_conv2d_fwd_f32split(const E2eftConvDesc* d, const void* pla
 
 // ---- nn.Linear in fp32 from split planes: out[m][n] = alpha / (s s_w) * sum_k a[m][k] w[n][k] + bias[n] + residual[m][n] on igemm5's GEMM mode.  `d`: dtype E2EFT_F32, k = the
 // fp32 operand's columns (% 64 == 0), lda = row stride of the PLANES in f16 elements (>= 2 k), ldw = row length of w_split [n][w0 (k) | w1 (k) | w0 (k)] (>= 3 k), ldo / ldr
-// in fp32 elements, one problem (nzo = nzi = 1), bias along n.  a ragged last 256-row tile is masked, launches of a few tiles are taken: ask e2eft_gemm_f32split_supported first.
+// in fp32 elements, one problem (nzo = nzi = 1), bias along n.  m > 256 (a ragged last 256-row tile is masked): ask e2eft_gemm_f32split_supported first.
 static bool f32split_gemm_params(const E2eftGemmDesc* d, IgemmParams& p) {
     if (!d || d->dtype != E2EFT_F32 || !option(E2EFT_OPT_F32_SPLIT) || d->nzo != 1 || d->nzi != 1 || d->bias_along_m) return false;
     if (d->m <= 0 || d->n <= 0 || d->k <= 0 || d->k % 64 != 0 || d->lda < 2 * d->k || d->lda % 8 != 0 || d->ldw < 3 * d->k || d->ldw % 8 != 0 || d->ldo < d->n) return false;

@@ -531,7 +531,7 @@ static int persistent_plan(int dtype, int mode, IgemmParams& p, int nz, long& to
                           (mode == 0 && p.K != 3 * p.split_c))) return -1;
     // whole 256-row tiles — except the fp32-split launches (F32O): their row table / A offsets zero the rows beyond M and epilogue_f32 masks them (the 18^2 UNet level
     // of the 576^2 recipe is 20.25 tiles per launch)
-    if ((p.M % BM != 0 && !(p.split_c > 0 && p.out_seg == 0)) || p.K % 64 != 0 || p.K / 64 < 3) return -1;
+    if ((p.M % BM != 0 && !(p.split_c > 0 && p.out_seg == 0 && p.M > BM)) || p.K % 64 != 0 || p.K / 64 < 3) return -1;
     if (p.N % 8 != 0 || p.ldo % 8 != 0 || (((uintptr_t)p.out) & 15) != 0) return -1;
     if (p.residual && (p.ldr % 8 != 0 || (((uintptr_t)p.residual) & 15) != 0)) return -1;
     if (p.bias && (((uintptr_t)p.bias) & 15) != 0) return -1;
@@ -551,10 +551,7 @@ static int persistent_plan(int dtype, int mode, IgemmParams& p, int nz, long& to
     if (gopt >= 8 && gopt < g_pers_cus) g_pers_cus = gopt;
     const int mtiles = cdiv(p.M, BM), ntiles = cdiv(p.N, BN);
     const long total = (long)mtiles * ntiles * nz;
-    // at least half a round of tiles (E2EFT_OPT_PERSISTENT_MIN_QROUNDS) — except the fp32-split launches: what they would fall back to is the fp32 matrix instruction at a
-    // sixteenth of the rate, so even the 60 tiles of a 9 x 9 UNet level (or the ten of a 16-row time-embedding projection) finish sooner here
-    const bool few_ok = p.split_c > 0 && total >= 2;
-    if ((!few_ok && 4 * total < (long)option(E2EFT_OPT_PERSISTENT_MIN_QROUNDS) * g_pers_cus) || total > 2000000000L || mtiles >= (1 << 22)) return -1;   // (tile / row splits use a float reciprocal: quotients below 2^22)
+    if (4 * total < (long)option(E2EFT_OPT_PERSISTENT_MIN_QROUNDS) * g_pers_cus || total > 2000000000L || mtiles >= (1 << 22)) return -1;   // (tile / row splits use a float reciprocal: quotients below 2^22)
     p.mtiles = mtiles;
     p.ntiles = ntiles;
     if (p.gn_partial) {   // statistics need whole tiles inside one image; otherwise igemm2 may still be able to emit them (128-row slabs): fall through

@@ -471,7 +471,7 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
         narrow_ok = cout > 4 or (rowadd is None and residual is None and not want)
         if NORM_FUSION_ENABLED and x2 is None and not sk and narrow_ok and lib.e2eft_conv2d_fwd_normed_supported(C.byref(d)) == 1:
             ws, coeff = groupnorm_stats(x, gamma, groups, eps)     # (a, mean) pairs; the apply pass is the convolution's operand fetch
-        elif (x.dtype == torch.float32 and x2 is None and up_to is None and rowadd is None and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1)
+        elif (x.dtype == torch.float32 and x2 is None and not sk and up_to is None and rowadd is None and (kh, kw, stride) == (3, 3, 1) and tuple(pad) == (1, 1, 1, 1)
               and (alpha == 1.0 or bias is None)
               and w_packed.shape[1] == 9 * c1 and f32split_shape_ok(B, H, W, c1, cout)):
             # fp32: the norm's apply pass writes the f16 split planes the convolution reads (csrc/f32split.hip) — no fp32 intermediate, no maximum pass
@@ -487,8 +487,7 @@ def conv2d(x, w_packed, bias, cout, kh, kw, stride=1, pad=(0, 0, 0, 0), x2=None,
             x2 = None
             d.c1, d.ldx1, d.c2, d.ldx2 = x.shape[3], _nhwc_ld(x), 0, 0
     label = _label or "conv%dx%ds%d%s%s B%d %dx%d %d->%d" % (kh, kw, stride, "u" if up_to else "", "n" if coeff is not None else "", B, hout, wout, d.c1 + d.c2, cout)
-    # (before the split-K plan of small fp32 problems: those run the fp32 instruction, a few tiles on the f16 pipe finish sooner)
-    if (F32_SPLIT_ENABLED and x.dtype == torch.float32 and coeff is None and up_to is None and rowadd is None
+    if (F32_SPLIT_ENABLED and x.dtype == torch.float32 and coeff is None and not sk and up_to is None and rowadd is None
             and (alpha == 1.0 or bias is None)
             and (d.c1 + d.c2) % 64 == 0 and w_packed.shape[1] == kh * kw * (d.c1 + d.c2)):
         r = _conv2d_f32split(x, w_packed, bias, cout, residual, alpha, out, want, label, geom=(kh, kw, stride, tuple(pad)), x2=x2)
@@ -542,7 +541,7 @@ def gemm(a, w, bias=None, residual=None, out=None, alpha=1.0, bias_along_m=False
     if residual is not None:
         assert tuple(residual.shape) == (M, N) and residual.dtype == a.dtype
     want = gn_rows_per_image > 0 and GN_STATS_ENABLED and N % 8 == 0 and M % gn_rows_per_image == 0 and not bias_along_m
-    if (F32_SPLIT_ENABLED and a.dtype == torch.float32 and not want and not bias_along_m and (alpha == 1.0 or bias is None) and K % 64 == 0 and N % 8 == 0 and w.is_contiguous()
+    if (F32_SPLIT_ENABLED and a.dtype == torch.float32 and not want and not bias_along_m and (alpha == 1.0 or bias is None) and K % 64 == 0 and M > 256 and N % 8 == 0 and w.is_contiguous()
             and a.data_ptr() % 16 == 0 and d.lda % 4 == 0 and out.data_ptr() % 16 == 0 and (residual is None or residual.data_ptr() % 16 == 0)
             and (bias is None or bias.data_ptr() % 16 == 0)):
         # fp32 nn.Linear of whole 256-row tiles: two-term f16 split planes on the f16 matrix pipe (csrc/f32split.hip; igemm5's GEMM mode)

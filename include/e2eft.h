@@ -187,7 +187,7 @@ int e2eft_conv2d_fwd_f32split(const E2eftConvDesc* d, const void* planes, const 
                               const float* residual, float* out, float* gn_partial, size_t gn_partial_bytes, int32_t* slab_rows, void* stream);
 /* nn.Linear in fp32 the same way (igemm5's GEMM mode): out[m][n] = alpha / (s s_w) * sum_k a[m][k] w[n][k] + bias[n] + residual[m][n].  `d`: dtype E2EFT_F32, k = columns of the
  * fp32 operand (% 64 == 0), lda = row stride of its planes [a0 (k) | a1 (k)] in f16 elements (e2eft_f32_split2 with pixels = m, c = k), ldw = row length of
- * w_split [n][w0 (k) | w1 (k) | w0 (k)], ldo / ldr in fp32 elements, one problem (nzo = nzi = 1); a ragged last 256-row tile is masked and launches of a few tiles are taken (the same holds for e2eft_conv2d_fwd_f32split on igemm5).  Ask e2eft_gemm_f32split_supported first. */
+ * w_split [n][w0 (k) | w1 (k) | w0 (k)], ldo / ldr in fp32 elements, one problem (nzo = nzi = 1), m > 256 (a ragged last 256-row tile is masked; the same holds for e2eft_conv2d_fwd_f32split on igemm5).  Ask e2eft_gemm_f32split_supported first. */
 /* e2eft_upconv2x_fwd in fp32 the same way: `d` as that call's (dtype E2EFT_F32) with ldx1 = the planes' pixel stride in f16 elements; w_phase_split: f16
  * [4][cout][2][2][w0 (c1) | w1 (c1) | w0 (c1)] — the fp32 phase weights split as ONE tensor (one s_w).  c1 % 64 == 0, win % 16 == 0, hin * win % 256 == 0, alpha 1. */
 int e2eft_upconv2x_fwd_f32split_supported(const E2eftConvDesc* d);

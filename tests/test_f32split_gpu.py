@@ -64,7 +64,6 @@ cases = [
     (2, 32, 32, 256, 128, True, False, False, (1, 1, 1, 0), "igemm5"),     # a 1x1 shortcut convolution (K = 3 C: three k-tiles per 64 channels)
     (5, 18, 18, 128, 128, True, True, False, (3, 3, 1, 1), "igemm5"),      # 1620 output pixels = 6.33 tiles: the ragged last tile's rows beyond M are zeroed on the way in and masked on the way out
     (10, 9, 9, 192, 64, False, False, True, (3, 3, 1, 1), "igemm5"),       # 810 pixels: 3.16 tiles, 81 pixels per image
-    (2, 9, 9, 128, 256, True, False, False, (3, 3, 1, 1), "igemm5"),       # 162 pixels: ONE ragged tile per N tile — few tiles are taken too (the alternative is the fp32 instruction)
 ]
 for (B, H, W, Cc, Co, hb, rs, wide, (kh, kw, st, pd), kern) in cases:
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cc + Co + W + kh)
@@ -143,7 +142,7 @@ print("two sources: forward %%.3e (fp32 MFMA %%.3e), weight gradient %%.3e (%%.3
 assert e1 <= max(1.5 * e2, 4e-7) and w1 <= max(1.5 * w2, 4e-7) and s1 <= max(1.5 * s2, 6e-7), (e1, e2, w1, w2, s1, s2)
 
 # ---- nn.Linear (e2eft_gemm_f32split, igemm5's GEMM mode): x W^T + b + residual against float64, beside the fp32 matrix instruction
-for (Mr, N, K, hb, rs) in [(1024, 320, 320, True, True), (2048, 1280, 64, False, False), (512, 640, 2560, True, False), (1100, 320, 320, True, True), (1296, 1280, 1280, False, True), (16, 1280, 1280, True, False)]:
+for (Mr, N, K, hb, rs) in [(1024, 320, 320, True, True), (2048, 1280, 64, False, False), (512, 640, 2560, True, False), (1100, 320, 320, True, True), (1296, 1280, 1280, False, True)]:
     g = torch.Generator().manual_seed(Mr + N + K)
     a = torch.randn(Mr, K, generator=g) * torch.exp(torch.randn(Mr, K, generator=g))
     w = torch.randn(N, K, generator=g) / K ** 0.5
