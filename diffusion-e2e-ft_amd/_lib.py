@@ -71,6 +71,7 @@ SIGNATURES = {
     "e2eft_upconv2x_fwd_supported": (_I, [C.POINTER(ConvDesc)]),
     "e2eft_upconv2x_fwd": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int32), _P]),
     "e2eft_groupnorm_fwd_split": (_I, [C.POINTER(GroupNormDesc), _P, _P, _P, _P, _I, _P, _P, _I, _P, _Z, _P]),
+    "e2eft_f32_split_weight": (_I, [_P, _L, _I, _P, _P, _P]),
     "e2eft_f32_split2_cat": (_I, [_P, _I, _I, _P, _I, _I, _L, _P, _I, _P, _P]),
     "e2eft_f32_split2": (_I, [_P, _L, _I, _I, _P, _I, _P, _P]),
     "e2eft_conv2d_fwd_f32split_supported": (_I, [C.POINTER(ConvDesc)]),

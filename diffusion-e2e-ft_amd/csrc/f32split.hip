@@ -59,7 +59,8 @@ __device__ __forceinline__ void split_scale(const unsigned amax_bits, float& s, 
 
 // one thread: eight channels of one pixel -> one 16-byte unit of each plane
 // (coff, ctot: this source's first column inside a plane and the plane's width — two sources side by side are the split of their channel concatenation)
-__global__ __launch_bounds__(256) void split2_f16_kernel(long pixels, int c, int ldx, int ldp, int coff, int ctot, const float* __restrict__ x, f16* __restrict__ planes,
+// third != 0: the first plane is written a second time behind the second one — the [w0 | w1 | w0] rows of a split WEIGHT (e2eft_f32_split_weight)
+__global__ __launch_bounds__(256) void split2_f16_kernel(long pixels, int c, int ldx, int ldp, int coff, int ctot, int third, const float* __restrict__ x, f16* __restrict__ planes,
                                                          const unsigned* __restrict__ amax_bits, float* __restrict__ scale_out) {
     float s, inv;
     split_scale(*amax_bits, s, inv);
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void split2_f16_kernel(long pixels, int c, int
         }
         st16(planes + pix * ldp + coff + ch, p0);
         st16(planes + pix * ldp + ctot + coff + ch, p1);
+        if (third) st16(planes + pix * ldp + 2 * ctot + coff + ch, p0);
     }
 }
 
@@ -128,9 +130,27 @@ extern "C" int e2eft_f32_split2(const float* x, int64_t pixels, int32_t c, int32
     const long nbm = nb > 1024 ? 1024 : nb;          // the reduction: few atomics
     hipLaunchKernelGGL(absmax_f32_kernel, dim3((unsigned)nbm), dim3(256), 0, s, (long)pixels, c, ldx, x, reinterpret_cast<unsigned*>(scale));
     if (nb > 65536) nb = 65536;
-    hipLaunchKernelGGL(split2_f16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (long)pixels, c, ldx, ldp, 0, c, x, (f16*)planes, reinterpret_cast<const unsigned*>(scale), scale);
+    hipLaunchKernelGGL(split2_f16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (long)pixels, c, ldx, ldp, 0, c, 0, x, (f16*)planes, reinterpret_cast<const unsigned*>(scale), scale);
     tag_kernel("split2_f16_kernel");
     return check_launch("f32_split2");
+}
+
+// a packed fp32 weight [rows = cout * taps][c] -> the operand e2eft_conv2d_fwd_f32split / e2eft_gemm_f32split multiply with: f16 [rows][w0 (c) | w1 (c) | w0 (c)] with
+// w s_w = w0 + w1, scale[1] = s_w, scale[2] = 1 / s_w (the consumers' w_inv_scale = scale + 2).  Two launches on the device: trainable weights are split once per
+// optimizer step and parameter, several hundred times per step — as a dozen tensor-library calls each that was the largest host-side cost of the fp32 step.
+extern "C" int e2eft_f32_split_weight(const float* w, int64_t rows, int32_t c, void* w_split, float* scale, void* stream) {
+    E2EFT_REQUIRE(w && w_split && scale && rows > 0, "f32_split_weight: null pointer / empty weight");
+    E2EFT_REQUIRE(c > 0 && c % 8 == 0, "f32_split_weight: c=%d must be a multiple of 8", c);
+    E2EFT_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)scale & 3) == 0, "f32_split_weight: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(scale, 0, sizeof(float), s) != hipSuccess) return fail(E2EFT_ERR_LAUNCH, "f32_split_weight: memset failed");
+    const long units = rows * (c / 8);
+    long nb = (units + 255) / 256;
+    const long nbm = nb > 1024 ? 1024 : nb;
+    hipLaunchKernelGGL(absmax_f32_kernel, dim3((unsigned)nbm), dim3(256), 0, s, (long)rows, c, c, w, reinterpret_cast<unsigned*>(scale));
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(split2_f16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (long)rows, c, c, 3 * c, 0, c, 1, w, (f16*)w_split, reinterpret_cast<const unsigned*>(scale), scale);
+    return check_launch("f32_split_weight");
 }
 
 // the channel concatenation [x1 (c1) | x2 (c2)] of two fp32 tensors as ONE pair of planes under ONE scale (the two-source convolutions of the UNet's up blocks:
@@ -153,7 +173,7 @@ extern "C" int e2eft_f32_split2_cat(const float* x1, int32_t c1, int32_t ldx1, c
     for (int i = 0; i < 2; ++i) {
         long nb = (pixels * (cs[i] / 8) + 255) / 256;
         if (nb > 65536) nb = 65536;
-        hipLaunchKernelGGL(split2_f16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (long)pixels, cs[i], lds[i], ldp, i ? c1 : 0, c1 + c2, xs[i], (f16*)planes,
+        hipLaunchKernelGGL(split2_f16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (long)pixels, cs[i], lds[i], ldp, i ? c1 : 0, c1 + c2, 0, xs[i], (f16*)planes,
                            reinterpret_cast<const unsigned*>(scale), scale);
     }
     tag_kernel("split2_f16_kernel");

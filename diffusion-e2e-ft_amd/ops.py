@@ -286,18 +286,13 @@ def f32_split_weight(w_packed, taps, c):
     ent = getattr(w_packed, "_e2eft_split", None)
     if ent is not None and ent[0] == w_packed._version:
         return ent[1], ent[2]
-    cout = w_packed.numel() // (taps * c)          # (a [4, cout, taps * c] stack of phase weights splits as one tensor: one scale)
-    assert w_packed.dtype == torch.float32 and w_packed.shape[-1] == taps * c and w_packed.is_contiguous()
-    with torch.no_grad():
-        wv = w_packed.detach().view(cout, taps, c)
-        ex = torch.frexp(wv.abs().max())[1]                  # max = m * 2^ex, m in [0.5, 1)  (0 -> ex = 0: any scale serves a zero weight)
-        k = (15 - ex).clamp(-100, 100)
-        one = torch.ones((), dtype=torch.float32, device=w_packed.device)
-        ws = wv * torch.ldexp(one, k)
-        w0 = ws.to(torch.float16)
-        w1 = (ws - w0.float()).to(torch.float16)
-        wsp = torch.cat([w0, w1, w0], dim=2).reshape(cout, taps * 3 * c).contiguous()
-        inv = torch.ldexp(one, -k).reshape(1).contiguous()
+    rows = w_packed.numel() // c                   # cout * taps (a [4, cout, taps * c] stack of phase weights splits as one tensor: one scale)
+    assert w_packed.dtype == torch.float32 and w_packed.shape[-1] == taps * c and w_packed.is_contiguous() and c % 8 == 0
+    src = w_packed.detach() if w_packed.data_ptr() % 16 == 0 else w_packed.detach().clone()      # (a slice of a flat buffer may start off a 16-byte boundary)
+    wsp = torch.empty((rows // taps, taps * 3 * c), dtype=torch.float16, device=w_packed.device)
+    scale = torch.empty(4, dtype=torch.float32, device=w_packed.device)
+    check(_lib.load().e2eft_f32_split_weight(_ptr(src), rows, c, _ptr(wsp), _ptr(scale), _stream()))      # (two launches; as tensor-library calls this was a dozen per weight)
+    inv = scale[2:3]
     w_packed._e2eft_split = (w_packed._version, wsp, inv)
     return wsp, inv
 

@@ -179,6 +179,9 @@ int e2eft_upconv2x_fwd(const E2eftConvDesc* d, const void* x, const void* w_phas
  *     the fp32 output).  Ask e2eft_conv2d_fwd_f32split_supported first (pure host arithmetic; E2EFT_OPT_F32_SPLIT = 0 makes it answer 0); E2EFT_ERR_UNSUPPORTED otherwise.
  *     The data gradient of such a convolution is the same call on dY with the flipped, transposed weights (e2eft_conv2d_dgrad's w_dgrad) split the same way. */
 int e2eft_f32_split2(const float* x, int64_t pixels, int32_t c, int32_t ldx, void* planes, int32_t ldp, float* scale, void* stream);
+/* a packed fp32 weight [rows = cout * taps][c] (16-byte aligned, c % 8 == 0) as the multiplied operand of the calls below: f16 [rows][w0 (c) | w1 (c) | w0 (c)] with
+ * w s_w = w0 + w1; scale: three device floats, on return scale[1] = s_w, scale[2] = 1 / s_w (pass scale + 2 as w_inv_scale).  Two launches, no host read. */
+int e2eft_f32_split_weight(const float* w, int64_t rows, int32_t c, void* w_split, float* scale, void* stream);
 /* the channel concatenation [x1 (c1) | x2 (c2)] as one pair of planes under one scale: planes [pixels][x1_0 | x2_0 | x1_1 | x2_1] (the UNet's two-source convolutions) */
 int e2eft_f32_split2_cat(const float* x1, int32_t c1, int32_t ldx1, const float* x2, int32_t c2, int32_t ldx2, int64_t pixels, void* planes, int32_t ldp,
                          float* scale, void* stream);
