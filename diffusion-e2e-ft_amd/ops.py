@@ -1059,41 +1059,19 @@ def conv2d_wgrad(dy, x, x2, cout, kh, kw, stride, pad, alpha, out=None):
         dyp, sdy = f32_split2(dy, keep=True)          # (the data-gradient convolution of the same dY has usually split it already: autograd._Conv2dFn.backward)
         xp, sx = f32_split2(x, x2=x2)                 # (two sources: the planes of their concatenation — the 16-bit kernel then sees ONE source of c1 + c2 channels)
         c0, c1 = dy.shape[3], cin_all
-        pairs = ((dyp[..., :c0], xp[..., :c1]), (dyp[..., :c0], xp[..., c1:]), (dyp[..., c0:], xp[..., :c1]))
-        lib = _lib.load()
-        Bx = x.shape[0]
-        lddy16 = 2 * c0
-        per_img16 = max(dy.shape[1] * dy.shape[2] * lddy16, x.shape[1] * x.shape[2] * 2 * c1) * 2
         r = None
-        if per_img16 * Bx < 0xFFFF0000 and dy.shape[1] * dy.shape[2] * Bx < (1 << 24):
-            # one descriptor, one partial buffer for the three launches, ONE reduction (the launches of a step's several hundred weight gradients are host time on a
-            # step that is launch-bound in places: three reductions, two additions and their allocations per gradient were most of this route's host cost)
-            d = _conv_desc(pairs[0][1], None, cout, kh, kw, stride, pad, None, alpha)
-            nbytes = lib.e2eft_conv2d_wgrad_workspace_bytes(C.byref(d), lddy16)
-            if nbytes > 0:
-                N = kh * kw * c1
-                big = torch.empty(3 * (nbytes // 4), dtype=torch.float32, device=dy.device)
-                ns = C.c_int32(0)
-                P = d.batch * d.hout * d.wout
-                for i, (a_, b_) in enumerate(pairs):
-                    with _timed("wgrad", 2.0 * P * cout * N, (P * (cout + c1)) * 2, label="wgrad %dx%ds%d P%d %d->%d" % (kh, kw, stride, P, c1, cout)):
-                        check(lib.e2eft_conv2d_wgrad(C.byref(d), _ptr(a_), lddy16, _ptr(b_), _ptr(None), C.c_void_p(big.data_ptr() + i * nbytes), nbytes, C.byref(ns), _stream()))
-                nsv = ns.value
-                allp = torch.cat([big[i * (nbytes // 4): i * (nbytes // 4) + nsv * cout * N].view(nsv, cout * N) for i in range(3)], dim=0) if nsv * cout * N * 4 != nbytes \
-                    else big.view(3 * nsv, cout * N)
-                r = colsum(allp, groups=1, out=None if out is None else out.view(1, -1)).view(cout, N)
-        else:
-            for (a_, b_) in pairs:           # (tensors past the kernel's 32-bit descriptor: the batch-cutting loop below, once per pair)
-                t = conv2d_wgrad(a_, b_, None, cout, kh, kw, stride, pad, alpha)
-                if t is None:
-                    r = None
-                    break
-                r = t if r is None else r.add_(t)
-            if r is not None and out is not None:
-                out.view(r.shape).copy_(r)
-                r = out.view(r.shape)
+        for (a_, b_) in ((dyp[..., :c0], xp[..., :c1]), (dyp[..., :c0], xp[..., c1:]), (dyp[..., c0:], xp[..., :c1])):
+            t = conv2d_wgrad(a_, b_, None, cout, kh, kw, stride, pad, alpha)
+            if t is None:
+                r = None
+                break
+            r = t if r is None else r.add_(t)
         if r is not None:
-            return r.mul_(sdy[2] * sx[2])
+            r = r.mul_(sdy[2] * sx[2])
+            if out is not None:
+                out.view(r.shape).copy_(r)
+                return out.view(r.shape)
+            return r
     B = x.shape[0]
     lddy = _nhwc_ld(dy)
     es = dy.element_size()
