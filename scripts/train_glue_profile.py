@@ -1,6 +1,6 @@
 """Which host code launches the ATen / runtime-copy kernels of a training step: torch.profiler with Python stacks over one E2E-FT step (full-size UNet + VAE,
 any batch), grouped by (aten op, innermost frames inside this package; ops the autograd engine issues itself show `_engine_run_backward`).
-Usage: python scripts/train_glue_profile.py [B] [res] [stacks|methods]   (methods: counters on the torch.Tensor methods instead of the profiler)"""
+Usage: python scripts/train_glue_profile.py [B] [res] [stacks|methods] [bf16|fp32]   (methods: counters on the torch.Tensor methods instead of the profiler)"""
 import collections
 import os
 import sys
@@ -18,7 +18,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 MODE = sys.argv[3] if len(sys.argv) > 3 else "stacks"
 dev = torch.device("cuda", 0)
-cdt = torch.bfloat16
+cdt = torch.float32 if (len(sys.argv) > 4 and sys.argv[4] == "fp32") else torch.bfloat16
 with torch.device(dev):
     unet = UNet2DConditionModel(in_channels=8)
     vae = AutoencoderKL().to(cdt)
